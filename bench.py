@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- measures BASELINE.json's metric on MI355X and prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan]
+
+workload `step` (default): one classify_mamba training step (frozen generator fwd + head fwd/bwd + per-parameter
+clip + Adam) on a synthetic batch of 8 volumes of 96^3 per GPU (BASELINE config 5's per-GPU share == config 3 + bwd).
+workload `scan`: BASELINE config 2, the fused selective scan alone (L=4096, ED=1024, N=16, bf16), fwd+bwd.
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU (RCCL).  The timed region is
+bracketed by barrier + synchronize on both sides; the reported time is the max over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(ROOT, "gfe-mamba_amd")
+for p in (ROOT, SRC):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def time_region(fn, iters):
+    """Average duration (ms) of fn() measured with HIP events on the stream the kernels are launched on."""
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+class ScanWorkload:
+    """BASELINE config 2: u, delta, z ~ N(0,1) (delta*0.1), dt-bias from the reference init
+    (mamba.py:150-155), A[e,n] = -(n+1) (mamba.py:160-161,232), B, C ~ N(0,1), D = 1; bf16 I/O, f32 state."""
+    name = "selective_scan fwd+bwd, L=4096 ED=1024 N=16 bf16 (config 2)"
+
+    def __init__(self, batch, dtype=torch.bfloat16, L=4096, ED=1024, N=16):
+        self.B, self.L, self.ED, self.N, self.dtype = batch, L, ED, N, dtype
+        g = torch.Generator().manual_seed(0)
+        dev = "cuda"
+        lp = lambda t: t.to(dtype).to(dev)
+        self.u = lp(torch.randn(batch, L, ED, generator=g)).requires_grad_(True)
+        self.draw = lp(torch.randn(batch, L, ED, generator=g) * 0.1).requires_grad_(True)
+        dt = torch.exp(torch.rand(ED, generator=g) * (torch.log(torch.tensor(0.1)) - torch.log(torch.tensor(0.001)))
+                       + torch.log(torch.tensor(0.001))).clamp(min=1e-4)
+        self.bias = (dt + torch.log(-torch.expm1(-dt))).to(dev).requires_grad_(True)
+        self.A = (-(torch.arange(1, N + 1, dtype=torch.float32)).repeat(ED, 1)).to(dev).requires_grad_(True)
+        self.Bm = lp(torch.randn(batch, L, N, generator=g)).requires_grad_(True)
+        self.Cm = lp(torch.randn(batch, L, N, generator=g)).requires_grad_(True)
+        self.D = torch.ones(ED, device=dev).requires_grad_(True)
+        self.z = lp(torch.randn(batch, L, ED, generator=g)).requires_grad_(True)
+        self.dy = lp(torch.randn(batch, L, ED, generator=g))
+        self.units = batch * L          # tokens per step
+        s = 2 if dtype == torch.bfloat16 else 4
+        # algorithmic bytes: fwd = u,delta,z read + y write + B,C read + A,D,bias; bwd = 7 streams + 4 B/C streams
+        self.bytes_fwd = 4 * batch * L * ED * s + 2 * batch * L * N * s + (ED * N + 2 * ED) * 4
+        self.bytes_bwd = 7 * batch * L * ED * s + 4 * batch * L * N * s + (2 * ED * N + 4 * ED) * 4
+
+    def fwd(self):
+        from gfe_hip.scan_ops import selective_scan_tm
+        self.y = selective_scan_tm(self.u, self.draw, self.A, self.Bm, self.Cm, self.D, z=self.z, delta_bias=self.bias,
+                                   delta_softplus=True)
+        return self.y
+
+    def step(self):
+        y = self.fwd()
+        for t in (self.u, self.draw, self.A, self.Bm, self.Cm, self.D, self.z, self.bias):
+            t.grad = None
+        y.backward(self.dy)
+
+    def roofline(self, iters=20):
+        with torch.no_grad():
+            self.fwd()
+            t_f = time_region(lambda: self.fwd(), iters)
+        t_s = time_region(self.step, iters)
+        t_b = max(t_s - t_f, 1e-6)
+        gbs = (self.bytes_fwd + self.bytes_bwd) / (t_s * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": "sscan_fwd+sscan_bwd (fused selective scan)",
+                "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
+                "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),
+                "algorithmic_bytes": self.bytes_fwd + self.bytes_bwd}
+
+    def cpu_baseline(self):
+        """oracle/scan_ref.c (plain C port of mamba.py:288-318), 1 core, forward only, on a bounded sample:
+        B=1, L=4096, 256 of the 1024 channels."""
+        from oracle import c_oracle
+        ch = 256
+        f = lambda t: t.detach()[:1, :, :ch].float().cpu().numpy() if t.dim() == 3 and t.shape[-1] == self.ED else t.detach()[:1].float().cpu().numpy()
+        t0 = time.perf_counter()
+        c_oracle.selective_scan(f(self.u), f(self.draw), self.A.detach()[:ch].cpu().numpy(), f(self.Bm), f(self.Cm),
+                                self.D.detach()[:ch].cpu().numpy(), z=f(self.z), bias=self.bias.detach()[:ch].cpu().numpy(), softplus=True)
+        dt = time.perf_counter() - t0
+        tok_s = self.L / (dt * self.ED / ch)
+        return {"value": round(tok_s, 1), "unit": "tokens/s (forward only)", "cores": 1, "kind": "port",
+                "sample": f"oracle/scan_ref.c, B=1 L=4096, {ch}/{self.ED} channels, forward only, scaled to ED={self.ED}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan"])
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (volumes for `step`, sequences for `scan`)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n_gpus = world
+
+    if a.workload == "scan":
+        wl = ScanWorkload(a.batch)
+        steps, warmup = a.steps or 50, a.warmup if a.warmup is not None else 10
+        metric, unit, dtype = "selective-scan tokens/sec (L=4096 ED=1024 N=16 bf16) fwd+bwd", "tokens/s", "bf16"
+        cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
+    else:
+        from gfe_hip.step_bench import StepWorkload
+        wl = StepWorkload(a.batch, world=world, rank=rank)
+        steps, warmup = a.steps or 10, a.warmup if a.warmup is not None else 3
+        metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
+        cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
+               "parallelism": f"dp{n_gpus}"}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+
+    roof = wl.roofline()
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
+        cpu = wl.cpu_baseline()
+    if rank == 0:
+        ms = el / steps * 1e3
+        out = {"metric": metric, "value": round(wl.units * n_gpus / (el / steps), 3), "unit": unit, "n_gpus": n_gpus,
+               "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
+        extra = getattr(wl, "extra", None)
+        if extra:
+            out["extra"] = extra() if callable(extra) else extra
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

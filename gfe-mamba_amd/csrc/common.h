@@ -1,0 +1,77 @@
+// Shared device/host helpers for the gfx950 kernels behind the C-ABI in include/gfe_hip.h.
+// gfx950 (MI355X / CDNA4) only: wave = 64 lanes, no other targets, no compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gfe_hip.h"
+
+#define GFE_WAVE 64
+
+// ---- error plumbing: entry points never throw, never sync, never allocate -------------------
+#define GFE_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
+static inline int gfe_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GFE_OK : GFE_ERR_HIP;
+}
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+typedef uint16_t bf16_t;   // raw storage; arithmetic is always f32
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+// plain cast => v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct IO<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ---- math --------------------------------------------------------------------------------------
+#define GFE_LOG2E 1.4426950408889634f
+#define GFE_LN2   0.6931471805599453f
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * GFE_LOG2E); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+// torch.nn.functional.softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); scratch must hold 16 floats; result in all threads
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

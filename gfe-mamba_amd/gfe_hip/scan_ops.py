@@ -1,0 +1,149 @@
+"""Autograd wrappers of the scan entry points (include/gfe_hip.h, Group A).
+
+`selective_scan_tm`  : fused selective scan in the token-major layout MambaBlock already has
+`selective_scan_fn`  : the reference's plug-in contract (cross_atten/mamba.py:243-252, channel-major layout)
+`pscan`              : drop-in for cross_atten/pscan.py:226
+"""
+import ctypes
+
+import torch
+
+from . import call, dtype_code, ptr, stream, lib
+
+
+def sscan_plan(B, L, ED, N, chunk=0, backward=False):
+    T, nc = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib().gfe_sscan_plan(B, L, ED, N, int(chunk), int(backward), ctypes.byref(T), ctypes.byref(nc))
+    if rc != 0:
+        raise ValueError(f"gfe_sscan_plan: unsupported shape B={B} L={L} ED={ED} N={N}")
+    return T.value, nc.value
+
+
+def _common_dtype(*ts):
+    ts = [t for t in ts if t is not None]
+    return torch.bfloat16 if all(t.dtype == torch.bfloat16 for t in ts) else torch.float32
+
+
+def _f32c(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+class _SelectiveScanTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk):
+        Bsz, L, ED = u.shape
+        N = A.shape[1]
+        dt = _common_dtype(u, delta, Bm, Cm, z)
+        cast = lambda t: None if t is None else t.detach().to(dt).contiguous()
+        u_, d_, B_, C_, z_ = cast(u), cast(delta), cast(Bm), cast(Cm), cast(z)
+        A_, D_, b_ = _f32c(A), _f32c(D), _f32c(delta_bias)
+        need_grad = any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
+        T, nc = sscan_plan(Bsz, L, ED, N, chunk, backward=need_grad)
+        hstate = sdelta = None
+        if nc > 1:
+            hstate = torch.empty((Bsz, nc, N, ED), device=u.device, dtype=torch.float32)
+            sdelta = torch.empty((Bsz, nc, ED), device=u.device, dtype=torch.float32)
+        y = torch.empty((Bsz, L, ED), device=u.device, dtype=dt)
+        call("gfe_selective_scan_fwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(y),
+             ptr(hstate), ptr(sdelta), Bsz, L, ED, N, T, int(bool(delta_softplus)), dtype_code(dt), stream())
+        ctx.save_for_backward(u_, d_, A_, B_, C_, D_, z_, b_, hstate, sdelta)
+        ctx.meta = (T, nc, bool(delta_softplus), dt,
+                    tuple(None if t is None else t.dtype for t in (u, delta, A, Bm, Cm, D, z, delta_bias)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u_, d_, A_, B_, C_, D_, z_, b_, hstate, sdelta = ctx.saved_tensors
+        T, nc, softplus, dt, in_dtypes = ctx.meta
+        Bsz, L, ED = u_.shape
+        N = A_.shape[1]
+        dev = u_.device
+        dy_ = dy.to(dt).contiguous()
+        du = torch.empty_like(u_)
+        dd = torch.empty_like(u_)
+        dz = torch.empty_like(u_) if z_ is not None else None
+        # one zeroed f32 slab for every atomically accumulated gradient
+        sizes = [N * ED, Bsz * L * N, Bsz * L * N, ED, ED]
+        slab = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        dA_ws, dB_ws, dC_ws, dD_ws, db_ws = torch.split(slab, sizes)
+        qstate = torch.empty_like(hstate) if nc > 1 else None
+        call("gfe_selective_scan_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_),
+             ptr(du), ptr(dd), ptr(dz), ptr(dA_ws), ptr(dB_ws), ptr(dC_ws),
+             ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
+             ptr(hstate), ptr(qstate), ptr(sdelta), Bsz, L, ED, N, T, int(softplus), dtype_code(dt), stream())
+        to = lambda g, i: None if in_dtypes[i] is None else g.to(in_dtypes[i])
+        dA = dA_ws.view(N, ED).t()
+        return (to(du, 0), to(dd, 1), to(dA, 2), to(dB_ws.view(Bsz, L, N), 3), to(dC_ws.view(Bsz, L, N), 4),
+                to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,
+                to(db_ws, 7) if b_ is not None else None, None, None)
+
+
+def selective_scan_tm(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=False, chunk=0):
+    """Token-major fused selective scan.  u, delta, z: (B, L, ED); Bm, Cm: (B, L, N); A: (ED, N); returns (B, L, ED).
+
+    y = selective_scan(u, softplus(delta + delta_bias), A, B, C, D) * silu(z)   (cross_atten/mamba.py:254-259, 220-222)
+    """
+    if not u.is_cuda:
+        raise RuntimeError("gfe_hip selective scan needs CUDA/HIP tensors (no CPU fallback)")
+    return _SelectiveScanTM.apply(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False):
+    """The reference's plug-in slot `MambaBlock.selective_scan_cuda` (cross_atten/mamba.py:180-186, 243-252).
+
+    u, delta, z: (B, ED, L); B, C: (B, N, L); A: (ED, N); D, delta_bias: (ED).  Returns (B, ED, L).
+    The reference hands over transposed views of token-major tensors (mamba.py:245-248), so the
+    transposes below are free for u/B/C/z; only `delta` (computed channel-major at mamba.py:238) is copied.
+    """
+    tm = lambda t: None if t is None else t.transpose(1, 2)
+    y = selective_scan_tm(tm(u), tm(delta), A, tm(B), tm(C), D, tm(z), delta_bias, delta_softplus)
+    return y.transpose(1, 2)
+
+
+class _PScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A_in, X_in, chunk):
+        Bsz, L, D, N = X_in.shape
+        dt = _common_dtype(A_in, X_in)
+        A = A_in.detach().to(dt).contiguous()
+        X = X_in.detach().to(dt).contiguous()
+        DN = D * N
+        T, nc = _pscan_plan(Bsz, L, DN, dt, chunk)
+        ws = torch.empty((Bsz, nc, 2, DN), device=A.device, dtype=torch.float32) if nc > 1 else None
+        H = torch.empty_like(X)
+        call("gfe_pscan_fwd", ptr(A), ptr(X), ptr(H), ptr(ws), Bsz, L, DN, T, dtype_code(dt), stream())
+        ctx.save_for_backward(A, H)
+        ctx.meta = (T, nc, dt, A_in.dtype, X_in.dtype)
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        A, H = ctx.saved_tensors
+        T, nc, dt, adt, xdt = ctx.meta
+        Bsz, L, D, N = H.shape
+        DN = D * N
+        g = gH.to(dt).contiguous()
+        gA = torch.empty_like(H)
+        gX = torch.empty_like(H)
+        ws = torch.empty((Bsz, nc, 2, DN), device=A.device, dtype=torch.float32) if nc > 1 else None
+        call("gfe_pscan_bwd", ptr(A), ptr(H), ptr(g), ptr(gA), ptr(gX), ptr(ws), Bsz, L, DN, T, dtype_code(dt), stream())
+        return gA.to(adt), gX.to(xdt), None
+
+
+def _pscan_plan(B, L, DN, dt, chunk):
+    if chunk and chunk > 0:
+        T = min(int(chunk), L)
+    else:
+        vec = 8 if dt == torch.bfloat16 else 4
+        waves = B * max(1, DN // (vec * 64))
+        want = -(-2048 // waves)
+        T = L if want <= 1 else max(32, -(-L // want))
+        T = min(T, L)
+    return T, -(-L // T)
+
+
+def pscan(A_in, X_in, chunk=0):
+    """H[t] = A[t] * H[t-1] + X[t] over dim 1 of (B, L, D, N) tensors (cross_atten/pscan.py:151-186); differentiable in both."""
+    if not X_in.is_cuda:
+        raise RuntimeError("gfe_hip pscan needs CUDA/HIP tensors (no CPU fallback)")
+    return _PScan.apply(A_in, X_in, chunk)

@@ -1,0 +1,370 @@
+"""ORACLE -- test infrastructure, not product code.
+
+A CPU restatement (plain torch ops on CPU tensors, fp32 or fp64) of the reference's algorithm for the
+classify_mamba hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this; the product path (gfe-mamba_amd/) never does.
+
+Pinning: the reference has no tests or golden vectors of its own.  This oracle is
+pinned against outputs of the reference itself, generated in the build container by tools/make_golden.py
+(which imports /root/reference) and committed as fixtures under tests/golden/; tests/test_oracle_golden.py
+checks every function below against them.
+
+All functions are pure: `sd` is a {state-dict key: tensor} mapping using the reference's key names, `pre`
+a key prefix.  Citations are file:line in the reference repository.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ------------------------------------------------------------------------------------------------
+# Group A -- scan, Mamba
+# ------------------------------------------------------------------------------------------------
+
+
+def npo2(n):
+    """cross_atten/pscan.py:13-18."""
+    return 2 ** math.ceil(math.log2(n))
+
+
+def pscan(A, X):
+    """H[t] = A[t]*H[t-1] + X[t], H[-1] = 0, over dim 1 of (B, L, D, N).
+
+    Sequential statement of what PScan.forward computes with its Blelloch sweeps (cross_atten/pscan.py:36-92,
+    151-186; the recurrence is stated at pscan.py:41-44).  Padding to npo2(L) (pscan.py:20-33) does not change
+    the first L outputs.
+    """
+    H = torch.empty_like(X)
+    h = torch.zeros_like(X[:, 0])
+    for t in range(X.shape[1]):
+        h = A[:, t] * h + X[:, t]
+        H[:, t] = h
+    return H
+
+
+def pscan_grads(A, H, gH):
+    """PScan.backward (cross_atten/pscan.py:188-224): gX = reverse scan with A shifted left (:216-219);
+    gA[t] = H[t-1]*gX[t], gA[0] = 0 (:221-222)."""
+    L = A.shape[1]
+    gX = torch.empty_like(gH)
+    r = torch.zeros_like(gH[:, 0])
+    for t in range(L - 1, -1, -1):
+        r = gH[:, t] + (A[:, t + 1] * r if t + 1 < L else 0)
+        gX[:, t] = r
+    gA = torch.zeros_like(gH)
+    gA[:, 1:] = H[:, :-1] * gX[:, 1:]
+    return gA, gX
+
+
+def selective_scan(x, delta, A, B, C, D):
+    """MambaBlock.selective_scan_seq / selective_scan (cross_atten/mamba.py:265-318).
+    x, delta: (B, L, ED); A: (ED, N); B, C: (B, L, N); D: (ED) -> (B, L, ED)."""
+    deltaA = torch.exp(delta.unsqueeze(-1) * A)                      # mamba.py:275 / 300
+    BX = delta.unsqueeze(-1) * B.unsqueeze(2) * x.unsqueeze(-1)      # mamba.py:276-278 / 301-303
+    h = torch.zeros(x.shape[0], x.shape[2], A.shape[1], dtype=deltaA.dtype)
+    ys = []
+    for t in range(x.shape[1]):                                      # mamba.py:308-310
+        h = deltaA[:, t] * h + BX[:, t]
+        ys.append((h * C[:, t].unsqueeze(1)).sum(-1))                # mamba.py:314 (hs @ C)
+    return torch.stack(ys, 1) + D * x                                # mamba.py:316
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False):
+    """Contract of the reference's plug-in slot (cross_atten/mamba.py:243-252): channel-major layouts
+    u, delta, z: (B, ED, L); B, C: (B, N, L).  Equivalent to the fallback path mamba.py:254-259 + 220-222."""
+    d = delta.transpose(1, 2)
+    if delta_bias is not None:
+        d = d + delta_bias
+    if delta_softplus:
+        d = F.softplus(d)                                            # mamba.py:256
+    x = u.transpose(1, 2)
+    y = selective_scan(x, d, A, B.transpose(1, 2), C.transpose(1, 2),
+                       D if D is not None else torch.zeros(A.shape[0], dtype=A.dtype))
+    if z is not None:
+        y = y * F.silu(z.transpose(1, 2))                            # mamba.py:220-222
+    return y.transpose(1, 2)
+
+
+def rmsnorm(x, w, eps=1e-5):
+    """cross_atten/mamba.py:408-418."""
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
+
+
+def mamba_block(x, sd, pre, d_state=16, d_conv=4):
+    """MambaBlock.forward + ssm (cross_atten/mamba.py:197-263), fallback (non-plug-in) arithmetic."""
+    L = x.shape[1]
+    ED = sd[pre + "in_proj.weight"].shape[0] // 2
+    dt_rank = sd[pre + "dt_proj.weight"].shape[1]
+    xz = x @ sd[pre + "in_proj.weight"].t()                          # :204 (bias=False, :48)
+    xs, z = xz.chunk(2, dim=-1)                                      # :205
+    xc = F.conv1d(xs.transpose(1, 2), sd[pre + "conv1d.weight"], sd[pre + "conv1d.bias"],
+                  padding=d_conv - 1, groups=ED)[:, :, :L].transpose(1, 2)   # :208-210
+    xc = F.silu(xc)                                                  # :212
+    A = -torch.exp(sd[pre + "A_log"].float())                        # :232
+    D = sd[pre + "D"].float()                                        # :233
+    dbc = xc @ sd[pre + "x_proj.weight"].t()                         # :235
+    delta, B, C = torch.split(dbc, [dt_rank, d_state, d_state], dim=-1)   # :236
+    delta = (sd[pre + "dt_proj.weight"] @ delta.transpose(1, 2)).transpose(1, 2)   # :238, :255
+    delta = F.softplus(delta + sd[pre + "dt_proj.bias"])             # :256
+    y = selective_scan(xc, delta, A, B, C, D)                        # :259
+    return (y * F.silu(z)) @ sd[pre + "out_proj.weight"].t()         # :220-223
+
+
+def mamba(x, sd, pre, n_layers):
+    """Mamba.forward / ResidualBlock.forward (cross_atten/mamba.py:69-77, 98-104)."""
+    for l in range(n_layers):
+        p = f"{pre}layers.{l}."
+        x = mamba_block(rmsnorm(x, sd[p + "norm.weight"]), sd, p + "mixer.") + x
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Group B -- tabular tokeniser, cross attention, head
+# ------------------------------------------------------------------------------------------------
+
+
+def categories_offset(categories, num_special_tokens=2):
+    """cross_atten/mamba_transformer.py:44-46."""
+    off = F.pad(torch.tensor(list(categories)), (1, 0), value=num_special_tokens)
+    return off.cumsum(dim=-1)[:-1]
+
+
+def build_condition(image_condition):
+    """cross_atten/mamba_transformer.py:89-94: (B,1,D1,D2,D3) x2 -> (B, 2*D3, D1*D2)."""
+    outs = []
+    for img in image_condition:
+        b, c, h, w, d = img.shape
+        outs.append(img.reshape(b * c, h * w, d).transpose(1, 2).contiguous())
+    return torch.cat(outs, dim=1)
+
+
+def cross_attention(x, y, sd, pre, n_heads):
+    """CrossAttention.forward (cross_atten/sd_cross_atten.py:49-70)."""
+    Bsz, _, E = x.shape
+    dh = E // n_heads
+    lin = lambda t, n: t @ sd[pre + n + ".weight"].t() + sd[pre + n + ".bias"]
+    q = lin(x, "q_proj").view(Bsz, -1, n_heads, dh).transpose(1, 2)
+    k = lin(y, "k_proj").view(Bsz, -1, n_heads, dh).transpose(1, 2)
+    v = lin(y, "v_proj").view(Bsz, -1, n_heads, dh).transpose(1, 2)
+    w = (q @ k.transpose(-1, -2)) / math.sqrt(dh)                    # :61-62
+    w = F.softmax(w, dim=-1)                                         # :63
+    o = (w @ v).transpose(1, 2).contiguous().view(x.shape)           # :65-67
+    return lin(o, "out_proj")                                        # :68
+
+
+def geglu_ff(x, sd, pre, drop_mask=None):
+    """FeedForward/GEGLU (cross_atten/corss_ft_transformer.py:10-22); drop_mask: pre-scaled dropout mask or None (eval)."""
+    h = F.layer_norm(x, x.shape[-1:], sd[pre + "0.weight"], sd[pre + "0.bias"])
+    h = h @ sd[pre + "1.weight"].t() + sd[pre + "1.bias"]
+    a, g = h.chunk(2, dim=-1)
+    h = a * F.gelu(g)
+    if drop_mask is not None:
+        h = h * drop_mask
+    return h @ sd[pre + "4.weight"].t() + sd[pre + "4.bias"]
+
+
+def cross_mamba_both(x_categ, x_numer, feature_img, image_condition, sd, depth, heads, pre="", drop_mask=None):
+    """Cross_mamba_both.forward (cross_atten/mamba_transformer.py:87-133)."""
+    cond = build_condition(image_condition)                          # :89-94
+    xs = []
+    if (pre + "categorical_embeds.weight") in sd:
+        idx = x_categ + sd[pre + "categories_offset"]                # :98
+        xs.append(sd[pre + "categorical_embeds.weight"][idx])        # :100
+    if (pre + "numerical_embedder.weights") in sd:                   # corss_ft_transformer.py:159-163
+        xs.append(x_numer.unsqueeze(-1) * sd[pre + "numerical_embedder.weights"] + sd[pre + "numerical_embedder.biases"])
+    x = torch.cat(xs, dim=1)                                         # :112
+    cls = sd[pre + "cls_token"].expand(x.shape[0], -1, -1)           # :116
+    x = torch.cat((cls, x, feature_img), dim=1)                      # :117
+    x = mamba(x, sd, pre + "transformer.", depth)                    # :121
+    x = x.mean(dim=1, keepdim=True)                                  # :122
+    x = cross_attention(x, cond, sd, pre + "final_cross.", heads) + x   # :124
+    x = geglu_ff(x, sd, pre + "final_feed.", drop_mask) + x          # :125
+    x = x.squeeze(1)                                                 # :127
+    x = F.layer_norm(x, x.shape[-1:], sd[pre + "to_logits.0.weight"], sd[pre + "to_logits.0.bias"])
+    return x @ sd[pre + "to_logits.1.weight"].t() + sd[pre + "to_logits.1.bias"]   # :131
+
+
+def combine_classifier_vit_mid(mid_input, mid_output, sd, pre=""):
+    """Combine_classfier_vit_mid.forward (classify/classifier.py:329-333)."""
+    t = torch.cat([mid_input, mid_output], dim=1).flatten(2)        # b c (h w)
+    f = t @ sd[pre + "vit_mid_linear.weight"].t() + sd[pre + "vit_mid_linear.bias"]
+    return f.transpose(1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# Group C -- frozen generator (Residual_mid_UNet3D_vit, eval, forward only)
+# ------------------------------------------------------------------------------------------------
+
+
+def single_conv(x, sd, pre, relu, num_groups=8):
+    """SingleConv order 'gcr'/'gc' (pytorch3dunet/unet3d/buildingblocks.py:38-67, 108-115): GroupNorm over
+    in_channels -> Conv3d k3 p1 no bias -> optional ReLU."""
+    C = x.shape[1]
+    g = num_groups if C >= num_groups else 1                         # :62-63
+    x = F.group_norm(x, g, sd[pre + "groupnorm.weight"], sd[pre + "groupnorm.bias"], eps=1e-5)
+    x = F.conv3d(x, sd[pre + "conv.weight"], None, padding=1)
+    return F.relu(x) if relu else x
+
+
+def resnet_block(x, sd, pre):
+    """ResNetBlock.forward, order 'gcr' => ReLU (buildingblocks.py:211-229)."""
+    if (pre + "conv1.weight") in sd:
+        r = F.conv3d(x, sd[pre + "conv1.weight"], sd[pre + "conv1.bias"])   # :191-196 (1x1x1, bias)
+    else:
+        r = x                                                        # :198 Identity
+    o = single_conv(r, sd, pre + "conv2.", relu=True)
+    o = single_conv(o, sd, pre + "conv3.", relu=False)
+    return F.relu(o + r)                                             # :226-227
+
+
+def fold_mid(x, md1=8):
+    """'b c (md1 md2) h w -> b c (h md1) (md2 w)' (pytorch3dunet/unet3d/model.py:150)."""
+    b, c, d, h, w = x.shape
+    md2 = d // md1
+    return x.view(b, c, md1, md2, h, w).permute(0, 1, 4, 2, 3, 5).reshape(b, c, h * md1, md2 * w)
+
+
+def unfold_mid(y, w, md1=8):
+    """'b c (h md1) (md2 w) -> b c (md1 md2) h w' (model.py:152)."""
+    b, c, H, W = y.shape
+    h, md2 = H // md1, W // w
+    return y.view(b, c, h, md1, md2, w).permute(0, 1, 3, 4, 2, 5).reshape(b, c, md1 * md2, h, w)
+
+
+def patchify(img, p):
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit_pytorch_diy/vit.py:96)."""
+    b, c, H, W = img.shape
+    h, w = H // p, W // p
+    return img.view(b, c, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(b, h * w, p * p * c)
+
+
+def unpatchify(t, p, h, c):
+    """'b (h w) (p1 p2 c) -> b c (h p1) (w p2)' (vit.py:109)."""
+    b, n, _ = t.shape
+    w = n // h
+    return t.view(b, h, w, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(b, c, h * p, w * p)
+
+
+def _ln(x, sd, pre):
+    return F.layer_norm(x, x.shape[-1:], sd[pre + "weight"], sd[pre + "bias"], eps=1e-5)
+
+
+def _linear(x, sd, pre):
+    y = x @ sd[pre + "weight"].t()
+    return y + sd[pre + "bias"] if (pre + "bias") in sd else y
+
+
+def vit_attention(x, sd, pre, heads):
+    """Attention.forward (vit.py:50-63), eval mode."""
+    b, n, _ = x.shape
+    h = _ln(x, sd, pre + "norm.")
+    qkv = h @ sd[pre + "to_qkv.weight"].t()
+    inner = qkv.shape[-1] // 3
+    dh = inner // heads
+    q, k, v = [t.view(b, n, heads, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    dots = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    out = (F.softmax(dots, dim=-1) @ v).transpose(1, 2).reshape(b, n, inner)
+    return _linear(out, sd, pre + "to_out.0.")
+
+
+def vit_feedforward(x, sd, pre):
+    """FeedForward (vit.py:14-27), eval mode, exact-erf GELU."""
+    h = _ln(x, sd, pre + "net.0.")
+    h = F.gelu(_linear(h, sd, pre + "net.1."))
+    return _linear(h, sd, pre + "net.4.")
+
+
+def vit_mid(img, sd, pre, patch, heads, depth):
+    """ViT.forward incl. from_patch_embedding (vit.py:95-110, 124-137), eval mode."""
+    b, c, H, W = img.shape
+    x = patchify(img, patch)
+    x = _ln(x, sd, pre + "to_patch_embedding.1.")
+    x = _linear(x, sd, pre + "to_patch_embedding.2.")
+    x = _ln(x, sd, pre + "to_patch_embedding.3.")
+    n = x.shape[1]
+    x = torch.cat((sd[pre + "cls_token"].expand(b, -1, -1), x), dim=1)   # :127-128
+    x = x + sd[pre + "pos_embedding"][:, :n + 1]                     # :130
+    for l in range(depth):                                           # vit.py:76-79
+        x = vit_attention(x, sd, f"{pre}transformer.layers.{l}.0.", heads) + x
+        x = vit_feedforward(x, sd, f"{pre}transformer.layers.{l}.1.") + x
+    x = _ln(x, sd, pre + "transformer.norm.")                        # :81
+    x = _ln(x, sd, pre + "from_patch_embedding.0.")                  # :103
+    x = _linear(x.transpose(1, 2), sd, pre + "from_patch_embedding.2.").transpose(1, 2)   # :104-106 (token axis)
+    x = _linear(x, sd, pre + "from_patch_embedding.4.")              # :107
+    x = _ln(x, sd, pre + "from_patch_embedding.5.")                  # :108
+    return unpatchify(x, patch, H // patch, c)                       # :109
+
+
+def nearest_resize(x, size):
+    """F.interpolate(x, size) default nearest (buildingblocks.py:523-531): dst i <- src floor(i*in/out)."""
+    for dim, s in zip((2, 3, 4), size):
+        n = x.shape[dim]
+        if n != s:
+            idx = torch.div(torch.arange(s) * n, s, rounding_mode="floor")
+            x = x.index_select(dim, idx)
+    return x
+
+
+def decoder(enc_feat, x, sd, pre):
+    """Decoder.forward for ResNetBlock: ConvTranspose3d k3 s2 p1 no bias -> nearest resize -> sum join -> ResNetBlock
+    (buildingblocks.py:389-400, 523-537)."""
+    x = F.conv_transpose3d(x, sd[pre + "upsampling.upsample.conv_transposed.weight"], None, stride=2, padding=1)
+    x = nearest_resize(x, enc_feat.shape[2:])
+    return resnet_block(enc_feat + x, sd, pre + "basic_module.")
+
+
+def generator(x, sd, pre="", levels=3, vit_patch=None, vit_heads=6, vit_depth=4, md1=8):
+    """Mid_UNet_vit.forward(x, output_vit_mid=True) in eval mode (pytorch3dunet/unet3d/model.py:137-175).
+    Returns (mid_input, mid_output, pet)."""
+    feats = []
+    for i in range(levels):
+        if i > 0:
+            x = F.max_pool3d(x, 2)                                   # buildingblocks.py:284, 306-307
+        x = resnet_block(x, sd, f"{pre}encoders.{i}.basic_module.")
+        feats.insert(0, x)
+    feats = feats[1:]
+    mid_input = fold_mid(x, md1)                                     # model.py:150
+    if vit_patch is None:
+        vit_patch = x.shape[3]                                       # patch = D2/4 (SURVEY 8-d geometry rule)
+    mid_output = vit_mid(mid_input, sd, pre + "mid.", vit_patch, vit_heads, vit_depth)
+    x = unfold_mid(mid_output, x.shape[-1], md1)                     # model.py:152
+    for j, ef in enumerate(feats):
+        x = decoder(ef, x, sd, f"{pre}decoders.{j}.")
+    pet = F.conv3d(x, sd[pre + "final_conv.weight"], sd[pre + "final_conv.bias"])   # model.py:162
+    return mid_input, mid_output, pet
+
+
+# ------------------------------------------------------------------------------------------------
+# Group G -- the step
+# ------------------------------------------------------------------------------------------------
+
+
+def bce_sigmoid(pred, y):
+    """classify_mamba.py:104: BCELoss(sigmoid(pred.squeeze(1)), y.float()), mean."""
+    return F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.float())
+
+
+def clip_per_param(grads, max_norm=1.0):
+    """classify_mamba.py:106-107: clip_grad_norm_ applied to each parameter on its own."""
+    out = []
+    for g in grads:
+        coef = max_norm / (g.norm(2) + 1e-6)
+        out.append(g * torch.clamp(coef, max=1.0))
+    return out
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (classify_mamba.py:64)."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    mhat = m / (1 - b1 ** step)
+    vhat = v / (1 - b2 ** step)
+    return p - lr * mhat / (vhat.sqrt() + eps), m, v
+
+
+def geometry(D1, D2, D3, md1=8):
+    """Derived constants for non-native volume sizes: returns dict(H, W, patch, num_patches, d_cross, keys)."""
+    assert D1 % 32 == 0 and D2 % 4 == 0 and D3 % 4 == 0
+    H, W, p = (D2 // 4) * md1, (D1 // 32) * (D3 // 4), D2 // 4
+    assert W % p == 0
+    return dict(H=H, W=W, patch=p, num_patches=(H // p) * (W // p), d_cross=D1 * D2, keys=2 * D3)

@@ -1,0 +1,127 @@
+"""Pins the oracle (oracle/ref_ops.py) against outputs of the reference itself (tests/golden/, made by
+tools/make_golden.py in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err, sub_sd, tt
+from oracle import ref_ops as O
+
+TOL = 2e-5   # fp32 arithmetic both sides; different summation order only
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 37, 64, 100])
+def test_pscan_matches_reference(L):
+    fx = golden("t0_pscan.npz")
+    A, X, gH = (tt(fx[f"pscan_L{L}_{k}"], torch.float64) for k in ("A", "X", "gH"))
+    H = O.pscan(A, X)
+    assert rel_err(H, tt(fx[f"pscan_L{L}_H"])) < 1e-12
+    gA, gX = O.pscan_grads(A, H, gH)
+    assert rel_err(gX, tt(fx[f"pscan_L{L}_gX"])) < 1e-12
+    assert (gA - tt(fx[f"pscan_L{L}_gA"])).abs().max() < 1e-12
+    assert torch.all(gA[:, 0] == 0)
+
+
+def test_selective_scan_matches_reference():
+    fx = golden("t0_selective_scan.npz")
+    g = lambda k: tt(fx["ss_" + k]).requires_grad_(True)
+    x, delta, A, B, C, D = g("x"), g("delta"), g("A"), g("B"), g("C"), g("D")
+    y = O.selective_scan(x, delta, A, B, C, D)
+    assert rel_err(y, tt(fx["ss_y"])) < TOL
+    assert rel_err(y, tt(fx["ss_y_seq"])) < TOL
+    (y * tt(fx["ss_w"])).sum().backward()
+    for k, v in dict(x=x, delta=delta, A=A, B=B, C=C, D=D).items():
+        assert rel_err(v.grad, tt(fx["ss_g" + k])) < 1e-4, k
+    # plug-in layout contract (mamba.py:243-252)
+    tr = lambda t: t.detach().transpose(1, 2)
+    yfn = O.selective_scan_fn(tr(x), tr(tt(fx["ss_draw"])), A.detach(), tr(B), tr(C), D.detach(), z=tr(tt(fx["ss_z"])),
+                              delta_bias=tt(fx["ss_dbias"]), delta_softplus=True)
+    assert rel_err(yfn.transpose(1, 2), tt(fx["ss_yfn"])) < TOL
+
+
+def test_mamba_block_and_stack():
+    fx = golden("t0_mamba.npz")
+    sd = sub_sd(fx, "sd.")
+    x = tt(fx["x"])
+    assert rel_err(O.rmsnorm(x, sd["layers.0.norm.weight"]), tt(fx["y_norm0"])) < TOL
+    assert rel_err(O.mamba_block(x, sd, "layers.0.mixer."), tt(fx["y_block0"])) < TOL
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xg = x.clone().requires_grad_(True)
+    y = O.mamba(xg, sdg, "", 2)
+    assert rel_err(y, tt(fx["y"])) < TOL
+    (y * tt(fx["w"])).sum().backward()
+    assert rel_err(xg.grad, tt(fx["gx"])) < 1e-4
+    for k, v in sdg.items():
+        assert rel_err(v.grad, tt(fx["g." + k])) < 2e-4, k
+
+
+def test_head_ops():
+    fx = golden("t0_head_ops.npz")
+    sd = sub_sd(fx, "ca.sd.")
+    x, y = tt(fx["ca.x"]).requires_grad_(True), tt(fx["ca.y"]).requires_grad_(True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = O.cross_attention(x, y, sdg, "", 2)
+    assert rel_err(o, tt(fx["ca.out"])) < TOL
+    (o * tt(fx["ca.w"])).sum().backward()
+    assert rel_err(x.grad, tt(fx["ca.gx"])) < 1e-4 and rel_err(y.grad, tt(fx["ca.gy"])) < 1e-4
+    for k, v in sdg.items():
+        if k == "k_proj.bias":     # exactly zero in exact arithmetic (softmax is shift-invariant): both sides are round-off
+            assert v.grad.abs().max() < 1e-6 and np.abs(fx["ca.g." + k]).max() < 1e-6
+            continue
+        assert rel_err(v.grad, tt(fx["ca.g." + k])) < 1e-4, k
+    sd = sub_sd(fx, "ff.sd.")
+    assert rel_err(O.geglu_ff(tt(fx["ff.x"]), sd, ""), tt(fx["ff.out"])) < TOL
+    sd = sub_sd(fx, "ne.sd.")
+    ne = tt(fx["ne.x"]).unsqueeze(-1) * sd["weights"] + sd["biases"]
+    assert rel_err(ne, tt(fx["ne.out"])) < TOL
+    off = O.categories_offset((11, 2, 2, 4, 4, 3, 3))
+    assert off.tolist() == fx["categories_offset"].tolist() == [2, 13, 15, 17, 21, 25, 28]
+
+
+def test_unet_ops():
+    fx = golden("t0_unet_ops.npz")
+    assert rel_err(O.resnet_block(tt(fx["rb.x"]), sub_sd(fx, "rb.sd."), ""), tt(fx["rb.out"])) < TOL
+    assert rel_err(O.resnet_block(tt(fx["rb2.x"]), sub_sd(fx, "rb2.sd."), ""), tt(fx["rb2.out"])) < TOL
+    sd = sub_sd(fx, "dec.sd.")
+    up = torch.nn.functional.conv_transpose3d(tt(fx["dec.x"]), sd["upsampling.upsample.conv_transposed.weight"], None, stride=2, padding=1)
+    up = O.nearest_resize(up, (8, 8, 8))
+    assert rel_err(up, tt(fx["dec.up"])) < TOL
+    assert rel_err(O.decoder(tt(fx["dec.ef"]), tt(fx["dec.x"]), sd, ""), tt(fx["dec.out"])) < TOL
+    for n in (3, 4, 12, 24, 47):   # nearest 2n-1 -> 2n duplicates the first plane: [0,0,1,2,...]
+        src = torch.arange(2 * n - 1, dtype=torch.float32).view(1, 1, -1, 1, 1)
+        got = O.nearest_resize(src, (2 * n, 1, 1)).flatten().long().tolist()
+        assert got == fx[f"nearest_idx_{n}"].tolist() == [max(i - 1, 0) for i in range(2 * n)]
+    assert torch.equal(torch.nn.functional.max_pool3d(tt(fx["mp.x"]), 2), tt(fx["mp.out"]))
+
+
+def test_vit():
+    fx = golden("t0_vit.npz")
+    sd = sub_sd(fx, "sd.")
+    out = O.vit_mid(tt(fx["x"]), sd, "", patch=8, heads=2, depth=2)
+    assert rel_err(out, tt(fx["out"])) < TOL
+
+
+def test_index_maps_bit_exact():
+    fx = golden("t0_index_maps.npz")
+    for name, shp in (("native", (40, 40, 24)), ("g96", (24, 24, 24)), ("g128", (32, 32, 32)), ("g32", (8, 8, 8))):
+        src = torch.arange(int(np.prod(shp)), dtype=torch.int64).view(1, 1, *shp)
+        f = O.fold_mid(src)
+        assert torch.equal(f[0, 0], tt(fx[f"fold_{name}"]))
+        assert torch.equal(O.unfold_mid(f, shp[2]), src)
+    img = torch.arange(2 * 16 * 8, dtype=torch.int64).view(1, 2, 16, 8)
+    p = O.patchify(img, 4)
+    assert torch.equal(p[0], tt(fx["patchify_c2_16x8_p4"]))
+    assert torch.equal(O.unpatchify(p, 4, 4, 2), img)
+    vol = torch.arange(2 * 4 * 6 * 8, dtype=torch.int64).view(2, 1, 4, 6, 8)
+    assert torch.equal(O.build_condition([vol]), tt(fx["condition_2x1x4x6x8"]))
+
+
+def test_c_scan_oracle():
+    """oracle/scan_ref.c against the reference fixture (both the plain and the fused-gate contract)."""
+    from oracle import c_oracle
+    fx = golden("t0_selective_scan.npz")
+    y = c_oracle.selective_scan(fx["ss_x"], fx["ss_delta"], fx["ss_A"], fx["ss_B"], fx["ss_C"], fx["ss_D"])
+    assert rel_err(tt(y), tt(fx["ss_y_seq"])) < TOL
+    y = c_oracle.selective_scan(fx["ss_x"], fx["ss_draw"], fx["ss_A"], fx["ss_B"], fx["ss_C"], fx["ss_D"], z=fx["ss_z"],
+                                bias=fx["ss_dbias"], softplus=True)
+    assert rel_err(tt(y), tt(fx["ss_yfn"])) < TOL

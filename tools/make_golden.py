@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REFERENCE (imported from /root/reference) on CPU.
+
+Build-container only: /root/reference does not exist on the GPU box and nothing under tests/, bench.py or
+smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
+cases regenerate their weights from gfe_hip/det_init.py on both sides.
+
+    python tools/make_golden.py [--only t0|t1|t2] [--out tests/golden]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+def _load_det_init():
+    spec = importlib.util.spec_from_file_location("det_init", os.path.join(ROOT, "gfe-mamba_amd", "gfe_hip", "det_init.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+det = _load_det_init()
+
+
+def import_reference():
+    """vit_pytorch_diy/dino.py:9 imports torchvision (absent here) -> stub it."""
+    for name in ("torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.path.insert(0, REF)
+    import cross_atten.pscan as r_pscan
+    import cross_atten.mamba as r_mamba
+    import cross_atten.sd_cross_atten as r_xattn
+    import cross_atten.corss_ft_transformer as r_ft
+    import cross_atten.mamba_transformer as r_mt
+    import classify.classifier as r_cls
+    import pytorch3dunet.unet3d.model as r_model
+    import pytorch3dunet.unet3d.buildingblocks as r_bb
+    import vit_pytorch_diy.vit as r_vit
+    return types.SimpleNamespace(pscan=r_pscan, mamba=r_mamba, xattn=r_xattn, ft=r_ft, mt=r_mt, cls=r_cls,
+                                 model=r_model, bb=r_bb, vit=r_vit)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def load_det(module, seed, prefix=""):
+    sd = det.det_state_dict(module.state_dict(), seed=seed, prefix=prefix)
+    module.load_state_dict(sd)
+    return sd
+
+
+def rnd(key, shape, seed=0, scale=1.0):
+    g = np.random.Generator(np.random.Philox(key=[abs(hash(key)) % (2 ** 32), seed]))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def rnd_det(key, shape, scale=1.0):
+    import zlib
+    g = np.random.Generator(np.random.Philox(key=[zlib.crc32(key.encode()), 12345]))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+def t0(R, out):
+    fx = {}
+    # --- pscan forward + gradients (fp64 reference arithmetic on fp32 inputs)
+    for L in (1, 2, 3, 4, 5, 37, 64, 100):
+        A = torch.rand(2, L, 8, 4, generator=torch.Generator().manual_seed(L)).float() * 0.9 + 0.05
+        X = rnd_det(f"pscan.X.{L}", (2, L, 8, 4))
+        gH = rnd_det(f"pscan.gH.{L}", (2, L, 8, 4))
+        A64 = A.double().requires_grad_(True)
+        X64 = X.double().requires_grad_(True)
+        H = R.pscan.pscan(A64, X64)
+        H.backward(gH.double())
+        fx[f"pscan_L{L}_A"], fx[f"pscan_L{L}_X"], fx[f"pscan_L{L}_gH"] = npy(A), npy(X), npy(gH)
+        fx[f"pscan_L{L}_H"], fx[f"pscan_L{L}_gA"], fx[f"pscan_L{L}_gX"] = npy(H), npy(A64.grad), npy(X64.grad)
+    np.savez_compressed(os.path.join(out, "t0_pscan.npz"), **fx)
+
+    # --- MambaBlock.selective_scan / selective_scan_seq  (B,L,ED,N) = (2,37,64,16)
+    fx = {}
+    cfg = R.mamba.MambaConfig(d_model=32, n_layers=1)
+    blk = R.mamba.MambaBlock(cfg)
+    Bz, L, ED, N = 2, 37, 64, 16
+    x = rnd_det("ss.x", (Bz, L, ED)).requires_grad_(True)
+    delta = (torch.nn.functional.softplus(rnd_det("ss.delta", (Bz, L, ED)) - 3.0)).detach().requires_grad_(True)
+    A = (-torch.exp(det.det_tensor("ss.A_log", (ED, N)))).requires_grad_(True)
+    Bm = rnd_det("ss.B", (Bz, L, N)).requires_grad_(True)
+    Cm = rnd_det("ss.C", (Bz, L, N)).requires_grad_(True)
+    D = det.det_tensor("ss.D", (ED,)).requires_grad_(True)
+    w = rnd_det("ss.w", (Bz, L, ED))
+    y = blk.selective_scan(x, delta, A, Bm, Cm, D)
+    y_seq = blk.selective_scan_seq(x, delta, A, Bm, Cm, D)
+    (y * w).sum().backward()
+    for k, v in dict(x=x, delta=delta, A=A, B=Bm, C=Cm, D=D, w=w, y=y, y_seq=y_seq).items():
+        fx["ss_" + k] = npy(v)
+    for k, v in dict(x=x, delta=delta, A=A, B=Bm, C=Cm, D=D).items():
+        fx["ss_g" + k] = npy(v.grad)
+    # plug-in contract (mamba.py:243-252): a torch callable with the selective_scan_fn layouts, installed at the slot
+    z = rnd_det("ss.z", (Bz, L, ED))
+    dbias = det.det_tensor("ss.dt_proj.bias", (ED,))
+    draw = rnd_det("ss.draw", (Bz, L, ED))
+    yfn = blk.selective_scan(x, torch.nn.functional.softplus(draw + dbias), A, Bm, Cm, D) * torch.nn.functional.silu(z)
+    fx["ss_z"], fx["ss_dbias"], fx["ss_draw"], fx["ss_yfn"] = npy(z), npy(dbias), npy(draw), npy(yfn)
+    np.savez_compressed(os.path.join(out, "t0_selective_scan.npz"), **fx)
+
+    # --- MambaBlock.forward + RMSNorm + ResidualBlock (d_model 32)
+    fx = {}
+    torch.manual_seed(0)
+    cfg = R.mamba.MambaConfig(d_model=32, n_layers=2)
+    m = R.mamba.Mamba(cfg)
+    sd = load_det(m, seed=1, prefix="t0mamba.")
+    xin = rnd_det("mamba.x", (2, 37, 32)).requires_grad_(True)
+    yb = m.layers[0].mixer(xin)
+    yn = m.layers[0].norm(xin)
+    ym = m(xin)
+    w = rnd_det("mamba.w", (2, 37, 32))
+    (ym * w).sum().backward()
+    fx.update({"sd." + k: npy(v) for k, v in sd.items()})
+    fx.update(x=npy(xin), w=npy(w), y_block0=npy(yb), y_norm0=npy(yn), y=npy(ym), gx=npy(xin.grad))
+    fx.update({"g." + k: npy(p.grad) for k, p in m.named_parameters()})
+    np.savez_compressed(os.path.join(out, "t0_mamba.npz"), **fx)
+
+    # --- CrossAttention, GEGLU FeedForward, NumericalEmbedder, categories_offset
+    fx = {}
+    ca = R.xattn.CrossAttention(n_heads=2, d_embed=16, d_cross=24)
+    sd = load_det(ca, seed=2, prefix="t0ca.")
+    xq = rnd_det("ca.x", (3, 1, 16)).requires_grad_(True)
+    yk = rnd_det("ca.y", (3, 6, 24)).requires_grad_(True)
+    o = ca(xq, yk)
+    w = rnd_det("ca.w", (3, 1, 16))
+    (o * w).sum().backward()
+    fx.update({"ca.sd." + k: npy(v) for k, v in sd.items()})
+    fx.update({"ca.g." + k: npy(p.grad) for k, p in ca.named_parameters()})
+    fx.update({"ca.x": npy(xq), "ca.y": npy(yk), "ca.w": npy(w), "ca.out": npy(o), "ca.gx": npy(xq.grad), "ca.gy": npy(yk.grad)})
+    ff = R.ft.FeedForward(16, mult=2, dropout=0.1).eval()
+    sd = load_det(ff, seed=3, prefix="t0ff.")
+    xf = rnd_det("ff.x", (3, 1, 16)).requires_grad_(True)
+    of = ff(xf)
+    (of * w).sum().backward()
+    fx.update({"ff.sd." + k: npy(v) for k, v in sd.items()})
+    fx.update({"ff.g." + k: npy(p.grad) for k, p in ff.named_parameters()})
+    fx.update({"ff.x": npy(xf), "ff.out": npy(of), "ff.gx": npy(xf.grad)})
+    ne = R.ft.NumericalEmbedder(16, 5)
+    sd = load_det(ne, seed=4, prefix="t0ne.")
+    xn = rnd_det("ne.x", (3, 5))
+    fx.update({"ne.sd." + k: npy(v) for k, v in sd.items()})
+    fx.update({"ne.x": npy(xn), "ne.out": npy(ne(xn))})
+    cm = R.mt.Cross_mamba_both(categories=(11, 2, 2, 4, 4, 3, 3), num_continuous=25, dim=16, depth=1, heads=2)
+    fx["categories_offset"] = npy(cm.categories_offset)
+    np.savez_compressed(os.path.join(out, "t0_head_ops.npz"), **fx)
+
+    # --- ResNetBlock 'gcr', Decoder (deconv + nearest + sum), nearest index list
+    fx = {}
+    rb = R.bb.ResNetBlock(8, 16, kernel_size=3, order="gcr", num_groups=8).eval()
+    sd = load_det(rb, seed=5, prefix="t0rb.")
+    xr = rnd_det("rb.x", (2, 8, 8, 8, 8))
+    fx.update({"rb.sd." + k: npy(v) for k, v in sd.items()})
+    fx.update({"rb.x": npy(xr), "rb.out": npy(rb(xr))})
+    rb2 = R.bb.ResNetBlock(16, 16, kernel_size=3, order="gcr", num_groups=8).eval()
+    sd = load_det(rb2, seed=6, prefix="t0rb2.")
+    xr2 = rnd_det("rb2.x", (2, 16, 6, 8, 4))
+    fx.update({"rb2.sd." + k: npy(v) for k, v in sd.items()})
+    fx.update({"rb2.x": npy(xr2), "rb2.out": npy(rb2(xr2))})
+    dec = R.bb.Decoder(16, 8, basic_module=R.bb.ResNetBlock, conv_layer_order="gcr", num_groups=8, upsample="default").eval()
+    sd = load_det(dec, seed=7, prefix="t0dec.")
+    xd = rnd_det("dec.x", (2, 16, 4, 4, 4))
+    ef = rnd_det("dec.ef", (2, 8, 8, 8, 8))
+    up = dec.upsampling(encoder_features=ef, x=xd)
+    fx.update({"dec.sd." + k: npy(v) for k, v in sd.items()})
+    fx.update({"dec.x": npy(xd), "dec.ef": npy(ef), "dec.up": npy(up), "dec.out": npy(dec(ef, xd))})
+    for n in (3, 4, 12, 24, 47):
+        src = torch.arange(2 * n - 1, dtype=torch.float32).view(1, 1, -1, 1, 1).expand(1, 1, -1, 2, 2)
+        r = torch.nn.functional.interpolate(src, size=(2 * n, 2, 2))
+        fx[f"nearest_idx_{n}"] = npy(r[0, 0, :, 0, 0]).astype(np.int64)
+    mp = torch.nn.MaxPool3d(2)
+    xm = rnd_det("mp.x", (1, 4, 6, 8, 10))
+    fx.update({"mp.x": npy(xm), "mp.out": npy(mp(xm))})
+    np.savez_compressed(os.path.join(out, "t0_unet_ops.npz"), **fx)
+
+    # --- ViT (image (64,8), patch 8, channels 32) incl. from_patch_embedding
+    fx = {}
+    vit = R.vit.ViT(image_size=(64, 8), patch_size=8, dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128,
+                    channels=32, dropout=0.1, emb_dropout=0.1).eval()
+    sd = load_det(vit, seed=8, prefix="t0vit.")
+    xi = rnd_det("vit.x", (2, 32, 64, 8))
+    fx.update({"sd." + k: npy(v) for k, v in sd.items()})
+    fx.update(x=npy(xi), out=npy(vit(xi)), tokens=npy(vit.to_patch_embedding(xi)))
+    np.savez_compressed(os.path.join(out, "t0_vit.npz"), **fx)
+
+    # --- pure index maps, as exact integers
+    from einops import rearrange
+    fx = {}
+    for name, shp in (("native", (40, 40, 24)), ("g96", (24, 24, 24)), ("g128", (32, 32, 32)), ("g32", (8, 8, 8))):
+        n = int(np.prod(shp))
+        src = torch.arange(n, dtype=torch.int64).view(1, 1, *shp)
+        folded = rearrange(src, "b c (md1 md2) h w -> b c (h md1) (md2 w)", md1=8)
+        back = rearrange(folded, "b c (h md1) (md2 w) -> b c (md1 md2) h w", md1=8, w=shp[2])
+        assert torch.equal(back, src)
+        fx[f"fold_{name}"] = npy(folded[0, 0])
+    img = torch.arange(2 * 16 * 8, dtype=torch.int64).view(1, 2, 16, 8)
+    pat = rearrange(img, "b c (h p1) (w p2) -> b (h w) (p1 p2 c)", p1=4, p2=4)
+    fx["patchify_c2_16x8_p4"] = npy(pat[0])
+    unp = rearrange(pat, "b (h w) (p1 p2 c) -> b c (h p1) (w p2)", p1=4, p2=4, h=4)
+    assert torch.equal(unp, img)
+    vol = torch.arange(2 * 1 * 4 * 6 * 8, dtype=torch.int64).view(2, 1, 4, 6, 8)
+    cond = rearrange(vol, "b c h w d -> (b c) (h w) d").transpose(1, 2).contiguous()
+    fx["condition_2x1x4x6x8"] = npy(cond)
+    np.savez_compressed(os.path.join(out, "t0_index_maps.npz"), **fx)
+
+
+# ------------------------------------------------------------------------------------------------
+def build_reference_models(R, vol, f_maps, dim, depth, heads, vit_dim, vit_depth, vit_heads, vit_dim_head, vit_mlp,
+                           cards, n_cont, seed):
+    import torch.nn as nn
+    D1, D2, D3 = vol
+    H, W, p = (D2 // 4) * 8, (D1 // 32) * (D3 // 4), D2 // 4
+    gen = R.model.Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=f_maps)
+    gen.mid = R.vit.ViT(image_size=(H, W), patch_size=p, dim=vit_dim, depth=vit_depth, heads=vit_heads, dim_head=vit_dim_head,
+                        mlp_dim=vit_mlp, dropout=0.1, emb_dropout=0.1, channels=f_maps[-1])
+    head = R.cls.Combine_classfier_vit_mid(seq_length=4)
+    head.vit_mid_linear = nn.Linear(H * W, 4)
+    ft = R.mt.Cross_mamba_both(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads)
+    ft.final_cross = R.xattn.CrossAttention(n_heads=heads, d_embed=dim, d_cross=D1 * D2)
+    load_det(gen, seed, "gen.")
+    load_det(head, seed, "head.")
+    load_det(ft, seed, "ft.")
+    return gen.eval(), head, ft
+
+
+def slices(t, n=256):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return npy(f[::step][:n].double())
+
+
+def run_step(R, gen, head, ft, vol, B, cards, n_cont, seed, full_grads):
+    x, x_cat, x_num, y = det.det_inputs(B, vol, cards, n_cont, seed=seed)
+    head.eval(); ft.eval()     # dropout off: parity fixtures are deterministic
+    with torch.no_grad():
+        mid_in, mid_out, pet = gen(x, output_vit_mid=True)
+    feat = head(mid_in, mid_out)
+    pred = ft(x_cat, x_num, feat, [x, pet])
+    loss = torch.nn.BCELoss()(torch.sigmoid(pred.squeeze(1)), y.float())
+    loss.backward()
+    params = [("head." + k, p) for k, p in head.named_parameters()] + [("ft." + k, p) for k, p in ft.named_parameters()]
+    fx = dict(pred=npy(pred.double()), loss=npy(loss.double()), feat=npy(feat.double()) if full_grads else slices(feat))
+    for name, t in (("mid_input", mid_in), ("mid_output", mid_out), ("pet", pet)):
+        fx[name + "_slice"] = slices(t)
+        fx[name + "_sum"] = npy(t.double().sum())
+        fx[name + "_abssum"] = npy(t.double().abs().sum())
+        if full_grads:
+            fx[name] = npy(t)
+    for k, p in params:
+        fx["gnorm." + k] = npy(p.grad.double().norm())
+        fx["gslice." + k] = slices(p.grad, 64)
+    # per-parameter clip (classify_mamba.py:106-107) then one Adam step (:64, :108)
+    allp = [p for _, p in params]
+    opt = torch.optim.Adam(allp, lr=1e-4)
+    for p in allp:
+        torch.nn.utils.clip_grad_norm_(p, max_norm=1.0)
+    before = [p.detach().clone() for p in allp]
+    opt.step()
+    for (k, p), b0 in zip(params, before):
+        fx["dnorm." + k] = npy((p.detach() - b0).double().norm())
+        fx["dslice." + k] = slices(p.detach() - b0, 64)
+    return fx
+
+
+def t1(R, out):
+    cards, n_cont, vol = (11, 2, 2, 4, 4, 3, 3), 25, (32, 32, 32)
+    gen, head, ft = build_reference_models(R, vol, (8, 16, 32), 64, 2, 8, 64, 2, 2, 16, 128, cards, n_cont, seed=11)
+    fx = run_step(R, gen, head, ft, vol, 2, cards, n_cont, seed=11, full_grads=True)
+    fx["meta"] = np.array([32, 32, 32, 8, 16, 32, 64, 2, 8, 64, 2, 2, 16, 128, 11])
+    np.savez_compressed(os.path.join(out, "t1_reduced_step.npz"), **fx)
+
+
+def t2(R, out):
+    cards, n_cont, vol = (11, 2, 2, 4, 4, 3, 3), 25, (96, 96, 96)
+    gen, head, ft = build_reference_models(R, vol, (64, 128, 256), 512, 6, 8, 512, 4, 6, 64, 2048, cards, n_cont, seed=21)
+    fx = run_step(R, gen, head, ft, vol, 2, cards, n_cont, seed=21, full_grads=False)
+    fx["meta"] = np.array([96, 96, 96, 64, 128, 256, 512, 6, 8, 512, 4, 6, 64, 2048, 21])
+    np.savez_compressed(os.path.join(out, "t2_full96_step.npz"), **fx)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_grad_enabled(True)
+    R = import_reference()
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2)):
+        if not a.only or a.only == name:
+            fn(R, a.out)
+            print("wrote", name)
