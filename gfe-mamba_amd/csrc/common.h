@@ -46,10 +46,18 @@ template <> struct IO<bf16_t> {
 #define GFE_LN2   0.6931471805599453f
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * GFE_LOG2E); }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * GFE_LN2; }   // v_log_f32 is log2
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp2(-x * GFE_LOG2E)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
-// torch.nn.functional.softplus(beta=1, threshold=20)
-__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+// torch.nn.functional.softplus(beta=1, threshold=20) = max(x,0) + log1p(exp(-|x|)); short series keeps relative
+// accuracy where 1+e would round away e (the reference's dt_proj.bias puts softplus outputs down to 1e-4).
+__device__ __forceinline__ float softplusf_(float x) {
+    if (x > 20.0f) return x;
+    const float e = fast_exp2(-fabsf(x) * GFE_LOG2E);
+    const float l = e < 0.0078125f ? e * fmaf(e, fmaf(e, 0.33333333f, -0.5f), 1.0f) : fast_log(1.0f + e);
+    return fmaxf(x, 0.0f) + l;
+}
 
 // ---- wave / block reductions -----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -411,6 +411,8 @@ int sscan_bwd_launch(const SScanBwdParams& p, hipStream_t st) {
     const int nsub = (p.T + S - 1) / S;
     const size_t lds = (size_t)nsub * N * 64 * sizeof(float);
     if (lds > 160 * 1024) return GFE_ERR_SHAPE;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)sscan_bwd_kernel<T, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
     hipLaunchKernelGGL((sscan_bwd_kernel<T, N, S>), dim3(p.ED / 64, p.nchunks, p.B), dim3(64), lds, st, p);
     return gfe_launch_status();
 }

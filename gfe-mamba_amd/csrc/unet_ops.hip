@@ -1,0 +1,226 @@
+// HBM-bound helpers of the frozen generator (channels-last bf16 activations): GroupNorm statistics, MaxPool3d(2),
+// the 1->C input lift and C->1 output projection (1x1x1 convs), and the bottleneck fold/unfold permutations.
+// Reference: pytorch3dunet/unet3d/buildingblocks.py:55-67 (GroupNorm before conv), :284,306-307 (MaxPool3d),
+// :191-196 (conv1 1x1x1 + bias), pytorch3dunet/unet3d/model.py:123,162 (final_conv), :150-152 (md1 fold/unfold).
+#include "common.h"
+
+namespace {
+
+// ---- GroupNorm statistics --------------------------------------------------------------------------------------
+// pass 1: per-block per-channel (sum, sumsq) partials, 16-B loads; pass 2 (one block per sample): f64 reduction over
+// blocks and over the channels of each group, then scale[b,c] = rstd*gamma, shift[b,c] = beta - mean*rstd*gamma, which
+// is what the conv kernel applies while staging its input tile.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws,
+                                                         int64_t S, int C, int vpb, int nblk) {
+    extern __shared__ float lds[];               // [2][C]
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int CP = C >> 3;                       // 16-B chunks per voxel
+    const int c = tid % CP, vl = tid / CP, VI = 256 / CP;
+    for (int i = tid; i < 2 * C; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    const int64_t v0 = (int64_t)blk * vpb;
+    const int64_t v1 = v0 + vpb < S ? v0 + vpb : S;
+    const bf16_t* xb = x + (size_t)b * S * C + c * 8;
+    for (int64_t v = v0 + vl; v < v1; v += VI) {
+        const uint4 w = *reinterpret_cast<const uint4*>(xb + (size_t)v * C);
+        const float f[8] = {bf16lo_to_f32(w.x), bf16hi_to_f32(w.x), bf16lo_to_f32(w.y), bf16hi_to_f32(w.y),
+                            bf16lo_to_f32(w.z), bf16hi_to_f32(w.z), bf16lo_to_f32(w.w), bf16hi_to_f32(w.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { atomicAdd(&lds[c * 8 + j], s[j]); atomicAdd(&lds[C + c * 8 + j], q[j]); }
+    __syncthreads();
+    float* o = ws + ((size_t)b * nblk + blk) * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) o[i] = lds[i];
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int64_t S, int C, int G, int nblk, float eps) {
+    extern __shared__ double dl[];               // [2][C] channel sums, then [2][G] mean / rstd
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < 2 * C; c += 256) {
+        double a = 0.0;
+        for (int k = 0; k < nblk; ++k) a += (double)ws[((size_t)b * nblk + k) * 2 * C + c];
+        dl[c] = a;
+    }
+    __syncthreads();
+    double* gm = dl + 2 * C;
+    const int cg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < cg; ++j) { s += dl[g * cg + j]; q += dl[C + g * cg + j]; }
+        const double n = (double)cg * (double)S;
+        const double mean = s / n;
+        double var = q / n - mean * mean;      // biased variance, as nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        gm[g] = mean; gm[G + g] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cg;
+        const float sc = (float)gm[G + g] * gamma[c];
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = beta[c] - (float)gm[g] * sc;
+    }
+}
+
+// ---- MaxPool3d(kernel 2, stride 2, floor) -------------------------------------------------------------------
+__device__ __forceinline__ uint32_t max_bf16x2(uint32_t a, uint32_t b) {
+    const float lo = fmaxf(bf16lo_to_f32(a), bf16lo_to_f32(b)), hi = fmaxf(bf16hi_to_f32(a), bf16hi_to_f32(b));
+    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);     // exact: inputs are bf16 values
+}
+__global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                      int B, int D, int H, int W, int C) {
+    const int CP = C >> 3, OD = D >> 1, OH = H >> 1, OW = W >> 1;
+    const int64_t total = (int64_t)B * OD * OH * OW * CP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CP); int64_t v = i / CP;
+        const int ow = (int)(v % OW); v /= OW;
+        const int oh = (int)(v % OH); v /= OH;
+        const int od = (int)(v % OD); const int b = (int)(v / OD);
+        uint4 m;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = 2 * od + (k >> 2), h = 2 * oh + ((k >> 1) & 1), w = 2 * ow + (k & 1);
+            const uint4 t = *reinterpret_cast<const uint4*>(x + ((((size_t)b * D + d) * H + h) * W + w) * C + c * 8);
+            if (first) { m = t; first = false; }
+            else { m.x = max_bf16x2(m.x, t.x); m.y = max_bf16x2(m.y, t.y); m.z = max_bf16x2(m.z, t.z); m.w = max_bf16x2(m.w, t.w); }
+        }
+        *reinterpret_cast<uint4*>(y + ((((size_t)b * OD + od) * OH + oh) * OW + ow) * C + c * 8) = m;
+    }
+}
+
+// ---- 1 -> C pointwise conv with bias (encoders.0.basic_module.conv1), input f32 or bf16 single channel ----------
+template <typename TI>
+__global__ __launch_bounds__(256) void conv_in1_kernel(const TI* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t nvox, int C) {
+    const int CP = C >> 3;
+    const int64_t total = nvox * CP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CP); const int64_t v = i / CP;
+        const float xv = IO<TI>::ld(x + v);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(w[c * 8 + j], xv, bias[c * 8 + j]);
+        *reinterpret_cast<uint4*>(y + (size_t)v * C + c * 8) =
+            make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    }
+}
+
+// ---- C -> 1 pointwise conv with bias (final_conv), output f32; 16-B lanes, C/8 lanes per voxel ------------------
+__global__ __launch_bounds__(256) void conv_out1_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, float bias,
+                                                        float* __restrict__ y, int64_t nvox, int C) {
+    const int CP = C >> 3;                       // power of two <= 64
+    const int64_t total = nvox * CP;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        float acc = 0.f;
+        if (i < total) {
+            const int c = (int)(i % CP);
+            const uint4 t = *reinterpret_cast<const uint4*>(x + (size_t)i * 8);
+            const float* wc = w + c * 8;
+            acc = bf16lo_to_f32(t.x) * wc[0] + bf16hi_to_f32(t.x) * wc[1] + bf16lo_to_f32(t.y) * wc[2] + bf16hi_to_f32(t.y) * wc[3] +
+                  bf16lo_to_f32(t.z) * wc[4] + bf16hi_to_f32(t.z) * wc[5] + bf16lo_to_f32(t.w) * wc[6] + bf16hi_to_f32(t.w) * wc[7];
+        }
+        for (int o = CP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (i < total && (i % CP) == 0) y[i / CP] = acc + bias;
+    }
+}
+
+// ---- bottleneck fold 'b c (md1 md2) h w -> b c (h md1) (md2 w)' on channels-last data, and its inverse ----------
+// src voxel (d = i1*md2 + i2, h, w)  <->  dst pixel (row = h*md1 + i1, col = i2*W + w); pure index permutation.
+__global__ __launch_bounds__(256) void fold_mid_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                       int B, int D, int H, int W, int C, int md1, int inverse) {
+    const int CP = C >> 3, md2 = D / md1;
+    const int64_t total = (int64_t)B * D * H * W * CP;
+    const int cols = md2 * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CP); int64_t v = i / CP;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H); v /= H;
+        const int d = (int)(v % D); const int b = (int)(v / D);
+        const int i1 = d / md2, i2 = d - i1 * md2;
+        const size_t vox = (((size_t)b * D + d) * H + h) * W + w;
+        const size_t pix = ((size_t)b * (H * md1) + (h * md1 + i1)) * cols + (i2 * W + w);
+        const size_t s = (inverse ? pix : vox) * C + c * 8, t = (inverse ? vox : pix) * C + c * 8;
+        *reinterpret_cast<uint4*>(dst + t) = *reinterpret_cast<const uint4*>(src + s);
+    }
+}
+
+static unsigned grid_for(int64_t total) {
+    int64_t g = ceil_div(total, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfe_groupnorm_plan(int64_t S, int* vox_per_block, int* nblk) {
+    int64_t vpb = ceil_div(S, 512);
+    if (vpb < 256) vpb = 256;
+    *vox_per_block = (int)vpb;
+    *nblk = (int)ceil_div(S, vpb);
+    return GFE_OK;
+}
+
+int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float* scale, float* shift, float* ws,
+                              int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream) {
+    GFE_REQUIRE(x && gamma && beta && scale && shift && ws, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && S > 0 && C >= 8 && C % 8 == 0 && (256 % (C / 8)) == 0 && G > 0 && C % G == 0 && G <= 256, GFE_ERR_SHAPE);
+    int vpb, nblk;
+    gfe_groupnorm_plan(S, &vpb, &nblk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, (unsigned)B), dim3(256), 2 * C * sizeof(float), st,
+                       (const bf16_t*)x, ws, S, (int)C, vpb, nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (2 * C + 2 * G) * sizeof(double), st,
+                       ws, gamma, beta, scale, shift, S, (int)C, (int)G, nblk, eps);
+    return gfe_launch_status();
+}
+
+int gfe_maxpool3d_2(const void* x, void* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, void* stream) {
+    GFE_REQUIRE(x && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && D >= 2 && H >= 2 && W >= 2 && C % 8 == 0, GFE_ERR_SHAPE);
+    const int64_t total = B * (D / 2) * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, (int)B, (int)D, (int)H, (int)W, (int)C);
+    return gfe_launch_status();
+}
+
+int gfe_conv_in1(const void* x, const float* w, const float* bias, void* y, int64_t nvox, int64_t C, int in_dtype, void* stream) {
+    GFE_REQUIRE(x && w && bias && y, GFE_ERR_NULL);
+    GFE_REQUIRE(nvox > 0 && C % 8 == 0, GFE_ERR_SHAPE);
+    const unsigned g = grid_for(nvox * (C / 8));
+    if (in_dtype == GFE_F32)
+        hipLaunchKernelGGL((conv_in1_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, bias, (bf16_t*)y, nvox, (int)C);
+    else if (in_dtype == GFE_BF16)
+        hipLaunchKernelGGL((conv_in1_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, bias, (bf16_t*)y, nvox, (int)C);
+    else return GFE_ERR_DTYPE;
+    return gfe_launch_status();
+}
+
+int gfe_conv_out1(const void* x, const float* w, float bias, float* y, int64_t nvox, int64_t C, void* stream) {
+    GFE_REQUIRE(x && w && y, GFE_ERR_NULL);
+    const int64_t CP = C / 8;
+    GFE_REQUIRE(nvox > 0 && C % 8 == 0 && CP <= 64 && (CP & (CP - 1)) == 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(conv_out1_kernel, dim3(grid_for(nvox * CP)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, bias, y, nvox, (int)C);
+    return gfe_launch_status();
+}
+
+int gfe_fold_mid(const void* src, void* dst, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int md1, int inverse, void* stream) {
+    GFE_REQUIRE(src && dst, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && md1 > 0 && D % md1 == 0 && C % 8 == 0, GFE_ERR_SHAPE);
+    const int64_t total = B * D * H * W * (C / 8);
+    hipLaunchKernelGGL(fold_mid_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, (int)B, (int)D, (int)H, (int)W, (int)C, md1, inverse);
+    return gfe_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+"""Tensor-level wrappers of the generator / GEMM / ViT entry points of include/gfe_hip.h.
+
+Pure plumbing: shape checks, output allocation (torch caching allocator), raw pointers + current stream.
+Activations of the generator are channels-last bf16: (B, D, H, W, C).
+"""
+import ctypes
+import itertools
+
+import numpy as np
+import torch
+
+from . import GFE_BF16, GFE_F32, call, dtype_code, lib, ptr, stream
+
+BF16 = torch.bfloat16
+
+
+def _i8(a):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.int8))
+    return arr, arr.ctypes.data
+
+
+def _i64(a):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.int64))
+    return arr, arr.ctypes.data
+
+
+def cout_pad(cout):
+    return lib().gfe_conv3d_cout_pad(cout)
+
+
+# ---- weight packing -----------------------------------------------------------------------------------------------
+CONV3_TAPS = [(kd - 1, kh - 1, kw - 1) for kd in range(3) for kh in range(3) for kw in range(3)]
+
+
+def _pack(w_tco, cin):
+    """w_tco: (ntaps, Cout, Cin) f32 -> [nslab][ntaps][CoutPad][32] bf16, zero padded."""
+    ntaps, cout, _ = w_tco.shape
+    nslab = (cin + 31) // 32
+    cp = cout_pad(cout)
+    buf = torch.zeros((ntaps, cp, nslab * 32), dtype=torch.float32, device=w_tco.device)
+    buf[:, :cout, :cin] = w_tco
+    return buf.view(ntaps, cp, nslab, 32).permute(2, 0, 1, 3).contiguous().to(BF16)
+
+
+def pack_conv3(weight):
+    """nn.Conv3d weight (Cout, Cin, 3, 3, 3) -> packed, tap order = CONV3_TAPS (cross-correlation: offset = k - 1)."""
+    cout, cin = weight.shape[:2]
+    return _pack(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(27, cout, cin), cin)
+
+
+def pack_conv1(weight):
+    """nn.Conv3d weight (Cout, Cin, 1, 1, 1) -> packed single tap."""
+    cout, cin = weight.shape[:2]
+    return _pack(weight.detach().float().reshape(1, cout, cin), cin)
+
+
+# per axis: output parity 0 (o = 2i): kernel index 1 at input offset 0; parity 1 (o = 2i+1): k=2 at offset 0, k=0 at offset +1
+_CT_AXIS = {0: [(0, 1)], 1: [(0, 2), (1, 0)]}
+
+
+def pack_convT(weight):
+    """nn.ConvTranspose3d weight (Cin, Cout, 3, 3, 3), stride 2, padding 1 -> {parity (pd,ph,pw): (packed, taps)}."""
+    cin, cout = weight.shape[:2]
+    w = weight.detach().float()
+    out = {}
+    for par in itertools.product((0, 1), repeat=3):
+        taps, mats = [], []
+        for (od, kd), (oh, kh), (ow, kw) in itertools.product(_CT_AXIS[par[0]], _CT_AXIS[par[1]], _CT_AXIS[par[2]]):
+            taps.append((od, oh, ow))
+            mats.append(w[:, :, kd, kh, kw].t())            # (Cout, Cin)
+        out[par] = (_pack(torch.stack(mats, 0), cin), taps)
+    return out
+
+
+# ---- generator ops --------------------------------------------------------------------------------------------------
+def conv_igemm(x, w_packed, taps, cout, gn=None, bias=None, res=None, relu=False, out=None, transposed=None):
+    """x: (B, D, H, W, Cin) bf16.  transposed: None, or (parity tuple, out tensor (B, 2D, 2H, 2W, Cout)) for one ConvT class."""
+    B, D, H, W, cin = x.shape
+    assert x.dtype == BF16 and x.is_contiguous()
+    tarr, tptr = _i8(taps)
+    if transposed is None:
+        if out is None:
+            out = torch.empty((B, D, H, W, cout), dtype=BF16, device=x.device)
+        OD, OH, OW = D, H, W
+        ostride, par, oshift = 1, (0, 0, 0), 0
+    else:
+        par, out = transposed
+        OD, OH, OW = out.shape[1:4]
+        ostride = 2
+        oshift = OD - (2 * D - 1)
+        assert oshift in (0, 1) and OH == 2 * H - 1 + oshift and OW == 2 * W - 1 + oshift, "unsupported upsampling size"
+    gs, gt = (gn if gn is not None else (None, None))
+    call("gfe_conv3d_igemm", ptr(x), ptr(w_packed), ptr(gs), ptr(gt), ptr(bias), ptr(res), ptr(out),
+         B, D, H, W, cin, cout, OD, OH, OW, len(taps), tptr, ostride, par[0], par[1], par[2], oshift, int(relu), stream())
+    return out
+
+
+def groupnorm_scale_shift(x, gamma, beta, groups, eps=1e-5):
+    """x: (B, ..., C) bf16 channels-last -> (scale, shift) each (B, C) f32."""
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    vpb, nblk = ctypes.c_int(), ctypes.c_int()
+    lib().gfe_groupnorm_plan(S, ctypes.byref(vpb), ctypes.byref(nblk))
+    ws = torch.empty((B, nblk.value, 2, C), dtype=torch.float32, device=x.device)
+    ss = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+    call("gfe_groupnorm_scale_shift", ptr(x), ptr(gamma), ptr(beta), ptr(ss[0]), ptr(ss[1]), ptr(ws), B, S, C, groups, eps, stream())
+    return ss[0], ss[1]
+
+
+def maxpool2(x):
+    B, D, H, W, C = x.shape
+    y = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    call("gfe_maxpool3d_2", ptr(x), ptr(y), B, D, H, W, C, stream())
+    return y
+
+
+def conv_in1(x, w, bias):
+    """x: (B, 1, D, H, W) f32|bf16 contiguous -> (B, D, H, W, C) bf16."""
+    B, _, D, H, W = x.shape
+    C = w.numel()
+    y = torch.empty((B, D, H, W, C), dtype=BF16, device=x.device)
+    call("gfe_conv_in1", ptr(x), ptr(w), ptr(bias), ptr(y), B * D * H * W, C, dtype_code(x.dtype), stream())
+    return y
+
+
+def conv_out1(x, w, bias_value):
+    """x: (B, D, H, W, C) bf16 -> (B, 1, D, H, W) f32."""
+    B, D, H, W, C = x.shape
+    y = torch.empty((B, 1, D, H, W), dtype=torch.float32, device=x.device)
+    call("gfe_conv_out1", ptr(x), ptr(w), float(bias_value), ptr(y), B * D * H * W, C, stream())
+    return y
+
+
+def fold_mid(x, md1=8, inverse=False, shape=None):
+    """forward: (B, D, H, W, C) -> (B, H*md1, (D/md1)*W, C); inverse: the opposite, `shape` = (D, H, W)."""
+    if not inverse:
+        B, D, H, W, C = x.shape
+        y = torch.empty((B, H * md1, (D // md1) * W, C), dtype=BF16, device=x.device)
+    else:
+        D, H, W = shape
+        B, C = x.shape[0], x.shape[-1]
+        y = torch.empty((B, D, H, W, C), dtype=BF16, device=x.device)
+    call("gfe_fold_mid", ptr(x), ptr(y), B, D, H, W, C, md1, int(inverse), stream())
+    return y
+
+
+# ---- GEMM / ViT ops ---------------------------------------------------------------------------------------------------
+def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=None):
+    """a: (M, K) bf16 (row stride allowed), b: (N, K) bf16 -> (M, N).  y = act(a b^T + bias) + res."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert a.dtype == BF16 and b.dtype == BF16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
+    if out is None:
+        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
+    call("gfe_gemm_bf16_nt", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),
+         ptr(res), 0 if res is None else res.stride(0), int(res is not None and res.dtype == torch.float32),
+         act, int(out.dtype == torch.float32), split_k, stream())
+    return out
+
+
+def transpose_bf16(x):
+    """(..., R, C) bf16 contiguous -> (..., C, R)."""
+    R, C = x.shape[-2:]
+    batch = x.numel() // (R * C)
+    y = torch.empty(x.shape[:-2] + (C, R), dtype=BF16, device=x.device)
+    call("gfe_transpose_bf16", ptr(x), ptr(y), batch, R, C, C, R, stream())
+    return y
+
+
+def cast(x, dtype):
+    x = x.contiguous()
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("gfe_cast", ptr(x), ptr(y), x.numel(), int(dtype == BF16), stream())
+    return y
+
+
+def contig_map(rows, length):
+    return [0, length, 0, 0, rows, 1, 1, length]
+
+
+def patch_map(Himg, Wimg, C, p):
+    """Row map of 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:96) on a channels-last (B, Himg, Wimg, C) image."""
+    return [Himg * Wimg * C, p * Wimg * C, p * C, Wimg * C, (Himg // p) * (Wimg // p), Wimg // p, p, p * C]
+
+
+def layernorm(x, gamma, beta, rows, length, out_dtype, in_map=None, out_map=None, out=None, out_shape=None, eps=1e-5):
+    im, ip = _i64(in_map or contig_map(rows, length))
+    om, op = _i64(out_map or contig_map(rows, length))
+    if out is None:
+        out = torch.empty(out_shape or (rows, length), dtype=out_dtype, device=x.device)
+    call("gfe_layernorm", ptr(x), ptr(out), ptr(gamma), ptr(beta), ip, op, rows, eps, dtype_code(x.dtype), dtype_code(out.dtype), stream())
+    return out
+
+
+def attention_small(q, k, v, B, H, nq, nk, dh, scale):
+    """q: (B*nq, >=H*dh) view, k/v: (B*nk, ...) views (row strides allowed) -> (B*nq, H*dh) bf16."""
+    o = torch.empty((B * nq, H * dh), dtype=BF16, device=q.device)
+    call("gfe_attention_small", ptr(q), ptr(k), ptr(v), ptr(o), B, H, nq, nk, dh,
+         nq * q.stride(0), q.stride(0), nk * k.stride(0), k.stride(0), nk * v.stride(0), v.stride(0), nq * H * dh, H * dh,
+         float(scale), stream())
+    return o
+
+
+def token_mix(x, w, bias, B, nin, nout, dim):
+    y = torch.empty((B, nout, dim), dtype=BF16, device=x.device)
+    call("gfe_token_mix", ptr(x), ptr(w), ptr(bias), ptr(y), B, nin, nout, dim, dtype_code(x.dtype), stream())
+    return y
+
+
+def vit_embed(tok, cls, pos, B, n, dim):
+    x = torch.empty((B, n + 1, dim), dtype=torch.float32, device=tok.device)
+    call("gfe_vit_embed", ptr(tok), ptr(cls), ptr(pos), ptr(x), B, n, dim, stream())
+    return x

@@ -1,0 +1,168 @@
+"""Building blocks of the residual 3D-UNet generator -- MI355X build.
+
+Same class names, constructor arguments and state-dict keys as the reference's
+pytorch3dunet/unet3d/buildingblocks.py (create_conv :10-86, SingleConv :89-115, ResNetBlock :180-229, Encoder :251-309,
+Decoder :312-400, create_encoders/decoders :403-461, TransposeConvUpsampling :498-542), restricted to the path
+`Residual_mid_UNet3D_vit` uses: ResNetBlock basic module, GroupNorm-before-conv orders ('gcr' / 'gc'), transposed-conv
+upsampling with summation joining.  The torch layers below only HOLD parameters; forward() runs the HIP kernels of
+libgfe_hip.so on channels-last bf16 activations (B, D, H, W, C).  Inference only (the generator is frozen:
+classify_mamba.py:53,100).
+"""
+import torch
+from torch import nn
+
+from gfe_hip import nn_ops as K
+
+
+class _PackCache:
+    """Packed bf16 weights, rebuilt when the source parameters change (load_state_dict / .to())."""
+
+    def __init__(self):
+        self.sig, self.val = None, None
+
+    def get(self, params, build):
+        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        if sig != self.sig:
+            with torch.no_grad():
+                self.val = build()
+            self.sig = sig
+        return self.val
+
+
+def _f32(p):
+    return p.detach().float().contiguous()
+
+
+class SingleConv(nn.Sequential):
+    """GroupNorm(in_channels) -> Conv3d(k3, p1, no bias) [-> ReLU]  (order 'gcr' / 'gc'; buildingblocks.py:38-67)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order='gcr', num_groups=8, padding=1, dropout_prob=0.1, is3d=True):
+        super().__init__()
+        assert is3d and kernel_size == 3 and padding == 1, "MI355X build covers the 3-D k3 p1 path"
+        assert order in ('gcr', 'gc'), f"layer order {order!r} is outside the hot path (GroupNorm before conv only)"
+        if in_channels < num_groups:
+            num_groups = 1                                           # buildingblocks.py:62-63
+        assert in_channels % num_groups == 0
+        self.add_module('groupnorm', nn.GroupNorm(num_groups=num_groups, num_channels=in_channels))
+        self.add_module('conv', nn.Conv3d(in_channels, out_channels, 3, padding=1, bias=False))
+        if 'r' in order:
+            self.add_module('ReLU', nn.ReLU(inplace=True))
+        self.relu = 'r' in order
+        self._pack = _PackCache()
+
+    def forward(self, x, residual=None):
+        """x: (B, D, H, W, Cin) bf16; optional residual is added before the (forced) ReLU: ResNetBlock tail."""
+        gn, conv = self.groupnorm, self.conv
+        w, g, b = self._pack.get([conv.weight, gn.weight, gn.bias],
+                                 lambda: (K.pack_conv3(conv.weight), _f32(gn.weight), _f32(gn.bias)))
+        ss = K.groupnorm_scale_shift(x, g, b, gn.num_groups, gn.eps)
+        return K.conv_igemm(x, w, K.CONV3_TAPS, conv.out_channels, gn=ss, res=residual, relu=self.relu or residual is not None)
+
+
+class ResNetBlock(nn.Module):
+    """r = conv1(x); o = conv3(conv2(r)); relu(o + r)  (buildingblocks.py:218-229; ReLU because order has no 'l'/'e')."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order='gcr', num_groups=8, is3d=True, **kwargs):
+        super().__init__()
+        self.conv1 = nn.Conv3d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
+        self.conv2 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups, is3d=is3d)
+        n_order = order
+        for c in 'rel':
+            n_order = n_order.replace(c, '')
+        self.conv3 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=n_order, num_groups=num_groups, is3d=is3d)
+        assert 'l' not in order and 'e' not in order
+        self.non_linearity = nn.ReLU(inplace=True)
+        self._pack = _PackCache()
+
+    def lift(self, x):
+        """conv1: 1x1x1 conv + bias; accepts the raw (B, 1, D, H, W) volume when in_channels == 1."""
+        c1 = self.conv1
+        if isinstance(c1, nn.Identity):
+            return x
+        if c1.in_channels == 1:
+            w, b = self._pack.get([c1.weight, c1.bias], lambda: (_f32(c1.weight).view(-1), _f32(c1.bias)))
+            return K.conv_in1(x, w, b)
+        w, b = self._pack.get([c1.weight, c1.bias], lambda: (K.pack_conv1(c1.weight), _f32(c1.bias)))
+        return K.conv_igemm(x, w, [(0, 0, 0)], c1.out_channels, bias=b)
+
+    def forward(self, x):
+        r = self.lift(x)
+        o = self.conv2(r)
+        return self.conv3(o, residual=r)
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels, out_channels, conv_kernel_size=3, apply_pooling=True, pool_kernel_size=2, pool_type='max',
+                 basic_module=ResNetBlock, conv_layer_order='gcr', num_groups=8, padding=1, upscale=2, dropout_prob=0.1, is3d=True):
+        super().__init__()
+        assert pool_type == 'max' and pool_kernel_size == 2 and is3d
+        self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
+        self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
+                                         order=conv_layer_order, num_groups=num_groups, padding=padding, upscale=upscale,
+                                         dropout_prob=dropout_prob, is3d=is3d)
+
+    def forward(self, x):
+        if self.pooling is not None:
+            x = K.maxpool2(x)
+        return self.basic_module(x)
+
+
+class TransposeConvUpsampling(nn.Module):
+    """ConvTranspose3d(k3, s2, p1, no bias) then nearest resize to the encoder feature size (buildingblocks.py:498-542)."""
+
+    class Upsample(nn.Module):
+        def __init__(self, conv_transposed, is3d):
+            super().__init__()
+            self.conv_transposed = conv_transposed
+            self.is3d = is3d
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, scale_factor=2, is3d=True):
+        super().__init__()
+        assert is3d and kernel_size == 3 and scale_factor == 2
+        self.upsample = self.Upsample(nn.ConvTranspose3d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False), is3d)
+        self._pack = _PackCache()
+
+    def forward(self, encoder_features, x):
+        """Returns encoder_features + resize(convT(x)) -- the upsampling AND the summation join (buildingblocks.py:396-400)."""
+        ct = self.upsample.conv_transposed
+        classes = self._pack.get([ct.weight], lambda: K.pack_convT(ct.weight))
+        out = torch.empty_like(encoder_features)
+        for par, (w, taps) in classes.items():
+            K.conv_igemm(x, w, taps, ct.out_channels, res=encoder_features, transposed=(par, out))
+        return out
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels, out_channels, conv_kernel_size=3, scale_factor=2, basic_module=ResNetBlock,
+                 conv_layer_order='gcr', num_groups=8, padding=1, upsample='default', dropout_prob=0.1, is3d=True):
+        super().__init__()
+        assert basic_module is ResNetBlock and upsample in ('default', 'deconv'), "hot path = deconv upsampling + summation join"
+        self.upsampling = TransposeConvUpsampling(in_channels, out_channels, kernel_size=conv_kernel_size, scale_factor=scale_factor, is3d=is3d)
+        self.basic_module = basic_module(out_channels, out_channels, encoder=False, kernel_size=conv_kernel_size,
+                                         order=conv_layer_order, num_groups=num_groups, padding=padding,
+                                         dropout_prob=dropout_prob, is3d=is3d)
+
+    def forward(self, encoder_features, x):
+        x = self.upsampling(encoder_features, x)          # upsample + nearest resize + sum join, one fused epilogue
+        return self.basic_module(x)
+
+
+def create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob,
+                    layer_order, num_groups, pool_kernel_size, is3d):
+    encoders = []
+    for i, out_feature_num in enumerate(f_maps):
+        encoders.append(Encoder(in_channels if i == 0 else f_maps[i - 1], out_feature_num, apply_pooling=i > 0,
+                                basic_module=basic_module, conv_layer_order=layer_order, conv_kernel_size=conv_kernel_size,
+                                num_groups=num_groups, pool_kernel_size=pool_kernel_size, padding=conv_padding,
+                                upscale=conv_upscale, dropout_prob=dropout_prob, is3d=is3d))
+    return nn.ModuleList(encoders)
+
+
+def create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_order, num_groups, upsample, dropout_prob, is3d):
+    decoders = []
+    rev = list(reversed(f_maps))
+    for i in range(len(rev) - 1):
+        decoders.append(Decoder(rev[i], rev[i + 1], basic_module=basic_module, conv_layer_order=layer_order,
+                                conv_kernel_size=conv_kernel_size, num_groups=num_groups, padding=conv_padding,
+                                upsample=upsample, dropout_prob=dropout_prob, is3d=is3d))
+    return nn.ModuleList(decoders)

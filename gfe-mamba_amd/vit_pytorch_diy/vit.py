@@ -1,0 +1,132 @@
+"""Modified lucidrains ViT with `from_patch_embedding` (reference: vit_pytorch_diy/vit.py:83-137) -- MI355X build.
+
+Same constructor kwargs and state-dict keys (to_patch_embedding.{1,2,3}, from_patch_embedding.{0,2,4,5}, pos_embedding,
+cls_token, transformer.layers.{l}.{0,1}..., transformer.norm).  torch layers only hold parameters; forward() runs HIP
+kernels on a channels-last bf16 image (B, H, W, C) and returns the same layout.  Eval-mode semantics (dropouts are
+identities): the ViT only lives inside the frozen generator.
+"""
+import torch
+from torch import nn
+
+from gfe_hip import nn_ops as K
+from gfe_hip.nn_ops import BF16
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class FeedForward(nn.Module):          # vit.py:14-27
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class Attention(nn.Module):            # vit.py:29-63
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self.norm = nn.LayerNorm(dim)
+        self.attend = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        project_out = not (heads == 1 and dim_head == dim)
+        assert project_out, "heads == 1 and dim_head == dim is outside the hot path"
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
+
+
+class Transformer(nn.Module):          # vit.py:65-81
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.layers = nn.ModuleList([nn.ModuleList([Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout),
+                                                    FeedForward(dim, mlp_dim, dropout=dropout)]) for _ in range(depth)])
+
+
+class ViT(nn.Module):
+    def __init__(self, *, image_size, patch_size, dim, depth, heads, mlp_dim, pool='cls', channels=3, dim_head=64,
+                 dropout=0., emb_dropout=0.):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+        patch_height, patch_width = pair(patch_size)
+        assert image_height % patch_height == 0 and image_width % patch_width == 0, 'Image dimensions must be divisible by the patch size.'
+        assert patch_height == patch_width, "square patches (reference: patch_size=40)"
+        assert pool in {'cls', 'mean'}
+        num_patches = (image_height // patch_height) * (image_width // patch_width)
+        patch_dim = channels * patch_height * patch_width
+        self.image_size, self.patch, self.channels, self.dim = (image_height, image_width), patch_height, channels, dim
+        self.num_patches, self.patch_dim = num_patches, patch_dim
+        # index 0 / 1,3 / 6 are the reference's parameter-free Rearrange layers (vit.py:96, 104, 106, 109)
+        self.to_patch_embedding = nn.Sequential(nn.Identity(), nn.LayerNorm(patch_dim), nn.Linear(patch_dim, dim), nn.LayerNorm(dim))
+        self.from_patch_embedding = nn.Sequential(nn.LayerNorm(dim), nn.Identity(), nn.Linear(num_patches + 1, num_patches),
+                                                  nn.Identity(), nn.Linear(dim, patch_dim), nn.LayerNorm(patch_dim), nn.Identity())
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.pool = pool
+        self.to_latent = nn.Identity()
+        self._sig, self._w = None, None
+
+    # ---- packed / cast weights (rebuilt when parameters change) -------------------------------------------------
+    def _weights(self):
+        params = list(self.parameters())
+        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        if sig != self._sig:
+            with torch.no_grad():
+                f = lambda p: p.detach().float().contiguous()
+                h = lambda p: K.cast(p.detach().float(), BF16)
+                tpe, fpe = self.to_patch_embedding, self.from_patch_embedding
+                w = dict(ln_p=(f(tpe[1].weight), f(tpe[1].bias)), w_embed=h(tpe[2].weight), b_embed=f(tpe[2].bias),
+                         ln_e=(f(tpe[3].weight), f(tpe[3].bias)), cls=f(self.cls_token).view(-1), pos=f(self.pos_embedding).view(-1, self.dim),
+                         ln_t=(f(self.transformer.norm.weight), f(self.transformer.norm.bias)),
+                         ln_f=(f(fpe[0].weight), f(fpe[0].bias)), w_tok=f(fpe[2].weight), b_tok=f(fpe[2].bias),
+                         w_un=h(fpe[4].weight), b_un=f(fpe[4].bias), ln_u=(f(fpe[5].weight), f(fpe[5].bias)), layers=[])
+                for attn, ff in self.transformer.layers:
+                    w["layers"].append(dict(ln1=(f(attn.norm.weight), f(attn.norm.bias)), wqkv=h(attn.to_qkv.weight),
+                                            wo=h(attn.to_out[0].weight), bo=f(attn.to_out[0].bias),
+                                            ln2=(f(ff.net[0].weight), f(ff.net[0].bias)), w1=h(ff.net[1].weight), b1=f(ff.net[1].bias),
+                                            w2=h(ff.net[4].weight), b2=f(ff.net[4].bias)))
+            self._w, self._sig = w, sig
+        return self._w
+
+    def forward(self, img):
+        """img: channels-last bf16 (B, H, W, C) [the generator's native layout] or NCHW float (converted).  Returns the
+        same layout it was given.  vit.py:124-137 (eval mode)."""
+        nchw = img.dim() == 4 and img.shape[1] == self.channels and img.shape[-1] != self.channels
+        if nchw:
+            img = K.cast(img.permute(0, 2, 3, 1).contiguous().float(), BF16)
+        assert img.is_cuda, "no CPU fallback"
+        B, Himg, Wimg, C = img.shape
+        assert (Himg, Wimg) == self.image_size and C == self.channels and img.dtype == BF16
+        w, p, n, dim, pd = self._weights(), self.patch, self.num_patches, self.dim, self.patch_dim
+        pm = K.patch_map(Himg, Wimg, C, p)
+        # to_patch_embedding: patchify + LN(patch_dim) -> Linear -> LN(dim)   (vit.py:95-100)
+        tok = K.layernorm(img, *w["ln_p"], rows=B * n, length=pd, out_dtype=BF16, in_map=pm)
+        mblk, nblk = -(-B * n // 64), -(-dim // 128)
+        split = max(1, min(pd // 512, -(-768 // (mblk * nblk))))
+        emb = K.gemm_nt(tok, w["w_embed"], bias=w["b_embed"], out_dtype=torch.float32, split_k=split)
+        emb = K.layernorm(emb, *w["ln_e"], rows=B * n, length=dim, out_dtype=torch.float32)
+        x = K.vit_embed(emb, w["cls"], w["pos"], B, n, dim).view(B * (n + 1), dim)          # vit.py:127-130
+        T = n + 1
+        heads, dh = self.transformer.layers[0][0].heads, self.transformer.layers[0][0].dim_head
+        inner = heads * dh
+        for lw in w["layers"]:                                                              # vit.py:76-79
+            h = K.layernorm(x, *lw["ln1"], rows=B * T, length=dim, out_dtype=BF16)
+            qkv = K.gemm_nt(h, lw["wqkv"])
+            o = K.attention_small(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, heads, T, T, dh, dh ** -0.5)
+            x = K.gemm_nt(o, lw["wo"], bias=lw["bo"], res=x, out_dtype=torch.float32)
+            h = K.layernorm(x, *lw["ln2"], rows=B * T, length=dim, out_dtype=BF16)
+            h = K.gemm_nt(h, lw["w1"], bias=lw["b1"], act=1)
+            x = K.gemm_nt(h, lw["w2"], bias=lw["b2"], res=x, out_dtype=torch.float32)
+        x = K.layernorm(x, *w["ln_t"], rows=B * T, length=dim, out_dtype=torch.float32)       # vit.py:81
+        # from_patch_embedding (vit.py:102-110)
+        x = K.layernorm(x, *w["ln_f"], rows=B * T, length=dim, out_dtype=torch.float32)
+        t = K.token_mix(x, w["w_tok"], w["b_tok"], B, T, n, dim).view(B * n, dim)
+        big = K.gemm_nt(t, w["w_un"], bias=w["b_un"])
+        out = K.layernorm(big, *w["ln_u"], rows=B * n, length=pd, out_dtype=BF16, out_map=pm, out_shape=(B, Himg, Wimg, C))
+        if nchw:
+            return out.permute(0, 3, 1, 2).float()
+        return out

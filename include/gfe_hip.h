@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 1
+#define GFE_ABI_VERSION 3
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -79,6 +79,97 @@ int gfe_pscan_fwd(const void* A, const void* X, void* H, float* ws,
 /* PScan.backward (pscan.py:188-224): gX = reverse scan of gH with A shifted left by one; gA[t] = H[t-1]*gX[t], gA[0] = 0. */
 int gfe_pscan_bwd(const void* A, const void* H, const void* gH, void* gA, void* gX, float* ws,
                   int64_t B, int64_t L, int64_t DN, int T, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Group C -- frozen generator (pytorch3dunet/unet3d), channels-last (NDHWC) bf16 activations
+ * ------------------------------------------------------------------------------------------- */
+
+/* Padded output-channel count of the packed weight layout used by gfe_conv3d_igemm. Host-only. */
+int gfe_conv3d_cout_pad(int64_t Cout);
+
+/* Implicit-GEMM convolution described by a tap list: y[v] = sum_t W[t] . x[v + off(t)].
+ * Replaces, depending on the tap list / flags:
+ *   SingleConv 'gcr'/'gc' = GroupNorm -> Conv3d k3 p1 no-bias [-> ReLU]  (buildingblocks.py:38-67): 27 taps, gn_scale/shift
+ *   ResNetBlock.conv1 = Conv3d k1 + bias (buildingblocks.py:191-196): 1 tap, bias
+ *   ResNetBlock tail `out += residual; ReLU` (buildingblocks.py:226-227): res + relu
+ *   TransposeConvUpsampling = ConvTranspose3d k3 s2 p1 no-bias -> F.interpolate(nearest, 2n-1 -> 2n) -> `encoder_features + x`
+ *   (buildingblocks.py:396-400, 523-537): 8 calls, one per output parity class (ostride 2, op_* parity, oshift 1, res = skip)
+ *   x: (B, D, H, W, Cin) bf16.  y, res: (B, OD, OH, OW, Cout) bf16.  Cin % 8 == 0, Cout % 8 == 0.
+ *   w_packed: [ceil(Cin/32)][ntaps][gfe_conv3d_cout_pad(Cout)][32] bf16, zero padded (tap order = tap_offsets order).
+ *   gn_scale, gn_shift: (B, Cin) f32 from gfe_groupnorm_scale_shift, or both NULL.  bias: (Cout) f32 or NULL.
+ *   tap_offsets: HOST pointer, ntaps x 3 int8 (dd, dh, dw) each in [-1, 1].
+ *   ostride 1: OD,OH,OW == D,H,W.  ostride 2: output index = 2*i + op_*, shifted by oshift (0/1) with index 0 duplicated
+ *   (nearest resize 2n-1 -> 2n: dst j <- src max(j-1, 0)); OD == 2*D - 1 + oshift. */
+int gfe_conv3d_igemm(const void* x, const void* w_packed, const float* gn_scale, const float* gn_shift, const float* bias,
+                     const void* res, void* y,
+                     int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                     int64_t OD, int64_t OH, int64_t OW,
+                     int ntaps, const int8_t* tap_offsets,
+                     int ostride, int op_d, int op_h, int op_w, int oshift, int relu, void* stream);
+
+/* GroupNorm statistics -> per-(sample, channel) affine: scale = rstd*gamma, shift = beta - mean*rstd*gamma
+ * (nn.GroupNorm(G, C), eps, biased variance; buildingblocks.py:55-67).  x: (B, S, C) bf16 channels-last, S = D*H*W.
+ * ws: (B, nblk, 2, C) f32 workspace, nblk from gfe_groupnorm_plan.  scale, shift: (B, C) f32. */
+int gfe_groupnorm_plan(int64_t S, int* vox_per_block, int* nblk);
+int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float* scale, float* shift, float* ws,
+                              int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream);
+
+/* MaxPool3d(kernel 2, stride 2) (buildingblocks.py:284): (B, D, H, W, C) -> (B, D/2, H/2, W/2, C) bf16. */
+int gfe_maxpool3d_2(const void* x, void* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, void* stream);
+
+/* encoders.0.basic_module.conv1: Conv3d(1, C, 1) + bias (buildingblocks.py:191-196). x: (nvox) f32|bf16 -> y: (nvox, C) bf16. */
+int gfe_conv_in1(const void* x, const float* w, const float* bias, void* y, int64_t nvox, int64_t C, int in_dtype, void* stream);
+
+/* final_conv: Conv3d(C, 1, 1) + bias (pytorch3dunet/unet3d/model.py:123,162). x: (nvox, C) bf16 -> y: (nvox) f32. */
+int gfe_conv_out1(const void* x, const float* w, float bias, float* y, int64_t nvox, int64_t C, void* stream);
+
+/* Bottleneck fold 'b c (md1 md2) h w -> b c (h md1) (md2 w)' (model.py:150) on channels-last data:
+ * src (B, D, H, W, C) -> dst (B, H*md1, (D/md1)*W, C); inverse != 0 runs model.py:152 (dst layout -> src layout). */
+int gfe_fold_mid(const void* src, void* dst, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int md1, int inverse, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM (every nn.Linear of the path)
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[M][N] = act(A[M][K] . B[N][K]^T + bias) + res   -- y = x W^T + b with W stored (N, K) like nn.Linear.weight.
+ *   A, B bf16 (lda, ldb in elements, multiples of 8; K % 8 == 0, N % 4 == 0).  bias (N) f32 or NULL.
+ *   res: (M, ldres) bf16|f32 or NULL.  act: 0 none, 1 exact-erf GELU.  C: bf16 or f32 (out_f32).
+ *   split_k > 1: K is cut into split_k ranges accumulated with f32 atomics into a ZEROED f32 C (no act/res). */
+int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
+                     int act, int out_f32, int split_k, void* stream);
+
+/* out[b][c][r] = in[b][r][c], bf16 (operand re-layout for dgrad / wgrad). */
+int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream);
+
+/* f32 <-> bf16 element cast (to_bf16 != 0: f32 -> bf16). */
+int gfe_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bottleneck ViT helpers (vit_pytorch_diy/vit.py)
+ * ------------------------------------------------------------------------------------------- */
+
+/* LayerNorm(len) with affine f32 gamma/beta over `rows` logical rows (nn.LayerNorm, eps; vit.py:97,99,103,108 and every
+ * pre-LN of the blocks).  Rows may be stored as `nseg` contiguous segments so that the patchify / un-patchify
+ * rearranges (vit.py:96, 109) are folded into the load / store addressing.
+ * in_map / out_map: HOST int64[8] = {batch_stride, outer_stride, inner_stride, seg_stride, rows_per_batch, n_inner, nseg, seglen}:
+ *   base(r, s) = (r / rpb)*batch_stride + ((r % rpb) / n_inner)*outer_stride + ((r % rpb) % n_inner)*inner_stride + s*seg_stride. */
+int gfe_layernorm(const void* x, void* y, const float* gamma, const float* beta, const int64_t* in_map, const int64_t* out_map,
+                  int64_t rows, float eps, int in_dtype, int out_dtype, void* stream);
+
+/* softmax(q k^T * scale) v per (batch, head) for short sequences (vit.py:55-62; also CrossAttention sd_cross_atten.py:61-65).
+ * bf16 q/k/v/o addressed as base + b*batch_stride + row*row_stride + h*dh + c.  nk <= 256, dh <= 64. */
+int gfe_attention_small(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dh,
+                        int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
+                        int64_t o_batch, int64_t o_row, float scale, void* stream);
+
+/* from_patch_embedding's Linear over the token axis (vit.py:104-106): y[b][j][:] = sum_i W[j][i] x[b][i][:] + bias[j].
+ * x: (B, nin, dim) f32|bf16, W: (nout, nin) f32, y: (B, nout, dim) bf16. */
+int gfe_token_mix(const void* x, const float* w, const float* bias, void* y, int64_t B, int64_t nin, int64_t nout, int64_t dim,
+                  int in_dtype, void* stream);
+
+/* cls token + positional embedding (vit.py:127-130): x[b][0] = cls + pos[0], x[b][1+i] = tok[b][i] + pos[1+i]; all f32. */
+int gfe_vit_embed(const float* tok, const float* cls, const float* pos, float* x, int64_t B, int64_t n, int64_t dim, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,187 @@
+"""GPU parity of the generator kernels (conv3d implicit GEMM, GroupNorm, pool, transposed conv, fold, ViT, GEMM) against
+reference-generated fixtures and the oracle.  bf16 activations -> tolerance 1e-2 rel (BASELINE.json north_star);
+index permutations and max-pool are bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, rel_err, sub_sd, tt
+from oracle import ref_ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-2
+BF = torch.bfloat16
+
+
+def cl(x):
+    """NCDHW f32 -> channels-last bf16 on the GPU."""
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(BF).to(DEV)
+
+
+def ncdhw(y):
+    return y.float().permute(0, 4, 1, 2, 3).cpu()
+
+
+def test_gemm_epilogues_and_splitk():
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K_) in [(192, 512, 4096), (200, 1152, 512), (37, 64, 1024), (300, 2048, 512), (1536, 512, 9216), (129, 132, 72)]:
+        a = torch.randn(M, K_, generator=g).to(BF)
+        b = (torch.randn(N, K_, generator=g) / K_ ** 0.5).to(BF)
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        ref = a.double() @ b.double().t()
+        ad, bd = a.to(DEV), b.to(DEV)
+        assert rel_err(K.gemm_nt(ad, bd, out_dtype=torch.float32), ref) < 2e-5
+        assert rel_err(K.gemm_nt(ad, bd), ref) < 5e-3                                  # bf16 output rounding
+        assert rel_err(K.gemm_nt(ad, bd, bias=bias.to(DEV), out_dtype=torch.float32, split_k=7), ref + bias.double()) < 2e-5
+        got = K.gemm_nt(ad, bd, bias=bias.to(DEV), res=res.to(DEV), act=1, out_dtype=torch.float32)
+        assert rel_err(got, F.gelu(ref + bias.double()) + res.double()) < 2e-5
+        got = K.gemm_nt(ad, bd, res=res.to(BF).to(DEV), out_dtype=torch.float32)
+        assert rel_err(got, ref + res.to(BF).double()) < 2e-5
+    x = torch.randn(3, 70, 130, generator=g).to(BF).to(DEV)
+    assert torch.equal(K.transpose_bf16(x), x.transpose(1, 2).contiguous())
+    f = torch.randn(1003, generator=g).to(DEV)
+    assert torch.equal(K.cast(f, BF), f.to(BF)) and torch.equal(K.cast(f.to(BF), torch.float32), f.to(BF).float())
+
+
+@pytest.mark.parametrize("C,shape", [(8, (2, 8, 8, 8)), (16, (1, 6, 8, 4)), (64, (2, 8, 16, 16)), (128, (1, 4, 8, 24)), (256, (1, 5, 8, 8))])
+def test_groupnorm_conv3_relu_residual(C, shape):
+    """GroupNorm -> Conv3d k3 p1 -> (+residual) -> ReLU for every channel width of the generator, odd sizes included."""
+    from gfe_hip import nn_ops as K
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, C, D, H, W, generator=g) * 2 + 0.5
+    w = torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    res = torch.randn(B, C, D, H, W, generator=g)
+    xb, rb = x.to(BF).float(), res.to(BF).float()
+    ref = F.relu(F.conv3d(F.group_norm(xb, 8, gamma, beta), w.to(BF).float(), padding=1) + rb)
+    xd = cl(x)
+    ss = K.groupnorm_scale_shift(xd, gamma.to(DEV), beta.to(DEV), 8)
+    # statistics against torch
+    xf = xb.view(B, 8, -1)
+    mean, var = xf.mean(-1), xf.var(-1, unbiased=False)
+    sc_ref = (1 / torch.sqrt(var + 1e-5)).repeat_interleave(C // 8, 1) * gamma
+    assert rel_err(ss[0], sc_ref) < 1e-4
+    y = K.conv_igemm(xd, K.pack_conv3(w.to(DEV)), K.CONV3_TAPS, C, gn=ss, res=cl(res), relu=True)
+    assert rel_err(ncdhw(y), ref) < TOL
+
+
+def test_resnet_block_vs_reference_fixture():
+    from pytorch3dunet.unet3d.buildingblocks import ResNetBlock
+    fx = golden("t0_unet_ops.npz")
+    for name, cin, cout in (("rb", 8, 16), ("rb2", 16, 16)):
+        m = ResNetBlock(cin, cout, kernel_size=3, order="gcr", num_groups=8)
+        m.load_state_dict(sub_sd(fx, name + ".sd."))
+        m = m.to(DEV)
+        y = m(cl(tt(fx[name + ".x"])))
+        assert rel_err(ncdhw(y), tt(fx[name + ".out"])) < TOL, name
+
+
+def test_decoder_vs_reference_fixture():
+    """ConvTranspose3d k3 s2 p1 -> nearest resize (first plane duplicated) -> + skip -> ResNetBlock."""
+    from pytorch3dunet.unet3d.buildingblocks import Decoder, ResNetBlock
+    fx = golden("t0_unet_ops.npz")
+    m = Decoder(16, 8, basic_module=ResNetBlock, conv_layer_order="gcr", num_groups=8, upsample="default")
+    m.load_state_dict(sub_sd(fx, "dec.sd."))
+    m = m.to(DEV)
+    x, ef = cl(tt(fx["dec.x"])), cl(tt(fx["dec.ef"]))
+    zero = torch.zeros_like(ef)
+    up = m.upsampling(zero, x)                      # skip = 0 isolates the upsampling
+    assert rel_err(ncdhw(up), tt(fx["dec.up"])) < TOL
+    assert rel_err(ncdhw(m(ef, x)), tt(fx["dec.out"])) < TOL
+
+
+def test_maxpool_and_fold_are_bit_exact():
+    from gfe_hip import nn_ops as K
+    fx = golden("t0_unet_ops.npz")
+    x = tt(fx["mp.x"]).repeat(1, 2, 1, 1, 1).to(BF)                 # 8 channels
+    assert torch.equal(ncdhw(K.maxpool2(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV))), F.max_pool3d(x.float(), 2))
+    g = torch.Generator().manual_seed(1)
+    for shp in ((24, 24, 24), (8, 8, 8), (40, 6, 4), (32, 32, 32)):
+        v = torch.randn(2, 16, *shp, generator=g).to(BF)
+        vd = v.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+        f = K.fold_mid(vd)
+        assert torch.equal(f.permute(0, 3, 1, 2).cpu(), O.fold_mid(v))            # model.py:150, oracle pinned to einops fixture
+        assert torch.equal(K.fold_mid(f, inverse=True, shape=shp), vd)             # model.py:152
+
+
+def test_pointwise_convs():
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 1, 4, 6, 8, generator=g)
+    w, b = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    y = K.conv_in1(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert rel_err(ncdhw(y), F.conv3d(x, w.view(64, 1, 1, 1, 1), b)) < 5e-3
+    xc = torch.randn(2, 64, 4, 6, 8, generator=g).to(BF)
+    wo = torch.randn(64, generator=g)
+    p = K.conv_out1(xc.permute(0, 2, 3, 4, 1).contiguous().to(DEV), wo.to(DEV), 0.25)
+    assert rel_err(p, F.conv3d(xc.float(), wo.view(1, 64, 1, 1, 1), torch.tensor([0.25]))) < 1e-5
+    # generic 1x1x1 conv with bias through the implicit GEMM (encoders.1/2 conv1)
+    x2 = torch.randn(1, 64, 4, 8, 8, generator=g)
+    w2, b2 = torch.randn(128, 64, 1, 1, 1, generator=g) / 8, torch.randn(128, generator=g)
+    y2 = K.conv_igemm(cl(x2), K.pack_conv1(w2.to(DEV)), [(0, 0, 0)], 128, bias=b2.to(DEV))
+    assert rel_err(ncdhw(y2), F.conv3d(x2.to(BF).float(), w2.to(BF).float(), b2)) < 5e-3
+
+
+def test_layernorm_attention_tokenmix():
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(50, 512, generator=g) * 3 + 1
+    ga, be = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    ref = F.layer_norm(x, (512,), ga, be)
+    assert rel_err(K.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), 50, 512, torch.float32), ref) < 1e-5
+    assert rel_err(K.layernorm(x.to(BF).to(DEV), ga.to(DEV), be.to(DEV), 50, 512, BF), F.layer_norm(x.to(BF).float(), (512,), ga, be)) < 1e-2
+    B, H, n, dh = 3, 6, 25, 64
+    qkv = torch.randn(B * n, 3 * H * dh, generator=g).to(BF)
+    q, k, v = [t.float().view(B, n, H, dh).transpose(1, 2) for t in qkv.chunk(3, -1)]
+    ref = (F.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, -1) @ v).transpose(1, 2).reshape(B * n, H * dh)
+    qd = qkv.to(DEV)
+    o = K.attention_small(qd[:, :H * dh], qd[:, H * dh:2 * H * dh], qd[:, 2 * H * dh:], B, H, n, n, dh, dh ** -0.5)
+    assert rel_err(o, ref) < 1e-2
+    xt = torch.randn(2, 25, 64, generator=g)
+    w, b = torch.randn(24, 25, generator=g), torch.randn(24, generator=g)
+    ref = (xt.transpose(1, 2) @ w.t() + b).transpose(1, 2)
+    assert rel_err(K.token_mix(xt.to(DEV), w.to(DEV), b.to(DEV), 2, 25, 24, 64), ref) < 1e-2
+
+
+def test_vit_vs_reference_fixture():
+    from vit_pytorch_diy import ViT
+    fx = golden("t0_vit.npz")
+    m = ViT(image_size=(64, 8), patch_size=8, dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128, channels=32, dropout=0.1, emb_dropout=0.1)
+    m.load_state_dict(sub_sd(fx, "sd."))
+    m = m.to(DEV).eval()
+    x = tt(fx["x"])
+    y = m(x.permute(0, 2, 3, 1).contiguous().to(BF).to(DEV))       # channels-last in -> channels-last out
+    assert rel_err(y.permute(0, 3, 1, 2), tt(fx["out"])) < 2e-2
+    y2 = m(x.to(DEV))                                              # NCHW float boundary
+    assert y2.shape == x.shape and rel_err(y2, tt(fx["out"])) < 2e-2
+
+
+def _t1_models():
+    import gfe_hip.det_init as det
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(8, 16, 32), vol_size=(32, 32, 32),
+                                  vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128))
+    gen.load_state_dict(det.det_state_dict(gen.state_dict(), seed=11, prefix="gen."))
+    return gen.to(DEV).eval(), det
+
+
+def test_generator_reduced_vs_reference_fixture():
+    """T1: the reference generator (f_maps (8,16,32), 32^3) run on CPU by tools/make_golden.py vs the HIP generator."""
+    fx = golden("t1_reduced_step.npz")
+    gen, det = _t1_models()
+    x, _, _, _ = det.det_inputs(2, (32, 32, 32), seed=11)
+    mid_in, mid_out, pet = gen(x.to(DEV), output_vit_mid=True)
+    assert mid_in.shape == (2, 32, 64, 8) and pet.shape == (2, 1, 32, 32, 32) and pet.dtype == torch.float32
+    assert rel_err(mid_in, tt(fx["mid_input"])) < 2e-2
+    assert rel_err(mid_out, tt(fx["mid_output"])) < 3e-2
+    assert rel_err(pet, tt(fx["pet"])) < 3e-2
+    # same weights through the oracle (fp32 CPU): tighter bound on what bf16 activations cost
+    sd = {k: v.float().cpu() for k, v in gen.state_dict().items()}
+    o_in, o_out, o_pet = O.generator(x, sd, vit_heads=2, vit_depth=2)
+    assert rel_err(o_pet, tt(fx["pet"])) < 1e-4
+    assert rel_err(pet, o_pet) < 3e-2
