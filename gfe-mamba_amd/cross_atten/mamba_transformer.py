@@ -1,0 +1,55 @@
+"""Cross_mamba_both -- MI355X build of the classifier used by classify_mamba.py (reference:
+cross_atten/mamba_transformer.py:11-133).  Same keyword-only constructor, forward(x_categ, x_numer, feature_img,
+image_condition) contract and state-dict keys.  Additive: `d_cross` (default 160*160, the reference's hard-coded value at
+:84) so that 96^3 / 128^3 volumes are constructible.  Cross_jamba_both / Cross_mamba_ablation are next-round scope."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from cross_atten.corss_ft_transformer import FeedForward, GEGLU, NumericalEmbedder  # noqa: F401
+from cross_atten.mamba import Mamba, MambaConfig
+from cross_atten.sd_cross_atten import CrossAttention
+from gfe_hip.train_ops import Condition, Linear
+
+
+class Cross_mamba_both(nn.Module):
+    def __init__(self, *, categories, num_continuous, dim, depth, heads, dim_head=16, dim_out=1, num_special_tokens=2,
+                 attn_dropout=0., ff_dropout=0., cross_ff_multi=2, cross_ff_dropout=0.1, d_cross=160 * 160):
+        super().__init__()
+        assert all(map(lambda n: n > 0, categories)), 'number of each category must be positive'
+        assert len(categories) + num_continuous > 0, 'input shape must not be null'
+        self.num_categories = len(categories)
+        self.num_unique_categories = sum(categories)
+        self.num_special_tokens = num_special_tokens
+        total_tokens = self.num_unique_categories + num_special_tokens
+        if self.num_unique_categories > 0:
+            categories_offset = F.pad(torch.tensor(list(categories)), (1, 0), value=num_special_tokens)
+            self.register_buffer('categories_offset', categories_offset.cumsum(dim=-1)[:-1])     # :44-46
+            self.categorical_embeds = nn.Embedding(total_tokens, dim)
+        self.num_continuous = num_continuous
+        if self.num_continuous > 0:
+            self.numerical_embedder = NumericalEmbedder(dim, self.num_continuous)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.transformer = Mamba(MambaConfig(d_model=dim, n_layers=depth, use_cuda=True))        # :64-65
+        self.to_logits = nn.Sequential(nn.LayerNorm(dim), Linear(dim, dim_out))
+        self.final_cross = CrossAttention(n_heads=heads, d_embed=dim, d_cross=d_cross)           # :84
+        self.final_feed = FeedForward(dim, mult=cross_ff_multi, dropout=cross_ff_dropout)        # :85
+
+    def forward(self, x_categ, x_numer, feature_img, image_condition=None):
+        assert x_categ.shape[-1] == self.num_categories, f'you must pass in {self.num_categories} values for your categories input'
+        if image_condition is None:
+            raise ValueError("Cross_mamba_both needs image_condition=[mri, pet] (the reference fails with NameError at :124)")
+        whole_condition = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))   # :89-94
+        xs = []
+        if self.num_unique_categories > 0:
+            xs.append(self.categorical_embeds(x_categ + self.categories_offset))                  # :98-100
+        if self.num_continuous > 0:
+            xs.append(self.numerical_embedder(x_numer))
+        x = torch.cat(xs, dim=1)
+        cls_tokens = self.cls_token.expand(x.shape[0], -1, -1)
+        x = torch.cat((cls_tokens, x, feature_img), dim=1)                                        # :117
+        x = self.transformer(x)
+        x = torch.mean(x, dim=1, keepdims=True)                                                   # :122
+        x = self.final_cross(x, whole_condition) + x                                              # :124
+        x = self.final_feed(x) + x                                                                # :125
+        return self.to_logits(x.squeeze(1))                                                       # :127-131

@@ -1,0 +1,85 @@
+"""The classify_mamba training / validation step (reference: classify_mamba.py:94-109 train, :129-135 val) on MI355X.
+
+One process per GPU; with world_size > 1 the batch is sharded over ranks and the flat gradient buffer is all-reduced
+(RCCL over xGMI) BEFORE the per-parameter clip, which makes the update identical to a single-process step on the
+global batch (BCELoss is a batch mean).
+"""
+import torch
+import torch.nn.functional as F
+
+from .train_ops import Condition, FlatAdam
+
+
+def dp_mean_scale(world_size):
+    """all_reduce(SUM) followed by this scale == gradient of the global-batch mean loss."""
+    return 1.0 / world_size
+
+
+class ClassifyStep:
+    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None):
+        self.gen, self.head, self.ft = gen.eval(), head, ft
+        self.all_params = list(head.parameters()) + list(ft.parameters())          # classify_mamba.py:57-61
+        self.opt = FlatAdam(self.all_params, lr=lr, max_norm=max_norm)             # Adam(lr=1e-4) + per-parameter clip
+        self.world_size, self.group = world_size, group
+
+    def forward(self, x, x_cat, x_num):
+        with torch.no_grad():
+            mid_input, mid_output, pet = self.gen(x, output_vit_mid=True)          # classify_mamba.py:100-101
+        mid_feature = self.head(mid_input, mid_output)                             # :102
+        pred = self.ft(x_cat, x_num, mid_feature, Condition([x, pet]))             # :103
+        return pred, (mid_input, mid_output, pet)
+
+    def train_step(self, x, x_cat, x_num, y):
+        self.head.train(); self.ft.train()
+        self.opt.zero_grad()
+        pred, _ = self.forward(x, x_cat, x_num)
+        loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.float())  # :104
+        loss.backward()                                                            # :105
+        self.opt.step(self.world_size, self.group)                                 # all-reduce, clip (:106-107), Adam (:108)
+        return loss.detach()
+
+    @torch.no_grad()
+    def eval_step(self, x, x_cat, x_num):
+        self.head.eval(); self.ft.eval()
+        pred, _ = self.forward(x, x_cat, x_num)
+        return torch.sigmoid(pred)                                                 # :135
+
+
+def build_models(vol=(96, 96, 96), f_maps=(64, 128, 256), dim=512, depth=6, heads=8, cards=(11, 2, 2, 4, 4, 3, 3), n_cont=25,
+                 vit_kwargs=None, seed=0, device="cuda"):
+    """Generator + head + classifier with geometry derived from `vol`, weights from the deterministic initialiser."""
+    from . import det_init as det
+    from classify.classifier import Combine_classfier_vit_mid
+    from cross_atten.mamba_transformer import Cross_mamba_both
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit, vit_geometry
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=f_maps, vol_size=vol, vit_kwargs=vit_kwargs)
+    (H, W), _ = vit_geometry(vol)
+    head = Combine_classfier_vit_mid(seq_length=4, in_features=H * W)
+    ft = Cross_mamba_both(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads,
+                          d_cross=vol[0] * vol[1])
+    gen.load_state_dict(det.det_state_dict(gen.state_dict(), seed=seed, prefix="gen."))
+    head.load_state_dict(det.det_state_dict(head.state_dict(), seed=seed, prefix="head."))
+    ft.load_state_dict(det.det_state_dict(ft.state_dict(), seed=seed, prefix="ft."))
+    return gen.to(device).eval(), head.to(device), ft.to(device)
+
+
+def smoke():
+    """One tiny train step of the whole path (reduced widths, 32^3 volumes) checked against the oracle's forward."""
+    from . import det_init as det
+    from oracle import ref_ops as O
+    gen, head, ft = build_models(vol=(32, 32, 32), f_maps=(8, 16, 32), dim=64, depth=2, heads=8,
+                                 vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), seed=11)
+    sd_g = {k: v.float().cpu() for k, v in gen.state_dict().items()}
+    sd_h = {k: v.float().cpu() for k, v in head.state_dict().items()}
+    sd_f = {k: (v.float() if v.dtype.is_floating_point else v).cpu() for k, v in ft.state_dict().items()}
+    x, x_cat, x_num, y = det.det_inputs(2, (32, 32, 32), seed=11)
+    step = ClassifyStep(gen, head, ft)
+    head.eval(); ft.eval()
+    pred, _ = step.forward(x.cuda(), x_cat.cuda(), x_num.cuda())
+    mi, mo, pet = O.generator(x, sd_g, vit_heads=2, vit_depth=2)
+    ref = O.cross_mamba_both(x_cat, x_num, O.combine_classifier_vit_mid(mi, mo, sd_h), [x, pet], sd_f, depth=2, heads=8)
+    err = (pred.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < 5e-2, f"smoke: logits differ from the oracle by {err}"
+    loss = step.train_step(x.cuda(), x_cat.cuda(), x_num.cuda(), y.cuda())
+    assert torch.isfinite(loss).item()
+    print("smoke ok: reduced classify_mamba step, logits rel err %.2e, loss %.4f" % (err, loss.item()))

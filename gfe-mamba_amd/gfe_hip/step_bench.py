@@ -1,0 +1,79 @@
+"""bench.py workload: the classify_mamba training step at 96^3, 8 volumes per GPU (BASELINE config 5's per-GPU share)."""
+import time
+
+import torch
+
+from . import det_init as det
+from .step import ClassifyStep, build_models
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+# generator conv FLOPs per 96^3 volume: 3x3x3 convs + transposed convs, multiply-add = 2 flop
+CONV_K3_GFLOP_PER_VOL = 4 * 195.7 + 4 * 97.8 + 2 * 48.9
+GEN_GFLOP_PER_VOL = 1356.1
+HEAD_GFLOP_PER_SAMPLE = 11.64
+
+
+class StepWorkload:
+    name = "classify_mamba train step (frozen generator fwd + head fwd/bwd + per-param clip + Adam), 96^3, synthetic"
+
+    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96)):
+        self.batch, self.world, self.vol = batch, world, vol
+        gen, head, ft = build_models(vol=vol, seed=0)
+        self.step_obj = ClassifyStep(gen, head, ft, world_size=world)
+        x, x_cat, x_num, y = det.det_inputs(batch, vol, seed=1000 + rank)
+        self.inputs = [t.cuda() for t in (x, x_cat, x_num, y)]
+        self.units = batch
+
+    def step(self):
+        return self.step_obj.train_step(*self.inputs)
+
+    def roofline(self, iters=3):
+        """Dominant kernel = conv_igemm (3x3x3 convs of the generator): algorithmic FLOPs / its measured device time."""
+        from . import nn_ops as K
+        gen = self.step_obj.gen
+        blk = gen.encoders[0].basic_module
+        x = self.inputs[0]
+        with torch.no_grad():
+            r = blk.lift(x)
+            conv = blk.conv2
+            w, g, b = conv._pack.get([conv.conv.weight, conv.groupnorm.weight, conv.groupnorm.bias], lambda: None)
+            ss = K.groupnorm_scale_shift(r, g, b, 8)
+            run = lambda: K.conv_igemm(r, w, K.CONV3_TAPS, 64, gn=ss, relu=True)
+            run()
+            torch.cuda.synchronize()
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(iters):
+                run()
+            e1.record(st)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+        flops = 2.0 * 27 * 64 * 64 * self.batch * self.vol[0] * self.vol[1] * self.vol[2]
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": None, "kernel": "conv_igemm_kernel<4,3> (GroupNorm+Conv3d 3x3x3 64->64 @96^3, ReLU)", "launch_ms": round(ms, 4),
+                "algorithmic_flops": flops}
+
+    def cpu_baseline(self):
+        """The oracle (plain torch CPU restatement of the reference path) forward+backward on 1 volume (bounded sample)."""
+        from oracle import ref_ops as O
+        st = self.step_obj
+        f32 = lambda m: {k: (v.float() if v.dtype.is_floating_point else v).cpu() for k, v in m.state_dict().items()}
+        sd_g, sd_h, sd_f = f32(st.gen), f32(st.head), f32(st.ft)
+        x, x_cat, x_num, y = [t[:1].cpu() for t in self.inputs]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            mi, mo, pet = O.generator(x, sd_g)
+        tr = {k: v.clone().requires_grad_(True) for k, v in list(sd_h.items()) + list(sd_f.items()) if v.dtype.is_floating_point}
+        sd_h2 = {k: tr.get(k, v) for k, v in sd_h.items()}
+        sd_f2 = {k: tr.get(k, v) for k, v in sd_f.items()}
+        pred = O.cross_mamba_both(x_cat, x_num, O.combine_classifier_vit_mid(mi, mo, sd_h2), [x, pet], sd_f2, depth=6, heads=8)
+        loss = O.bce_sigmoid(pred, y)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle/ref_ops.py (torch CPU fp32): generator fwd + head fwd/bwd on 1 volume of 96^3 (no optimiser)"}
+
+    def extra(self):
+        return {"generator_gflop_per_volume": GEN_GFLOP_PER_VOL, "head_gflop_per_sample": HEAD_GFLOP_PER_SAMPLE}

@@ -1,0 +1,184 @@
+"""Autograd plumbing for the trainable head: Linear over the bf16 MFMA GEMM, the head Linear over channels-last mid
+features, the image condition buffers, and the flat-buffer per-parameter-clip + Adam step (with the DP all-reduce).
+
+Numerics: master weights, residual stream and reductions are f32; GEMM operands are rounded to bf16 (f32 accumulate).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import call, nn_ops as K, ptr, stream
+from .nn_ops import BF16
+
+_SHADOW = {}        # id(parameter) -> bf16 view kept fresh by FlatAdam (avoids a cast per use)
+
+
+def _w16(weight):
+    s = _SHADOW.get(id(weight))
+    if s is not None and s[1] == weight._version:
+        return s[0]
+    return K.cast(weight.detach().float(), BF16)
+
+
+def _gemm(a16, b16, bias=None):
+    """(M, K) x (N, K)^T -> (M, N) f32; zero-pads K to a multiple of 8 and N to a multiple of 4 (tiny test widths only)."""
+    Kd, N = a16.shape[1], b16.shape[0]
+    pk, pn = (-Kd) % 8, (-N) % 4
+    if pk or pn or a16.stride(0) % 8 or b16.stride(0) % 8 or a16.stride(1) != 1 or b16.stride(1) != 1:
+        a16 = F.pad(a16, (0, pk)).contiguous()
+        b16 = F.pad(b16, (0, pk, 0, pn)).contiguous()
+        if bias is not None and pn:
+            bias = F.pad(bias, (0, pn))
+    y = K.gemm_nt(a16, b16, bias=bias, out_dtype=torch.float32)
+    return y[:, :N] if pn else y
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b.  Optional precomputed bf16 operands: x16 (M, K) and xT16 (K, M) for inputs that are reused."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, x16, xT16):
+        N, Kd = weight.shape
+        xs = x.shape
+        if x16 is None:
+            x16 = K.cast(x.detach().reshape(-1, Kd).float(), BF16)
+        y = _gemm(x16, _w16(weight), None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(x16, xT16, weight)
+        ctx.meta = (xs, bias is not None, x.dtype)
+        return y.reshape(xs[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, xT16, weight = ctx.saved_tensors
+        xs, has_bias, xdt = ctx.meta
+        N, Kd = weight.shape
+        dy2 = dy.reshape(-1, N)
+        dy16 = K.cast(dy2.float(), BF16)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(dy16, K.transpose_bf16(_w16(weight))).reshape(xs).to(xdt)          # (M, N) x (K, N)^T
+        if ctx.needs_input_grad[1]:
+            if xT16 is None:
+                xT16 = K.transpose_bf16(x16)                                              # (K, M)
+            dw = _gemm(K.transpose_bf16(dy16), xT16).to(weight.dtype)                     # (N, M) x (K, M)^T
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, x16=None, xT16=None):
+    if not x.is_cuda:
+        raise RuntimeError("gfe_hip linear needs CUDA/HIP tensors (no CPU fallback)")
+    return _LinearFn.apply(x, weight, bias, x16, xT16)
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose forward/backward run on the bf16 MFMA GEMM (same parameters / state-dict keys)."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
+
+
+class _MidLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mid_in, mid_out, weight, bias):
+        B, H, W, C = mid_in.shape
+        S = weight.shape[0]
+        out = torch.zeros((B, 2 * C, S), dtype=torch.float32, device=mid_in.device)
+        w = weight.detach().float().contiguous()
+        call("gfe_mid_linear_fwd", ptr(mid_in), ptr(mid_out), ptr(w), ptr(out), B, H * W, C, S, stream())
+        ctx.save_for_backward(mid_in, mid_out)
+        ctx.S = S
+        return out + bias.detach().float()
+
+    @staticmethod
+    def backward(ctx, dout):
+        mid_in, mid_out = ctx.saved_tensors
+        B, H, W, C = mid_in.shape
+        d = dout.float().contiguous()
+        dW = torch.empty((ctx.S, H * W), dtype=torch.float32, device=d.device)
+        call("gfe_mid_linear_wgrad", ptr(mid_in), ptr(mid_out), ptr(d), ptr(dW), B, H * W, C, ctx.S, stream())
+        return None, None, dW, d.sum((0, 1))
+
+
+def mid_linear(mid_in_cl, mid_out_cl, weight, bias):
+    """mid_*_cl: (B, H, W, C) bf16 channels-last; returns (B, 2C, S) f32 = Linear over (h w) of cat([in, out], dim=1)."""
+    return _MidLinearFn.apply(mid_in_cl, mid_out_cl, weight, bias)
+
+
+class Condition:
+    """bf16 image condition of Cross_mamba_both (mamba_transformer.py:89-94) in the two layouts the K/V GEMMs read:
+    cond (B*keys, d_cross) for the forward, condT (d_cross, B*keys) for the weight gradient."""
+
+    def __init__(self, images):
+        B = images[0].shape[0]
+        HW = images[0].shape[2] * images[0].shape[3]
+        D3 = images[0].shape[4]
+        n = len(images)
+        dev = images[0].device
+        self.B, self.keys, self.d_cross = B, n * D3, HW
+        self.cond = torch.empty((B, n * D3, HW), dtype=BF16, device=dev)
+        self.condT = torch.empty((HW, B * n * D3), dtype=BF16, device=dev)
+        for i, img in enumerate(images):
+            assert img.shape[1] == 1, "condition images are single-channel"
+            src = img.detach().float().contiguous()
+            call("gfe_transpose_f32_to_bf16", ptr(src), self.cond.data_ptr() + i * D3 * HW * 2, B, HW, D3, n * D3 * HW, HW, stream())
+            call("gfe_interleave_rows_bf16", ptr(src), ptr(self.condT), B, HW, D3, B * n * D3, n * D3, i * D3, stream())
+
+
+class FlatAdam:
+    """Adam(lr, betas, eps) preceded by clip_grad_norm_(p, max_norm) on EACH parameter (classify_mamba.py:64, 106-108),
+    over flat f32 buffers: one all-reduce (DP), one norm pass, one update pass for every tensor."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, chunk=8192):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        offs = np.concatenate([[0], np.cumsum([(s + 7) // 8 * 8 for s in sizes])])     # 32-B aligned tensors
+        total = int(offs[-1])
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_p16 = torch.zeros(total, dtype=BF16, device=dev)
+        rec = []
+        for tid, (p, o, s) in enumerate(zip(self.params, offs[:-1], sizes)):
+            o = int(o)
+            self.flat_p[o:o + s].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[o:o + s].view(p.shape)
+            p.grad = self.flat_g[o:o + s].view(p.shape)
+            for c0 in range(0, s, chunk):
+                rec.append((o + c0, min(chunk, s - c0), tid))
+        tab = np.zeros(len(rec), dtype=np.dtype([("off", "<i8"), ("len", "<i4"), ("tid", "<i4")]))
+        tab["off"], tab["len"], tab["tid"] = zip(*rec)
+        self.chunks = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        self.nchunks = len(rec)
+        self.norm2 = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        self.offs, self.sizes = offs, sizes
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.t = 0
+        self.flat_p16.copy_(self.flat_p)
+        self._register_shadows()
+
+    def _register_shadows(self):
+        for p, o, s in zip(self.params, self.offs[:-1], self.sizes):
+            o = int(o)
+            _SHADOW[id(p)] = (self.flat_p16[o:o + s].view(p.shape), p._version)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o, s in zip(self.params, self.offs[:-1], self.sizes):      # autograd keeps accumulating in place
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + int(o) * 4:
+                p.grad = self.flat_g[int(o):int(o) + s].view(p.shape)
+
+    def step(self, world_size=1, group=None):
+        import torch.distributed as dist
+        if world_size > 1:
+            dist.all_reduce(self.flat_g, group=group)                     # SUM over ranks; mean folded into grad_scale
+        self.t += 1
+        self.norm2.zero_()
+        call("gfe_clip_adam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.flat_p16),
+             ptr(self.chunks), self.nchunks, ptr(self.norm2), 1.0 / world_size, self.max_norm, self.lr, self.betas[0], self.betas[1],
+             self.eps, self.t, stream())
+        # parameters are rewritten by the kernel (no version bump): the registered bf16 shadows stay current by construction

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 3
+#define GFE_ABI_VERSION 4
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -170,6 +170,37 @@ int gfe_token_mix(const void* x, const float* w, const float* bias, void* y, int
 
 /* cls token + positional embedding (vit.py:127-130): x[b][0] = cls + pos[0], x[b][1+i] = tok[b][i] + pos[1+i]; all f32. */
 int gfe_vit_embed(const float* tok, const float* cls, const float* pos, float* x, int64_t B, int64_t n, int64_t dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Group B / G -- trainable head and the optimiser step
+ * ------------------------------------------------------------------------------------------- */
+
+/* Combine_classfier_vit_mid (classify/classifier.py:329-333): Linear(H*W -> S) over cat([mid_input, mid_output], dim=1),
+ * evaluated on the generator's channels-last mid features without materialising the concat:
+ *   out[b][src*C + c][s] = sum_hw mid_src[b][hw][c] * W[s][hw]      (bias and the final transpose are host-side views)
+ * mid_in, mid_out: (B, HW, C) bf16; W: (S, HW) f32; out_zeroed: (B, 2C, S) f32, zero on entry (atomic accumulation). S == 4. */
+int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* W, float* out_zeroed,
+                       int64_t B, int64_t HW, int64_t C, int64_t S, void* stream);
+
+/* Weight gradient of the above: dW[s][hw] = sum_{b,c} dout[b][c][s] * mid[b][hw][c]; dout: (B, 2C, S) f32; dW: (S, HW) f32. */
+int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* dout, float* dW,
+                         int64_t B, int64_t HW, int64_t C, int64_t S, void* stream);
+
+/* Per-PARAMETER clip_grad_norm_(p, max_norm) followed by one Adam step (classify_mamba.py:64, 106-108) over flat f32
+ * buffers holding every trainable tensor back to back.  chunks: device array of {int64 offset, int32 length, int32 tensor_id}
+ * (16 B each), no chunk crossing a tensor boundary.  norm2_zeroed: (n_tensors) f32, zero on entry.  grad_scale multiplies g
+ * first (1/world_size after an all-reduce SUM).  p_bf16: optional flat bf16 copy of p refreshed in the same pass. */
+int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
+                  float* norm2_zeroed, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                  int64_t step, void* stream);
+
+/* Image condition (cross_atten/mamba_transformer.py:89-94): 'b c h w d -> (b c) (h w) d' then transpose(1, 2):
+ * out[b][c][r] (bf16, row stride ldo, batch stride out_batch_stride) = in[b][r][c] (f32, contiguous (batch, R, Cc)). */
+int gfe_transpose_f32_to_bf16(const float* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t out_batch_stride, int64_t ldo, void* stream);
+
+/* The same data laid out for the K/V weight gradient: out[r][b*per_batch_cols + col_off + c] (bf16, row stride ldo) = in[b][r][c]. */
+int gfe_interleave_rows_bf16(const float* in, void* out, int64_t B, int64_t R, int64_t Cc, int64_t ldo, int64_t per_batch_cols,
+                             int64_t col_off, void* stream);
 
 #ifdef __cplusplus
 }
