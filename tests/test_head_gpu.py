@@ -157,6 +157,8 @@ def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_g
     before = st.opt.flat_p.clone()
     st.opt.step()
     for (k, p), o, s in zip(zip(names, st.all_params), st.opt.offs[:-1], st.opt.sizes):
+        if k.endswith("k_proj.bias"):     # gradient is exactly zero in exact arithmetic; Adam normalises pure round-off
+            continue
         ref = float(fx["dnorm." + k])
         got = (st.opt.flat_p[int(o):int(o) + s] - before[int(o):int(o) + s]).double().norm().item()
         assert abs(got - ref) / max(ref, 1e-12) < 0.1, (k, got, ref)     # Adam's first step is ~lr*sign(g): robust to bf16 noise
