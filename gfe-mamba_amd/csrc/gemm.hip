@@ -5,8 +5,8 @@
 // 235-238, 223), CrossAttention q/k/v/out (cross_atten/sd_cross_atten.py:42-45), GEGLU FF (corss_ft_transformer.py:15-22).
 //
 // Tile BMx128x64, 4 waves as 2(M) x 2(N), MFMA 16x16x32 with swapped operands (B rows = MFMA A operand) so that a lane
-// owns 4 consecutive n of one m -> 8-byte stores.  LDS rows are 144 B (128 B of K + 16 B pad): the 16-lane ds_read_b128
-// groups hit 16 distinct bank slots.  Register-prefetched double buffering (global loads of tile k+1 fly under the MFMAs
+// owns 4 consecutive n of one m -> 8-byte stores.  LDS rows are 128 B with the 16-B chunks XOR-swizzled by (row & 7): every
+// ds_read_b128 fragment read takes the ideal 4 LDS cycles (tools/lds_bank_model.py; a 144-B padded stride costs 8).  Register-prefetched double buffering (global loads of tile k+1 fly under the MFMAs
 // of tile k).  f32 accumulate; epilogue: +bias, exact-erf GELU, +residual, bf16 or f32 store, or f32 atomics for split-K.
 #include "common.h"
 
@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-constexpr int BN = 128, BK = 64, RS = 144;     // RS: LDS row stride in bytes
+constexpr int BN = 128, BK = 64, RS = 128;     // RS: LDS row stride in bytes (no padding; 16-B chunk c of row r lives at slot c ^ (r & 7))
 
 struct GemmParams {
     const bf16_t* A; const bf16_t* B; void* C; const float* bias; const void* res;
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
         uint8_t* sa = smem + buf * STAGE;
         uint8_t* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_ITEMS; ++i) { const int it = tid + i * 256; *reinterpret_cast<uint4*>(sa + (it >> 3) * RS + (it & 7) * 16) = ra[i]; }
+        for (int i = 0; i < A_ITEMS; ++i) { const int it = tid + i * 256; *reinterpret_cast<uint4*>(sa + (it >> 3) * RS + (((it & 7) ^ ((it >> 3) & 7)) * 16)) = ra[i]; }
 #pragma unroll
-        for (int i = 0; i < B_ITEMS; ++i) { const int it = tid + i * 256; *reinterpret_cast<uint4*>(sb + (it >> 3) * RS + (it & 7) * 16) = rb[i]; }
+        for (int i = 0; i < B_ITEMS; ++i) { const int it = tid + i * 256; *reinterpret_cast<uint4*>(sb + (it >> 3) * RS + (((it & 7) ^ ((it >> 3) & 7)) * 16)) = rb[i]; }
     };
 
     if (nk > 0) { gload(0); lstore(0); }
@@ -76,15 +76,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
-        const uint8_t* sa = smem + (kt & 1) * STAGE + (wm * (BM / 2) + lr) * RS + lq * 16;
-        const uint8_t* sb = smem + (kt & 1) * STAGE + A_BYTES + (wn * 64 + lr) * RS + lq * 16;
+        const uint8_t* sa = smem + (kt & 1) * STAGE + (wm * (BM / 2) + lr) * RS;
+        const uint8_t* sb = smem + (kt & 1) * STAGE + A_BYTES + (wn * 64 + lr) * RS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 bf[4], af[MT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * RS + ks * 64);
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * RS + (((ks * 4 + lq) ^ (lr & 7)) * 16));
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RS + ks * 64);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RS + (((ks * 4 + lq) ^ (lr & 7)) * 16));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll

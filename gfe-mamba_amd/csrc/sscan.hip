@@ -382,7 +382,8 @@ static int pick_chunk(int64_t B, int64_t L, int64_t ED, int req) {
     int64_t want = ceil_div(2048, waves_per_chunk);           // chunks needed for ~2048 waves
     if (want <= 1) return (int)L;
     int64_t T = ceil_div(L, want);
-    if (T < 32) T = 32;
+    const int64_t tmin = L <= 256 ? 8 : 32;      // short sequences (the model's L = 37): favour parallel chunks over state traffic
+    if (T < tmin) T = tmin;
     T = ceil_div(T, 8) * 8;
     return (int)(T < L ? T : L);
 }

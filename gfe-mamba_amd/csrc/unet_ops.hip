@@ -38,20 +38,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     for (int i = tid; i < 2 * C; i += 256) o[i] = lds[i];
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ scale,
-                                                          float* __restrict__ shift, int64_t S, int C, int G, int nblk, float eps) {
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale,
+                                                           float* __restrict__ shift, int64_t S, int C, int G, int nblk, float eps) {
     extern __shared__ double dl[];               // [2][C] channel sums, then [2][G] mean / rstd
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < 2 * C; c += 256) {
+    // column c = tid % (2C) is summed by 1024/(2C) threads striding over the nblk partials, merged through LDS atomics
+    const int ncol = 2 * C;
+    for (int c = tid; c < ncol + 2 * G; c += 1024) dl[c] = 0.0;
+    __syncthreads();
+    const int tpc = 1024 / ncol;                 // threads per column (2C <= 1024)
+    if (tid < tpc * ncol) {
+        const int c = tid % ncol, part = tid / ncol;
         double a = 0.0;
-        for (int k = 0; k < nblk; ++k) a += (double)ws[((size_t)b * nblk + k) * 2 * C + c];
-        dl[c] = a;
+        for (int k = part; k < nblk; k += tpc) a += (double)ws[((size_t)b * nblk + k) * ncol + c];
+        atomicAdd(&dl[c], a);
     }
     __syncthreads();
     double* gm = dl + 2 * C;
     const int cg = C / G;
-    for (int g = tid; g < G; g += 256) {
+    for (int g = tid; g < G; g += 1024) {
         double s = 0.0, q = 0.0;
         for (int j = 0; j < cg; ++j) { s += dl[g * cg + j]; q += dl[C + g * cg + j]; }
         const double n = (double)cg * (double)S;
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         gm[g] = mean; gm[G + g] = 1.0 / sqrt(var + (double)eps);
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += 1024) {
         const int g = c / cg;
         const float sc = (float)gm[G + g] * gamma[c];
         scale[(size_t)b * C + c] = sc;
@@ -164,7 +170,7 @@ static unsigned grid_for(int64_t total) {
 extern "C" {
 
 int gfe_groupnorm_plan(int64_t S, int* vox_per_block, int* nblk) {
-    int64_t vpb = ceil_div(S, 512);
+    int64_t vpb = ceil_div(S, 96);
     if (vpb < 256) vpb = 256;
     *vox_per_block = (int)vpb;
     *nblk = (int)ceil_div(S, vpb);
@@ -174,13 +180,13 @@ int gfe_groupnorm_plan(int64_t S, int* vox_per_block, int* nblk) {
 int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float* scale, float* shift, float* ws,
                               int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream) {
     GFE_REQUIRE(x && gamma && beta && scale && shift && ws, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && S > 0 && C >= 8 && C % 8 == 0 && (256 % (C / 8)) == 0 && G > 0 && C % G == 0 && G <= 256, GFE_ERR_SHAPE);
+    GFE_REQUIRE(B > 0 && S > 0 && C >= 8 && C % 8 == 0 && (256 % (C / 8)) == 0 && G > 0 && C % G == 0 && G <= 256 && 2 * C <= 1024, GFE_ERR_SHAPE);
     int vpb, nblk;
     gfe_groupnorm_plan(S, &vpb, &nblk);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, (unsigned)B), dim3(256), 2 * C * sizeof(float), st,
                        (const bf16_t*)x, ws, S, (int)C, vpb, nblk);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), (2 * C + 2 * G) * sizeof(double), st,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G) * sizeof(double), st,
                        ws, gamma, beta, scale, shift, S, (int)C, (int)G, nblk, eps);
     return gfe_launch_status();
 }

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv kernel alone (for rocprofv3 --pmc passes and A/B timing).
+    python tools/conv_bench.py [C] [D] [B] [iters]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gfe-mamba_amd"))
+import torch
+from gfe_hip import nn_ops as K
+
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, D, D, D, C, generator=g).to(torch.bfloat16).cuda()
+w = K.pack_conv3((torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5).cuda())
+ss = K.groupnorm_scale_shift(x, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 8)
+y = K.conv_igemm(x, w, K.CONV3_TAPS, C, gn=ss, relu=True)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    K.conv_igemm(x, w, K.CONV3_TAPS, C, gn=ss, relu=True, out=y)
+e1.record()
+e1.synchronize()
+ms = e0.elapsed_time(e1) / iters
+fl = 2.0 * 27 * C * C * B * D ** 3
+print(f"conv C={C} D={D} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
