@@ -22,6 +22,17 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#if defined(GFE_EXP_NOMFMA)   // timing experiment only: everything but the matrix instructions
+#define GFE_MFMA(a, b, c) (c)
+#else
+#define GFE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+#if defined(GFE_EXP_NOBAR)    // timing experiment only: no per-stage barrier
+#define GFE_STAGE_BARRIER() do {} while (0)
+#else
+#define GFE_STAGE_BARRIER() __syncthreads()
+#endif
+
 namespace {
 
 constexpr int TD = 4, TH = 8, TW = 8;          // output tile (class-grid voxels)
@@ -174,7 +185,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         const bf16_t* wslab = p.w + ((size_t)slab * p.ntaps * p.CoutPad + (size_t)cg * WROWS_TAP) * 32;
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl) {
+#if defined(GFE_EXP_WHOT)
+            const int tap = 0 * (stage * TPS + tl);      // timing experiment only: every stage re-reads the same (hot) weights
+#else
             const int tap = stage * TPS + tl;
+#endif
 #pragma unroll
             for (int j = 0; j < WJ; ++j) {
                 const int itl = tid + j * 256;
@@ -185,6 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
     };
     auto wstore = [&](const uint4 (&wr)[TPS * WJ], int buf) {
+#if defined(GFE_EXP_NOW)
+        if (buf >= 0) return;                             // timing experiment only: weights are never restaged
+#endif
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl)
 #pragma unroll
@@ -202,6 +220,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     for (int u = 0; u < nunits; ++u) {
         const int slab = u % p.nslab;
         // registers hold unit u (activations + stage-0 weights); every wave passed the barrier that ended unit u-1
+#if defined(GFE_EXP_NOA)
+        if (u == 0)
+#endif
         if (PIPE) {
             astore(cur, slab, 0, PLANES);
         } else {      // wide variant: no register budget to hold a tile across the MFMA loop -> two batches of 3 planes
@@ -215,7 +236,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         if constexpr (REG27 && DEEP) wload(wq[0], slab, 3);   // set 0 was just drained: stage 3 goes out now
         if (next_unit) {
             if (nslab_next == 0) advance(nxt);
+#if !defined(GFE_EXP_NOA)
             if (PIPE) aload(nxt, nslab_next, 0, PLANES);     // in flight under this unit's MFMAs
+#endif
         }
         if (slab == 0) {
 #pragma unroll
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 for (int ct = 0; ct < NT; ++ct) acc[xt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-        if constexpr (REG27) {
+        if constexpr (REG27 && DEEP) {
             // regular 3x3x3, 9 stages = (kd, kh), 3 taps kw = 0..2 each.  Weight pipeline: the loads of stage s+4 are issued
             // when stage s ends (3 stages ~ 1 us ahead of their ds_write: L2 latency under load is longer than one stage).
             for (int kd = 0; kd < 3; ++kd) {
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
 #pragma unroll
                             for (int xt = 0; xt < 4; ++xt)
-                                acc[xt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[xt], acc[xt][ct], 0, 0, 0);
+                                acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
                         }
                     }
                     if constexpr (DEEP) {
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                     } else {
                         if (s + 1 < 9) wstore(wq[0], (s + 1) & 1);
                     }
-                    __syncthreads();
+                    GFE_STAGE_BARRIER();
                 }
             }
         } else {
@@ -272,6 +295,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 if (more) wload(wq[0], slab, s + 1);
                 else if (next_unit) wload(wq[0], nslab_next, 0);
                 const uint8_t* wb = sW + (s & 1) * WSTAGE_BYTES + wbase;
+                if constexpr (REG27) {
+                    // regular 3x3x3: stage s = (kd, kh), taps kw = 0..2 -> one base per voxel tile + immediate offsets
+                    const int kd = s / 3, kh = s - kd * 3;
+                    const int sbase = (kd * PH + kh) * PW * VSTRIDE, sx = (kh & 1) << 5;
+                    int ax[4];
+#pragma unroll
+                    for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
+#pragma unroll
+                    for (int tl = 0; tl < TPS; ++tl) {
+                        bf16x8 xf[4];
+#pragma unroll
+                        for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(sA + ax[xt] + tl * VSTRIDE);
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct) {
+                            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
+#pragma unroll
+                            for (int xt = 0; xt < 4; ++xt)
+                                acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     const int tap = s * TPS + tl;
@@ -285,14 +329,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
 #pragma unroll
                             for (int xt = 0; xt < 4; ++xt)
-                                acc[xt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[xt], acc[xt][ct], 0, 0, 0);
+                                acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
                         }
                     }
                 }
+                }
                 if (more) wstore(wq[0], (s + 1) & 1);
-                __syncthreads();
+                GFE_STAGE_BARRIER();
             }
         }
+#if defined(GFE_EXP_NOEPI)
+        if (slab != p.nslab - 1 || u + 1 < nunits) { if (slab == p.nslab - 1) advance(cur); continue; }
+#endif
         if (slab != p.nslab - 1) continue;
 
         // ---- epilogue: bias, skip/residual add, ReLU, bf16 store (lane: voxel = lr of tile xt, channels 16*ct + 4*lq + 0..3)
@@ -312,27 +360,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                         const int dd_ = zd ? 0 : od + p.oshift, dh_ = zh ? 0 : oh + p.oshift, dw_ = zw ? 0 : ow + p.oshift;
                         if (dd_ >= p.OD || dh_ >= p.OH || dw_ >= p.OW) continue;
                         const size_t vox = (((size_t)b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_;
+                        // weight rows were permuted at pack time (row ct*16 + 4*lq + r  <->  channel lq*4*NT + 4*ct + r), so this lane
+                        // owns 4*NT CONSECUTIVE output channels of the voxel: one 8*NT-byte contiguous piece (full 128-B rows per voxel)
+                        const int c0 = cg * NT * 16 + lq * 4 * NT;
+                        if (c0 >= p.Cout) continue;
+                        float v[4 * NT];
 #pragma unroll
-                        for (int ct = 0; ct < NT; ++ct) {
-                            const int c0 = (cg * NT + ct) * 16 + lq * 4;
-                            if (c0 >= p.Cout) continue;
-                            float v[4] = {acc[xt][ct][0], acc[xt][ct][1], acc[xt][ct][2], acc[xt][ct][3]};
-                            if (p.bias) {
+                        for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] += p.bias[c0 + r];
-                            }
-                            const size_t o = vox * p.Cout + c0;
-                            if (p.res) {
-                                const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
-                                v[0] += bf16lo_to_f32(rv.x); v[1] += bf16hi_to_f32(rv.x);
-                                v[2] += bf16lo_to_f32(rv.y); v[3] += bf16hi_to_f32(rv.y);
-                            }
-                            if (p.relu) {
+                            for (int r = 0; r < 4; ++r) v[4 * ct + r] = acc[xt][ct][r];
+                        if (p.bias) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                            }
-                            *reinterpret_cast<uint2*>(p.y + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            for (int i = 0; i < 4 * NT; ++i) v[i] += p.bias[c0 + i];
                         }
+                        const size_t o = vox * p.Cout + c0;
+                        if (p.res) {
+                            const uint2* rp = reinterpret_cast<const uint2*>(p.res + o);
+#pragma unroll
+                            for (int i = 0; i < NT; ++i) {
+                                const uint2 rv = rp[i];
+                                v[4 * i] += bf16lo_to_f32(rv.x); v[4 * i + 1] += bf16hi_to_f32(rv.x);
+                                v[4 * i + 2] += bf16lo_to_f32(rv.y); v[4 * i + 3] += bf16hi_to_f32(rv.y);
+                            }
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int i = 0; i < 4 * NT; ++i) v[i] = fmaxf(v[i], 0.f);
+                        }
+                        uint2* yp = reinterpret_cast<uint2*>(p.y + o);
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) yp[i] = make_uint2(pack_bf16x2(v[4 * i], v[4 * i + 1]), pack_bf16x2(v[4 * i + 2], v[4 * i + 3]));
                     }
         }
         advance(cur);

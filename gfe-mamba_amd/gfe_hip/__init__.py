@@ -10,7 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-LIB_PATH = os.path.join(_HERE, "libgfe_hip.so")
+LIB_PATH = os.environ.get("GFE_HIP_LIB", os.path.join(_HERE, "libgfe_hip.so"))   # override: kernel A/B experiments only
 HEADER_PATH = os.path.join(_ROOT, "include", "gfe_hip.h")
 
 GFE_F32, GFE_BF16 = 0, 1

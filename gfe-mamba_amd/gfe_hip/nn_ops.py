@@ -32,13 +32,24 @@ def cout_pad(cout):
 CONV3_TAPS = [(kd - 1, kh - 1, kw - 1) for kd in range(3) for kh in range(3) for kw in range(3)]
 
 
+def _row_perm(cp):
+    """Packed weight row -> output channel.  Inside a group of NT 16-row MFMA tiles, row ct*16 + 4*lq + r carries channel
+    lq*4*NT + 4*ct + r, so that an MFMA lane (which owns rows 4*lq..4*lq+3 of every tile) ends up with 4*NT consecutive
+    output channels of its voxel and the epilogue stores contiguous 8*NT-byte pieces."""
+    nt = min(cp, 128) // 16
+    rho = torch.arange(cp)
+    g, r = rho // (nt * 16), rho % (nt * 16)
+    return g * nt * 16 + ((r >> 2) & 3) * 4 * nt + (r >> 4) * 4 + (r & 3)
+
+
 def _pack(w_tco, cin):
-    """w_tco: (ntaps, Cout, Cin) f32 -> [nslab][ntaps][CoutPad][32] bf16, zero padded."""
+    """w_tco: (ntaps, Cout, Cin) f32 -> [nslab][ntaps][CoutPad][32] bf16, zero padded, rows permuted (see _row_perm)."""
     ntaps, cout, _ = w_tco.shape
     nslab = (cin + 31) // 32
     cp = cout_pad(cout)
     buf = torch.zeros((ntaps, cp, nslab * 32), dtype=torch.float32, device=w_tco.device)
     buf[:, :cout, :cin] = w_tco
+    buf = buf[:, _row_perm(cp).to(buf.device)]
     return buf.view(ntaps, cp, nslab, 32).permute(2, 0, 1, 3).contiguous().to(BF16)
 
 

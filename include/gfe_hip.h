@@ -95,7 +95,8 @@ int gfe_conv3d_cout_pad(int64_t Cout);
  *   TransposeConvUpsampling = ConvTranspose3d k3 s2 p1 no-bias -> F.interpolate(nearest, 2n-1 -> 2n) -> `encoder_features + x`
  *   (buildingblocks.py:396-400, 523-537): 8 calls, one per output parity class (ostride 2, op_* parity, oshift 1, res = skip)
  *   x: (B, D, H, W, Cin) bf16.  y, res: (B, OD, OH, OW, Cout) bf16.  Cin % 8 == 0, Cout % 8 == 0.
- *   w_packed: [ceil(Cin/32)][ntaps][gfe_conv3d_cout_pad(Cout)][32] bf16, zero padded (tap order = tap_offsets order).
+  *   w_packed: [ceil(Cin/32)][ntaps][gfe_conv3d_cout_pad(Cout)][32] bf16, zero padded (tap order = tap_offsets order); inside each
+ *   group of NT = min(CoutPad,128)/16 tiles, packed row ct*16 + 4*q + r holds output channel q*4*NT + 4*ct + r (gfe_hip/nn_ops.py:_row_perm).
  *   gn_scale, gn_shift: (B, Cin) f32 from gfe_groupnorm_scale_shift, or both NULL.  bias: (Cout) f32 or NULL.
  *   tap_offsets: HOST pointer, ntaps x 3 int8 (dd, dh, dw) each in [-1, 1].
  *   ostride 1: OD,OH,OW == D,H,W.  ostride 2: output index = 2*i + op_*, shifted by oshift (0/1) with index 0 duplicated
