@@ -24,7 +24,7 @@
 namespace {
 
 struct SScanParams {
-    const void* u; const void* delta; const void* z; const void* Bm; const void* Cm;
+    const void* u; const void* delta; const void* z; const float* Bm; const float* Cm;
     const float* A; const float* D; const float* dbias;
     void* y;
     float* hstate;      // (B, nchunks, N, ED)
@@ -32,27 +32,46 @@ struct SScanParams {
     int B, L, ED, T, nchunks, softplus;
 };
 
-// wave-uniform row of N values (N contiguous) -> f32 registers (scalar path when the compiler proves uniformity)
-template <typename T, int N> struct RowLd;
-template <int N> struct RowLd<float, N> {
-    static __device__ __forceinline__ void ld(const float* __restrict__ p, float (&o)[N]) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) o[i] = p[i];
+// B / C rows (N f32 each, shared by every channel) reach the lanes through a wave-private LDS tile of TT rows: each lane
+// fetches ONE float4 of the (contiguous) TT x N block, parks it in LDS, and every step reads its row back with broadcast
+// ds_read_b128.  (Fetching rows on the scalar path looked attractive but the bf16 unpack + addressing cost ~90 SALU
+// instructions per step on the CU's single scalar ALU and, in unrolled code, spilled SGPRs into v_readlane/v_writelane chains.)
+__device__ __forceinline__ int opaque_zero() { int v; asm volatile("v_mov_b32 %0, 0" : "=v"(v)); return v; }
+
+template <int N, int TT>
+struct RowTile {
+    static constexpr int F4 = TT * N / 4;                  // float4 per tile (<= 64)
+    float4* lds;                                            // this wave's 2 x F4 float4
+    const float* g;                                         // (rows, N) f32
+    int64_t last_f4;                                        // index of the last valid float4 of the tensor
+    int lane;
+    int vzero;                                              // opaque per-lane 0: keeps the broadcast rows in VGPRs (the compiler
+                                                            // otherwise proves them wave-uniform, moves them to SGPRs and spills)
+    __device__ __forceinline__ float4 fetch(int64_t row0) const {   // rows row0 .. row0+TT-1 (clamped at the tensor end)
+        if (lane >= F4) return make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t i = row0 * (N / 4) + lane;
+        i = i < 0 ? 0 : (i > last_f4 ? last_f4 : i);
+        return reinterpret_cast<const float4*>(g)[i];
     }
-};
-template <int N> struct RowLd<bf16_t, N> {
-    static __device__ __forceinline__ void ld(const bf16_t* __restrict__ p, float (&o)[N]) {
-        const uint32_t* __restrict__ w = reinterpret_cast<const uint32_t*>(p);
+    __device__ __forceinline__ void park(int buf, const float4& v) const { if (lane < F4) lds[buf * F4 + lane] = v; }
+    __device__ __forceinline__ void row(int buf, int r, float (&o)[N]) const {
 #pragma unroll
-        for (int i = 0; i < N / 2; ++i) { uint32_t v = w[i]; o[2 * i] = bf16lo_to_f32(v); o[2 * i + 1] = bf16hi_to_f32(v); }
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 v = lds[buf * F4 + r * (N / 4) + q + vzero];
+            o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+        }
     }
 };
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// One lane = one channel; its u/delta/z values are fetched as register tiles of TT timesteps, the next tile in flight
+// (3*TT 128-byte wave loads outstanding) while the current one is consumed: with 2-byte lanes that is what it takes to keep
+// ~40 KB per CU in flight (HBM latency x bandwidth); a 4-step unroll left the kernel latency-bound at 8 % of HBM.
 template <typename T, int N, bool STATE_ONLY>
 __global__ __launch_bounds__(256) void sscan_fwd_kernel(const SScanParams p) {
+    constexpr int TT = 16;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (e >= p.ED) return;
@@ -60,9 +79,15 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const SScanParams p) {
     const T* __restrict__ u = (const T*)p.u;
     const T* __restrict__ dl = (const T*)p.delta;
     const T* __restrict__ z = (const T*)p.z;
-    const T* __restrict__ Bm = (const T*)p.Bm;
-    const T* __restrict__ Cm = (const T*)p.Cm;
     T* __restrict__ y = (T*)p.y;
+    const bool has_z = !STATE_ONLY && z != nullptr;
+    extern __shared__ float4 sm4[];
+    constexpr int F4 = RowTile<N, TT>::F4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t last_f4 = (int64_t)p.B * p.L * (N / 4) - 1;
+    const int vz = opaque_zero();
+    const RowTile<N, TT> tB{sm4 + wid * 4 * F4, p.Bm, last_f4, lane, vz};
+    const RowTile<N, TT> tC{sm4 + wid * 4 * F4 + 2 * F4, p.Cm, last_f4, lane, vz};
 
     float A2[N], h[N];
 #pragma unroll
@@ -79,35 +104,67 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const SScanParams p) {
     const float Dv = (!STATE_ONLY && p.D) ? p.D[e] : 0.f;
     float sd = 0.f;
 
-#pragma unroll 4
-    for (int t = t0; t < t1; ++t) {
-        const size_t row = (size_t)b * p.L + t;
-        const size_t off = row * p.ED + e;
-        float dt = IO<T>::ld(dl + off) + bias;
-        if (p.softplus) dt = softplusf_(dt);
-        const float uu = IO<T>::ld(u + off);
-        const float dtu = dt * uu;
-        float Bv[N];
-        RowLd<T, N>::ld(Bm + row * N, Bv);
-        if (STATE_ONLY) {
-            sd += dt;
+    T ub[TT], db[TT], zb[TT], un[TT], dn[TT], zn[TT];
+    auto load_tile = [&](int tb, T (&uu)[TT], T (&dd)[TT], T (&zz)[TT]) {
 #pragma unroll
-            for (int n = 0; n < N; ++n) h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
-        } else {
-            float Cv[N];
-            RowLd<T, N>::ld(Cm + row * N, Cv);
-            float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-            for (int n = 0; n < N; n += 2) {
-                h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
-                h[n + 1] = fmaf(fast_exp2(dt * A2[n + 1]), h[n + 1], dtu * Bv[n + 1]);
-                acc0 = fmaf(h[n], Cv[n], acc0);
-                acc1 = fmaf(h[n + 1], Cv[n + 1], acc1);
-            }
-            float yv = fmaf(Dv, uu, acc0 + acc1);
-            if (z) yv *= siluf_(IO<T>::ld(z + off));
-            IO<T>::st(y + off, yv);
+        for (int s2 = 0; s2 < TT; ++s2) {
+            const int t = min(tb + s2, t1 - 1);                       // clamped: tail steps are loaded but never used
+            const size_t off = ((size_t)b * p.L + t) * p.ED + e;
+            uu[s2] = u[off];
+            dd[s2] = dl[off];
+            if (has_z) zz[s2] = z[off];
         }
+    };
+    load_tile(t0, ub, db, zb);
+    tB.park(0, tB.fetch((int64_t)b * p.L + t0));
+    if (!STATE_ONLY) tC.park(0, tC.fetch((int64_t)b * p.L + t0));
+    int cur = 0;
+    for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
+        const bool more = tb + TT < t1;
+        float4 fb, fc;
+        if (more) {
+            load_tile(tb + TT, un, dn, zn);
+            fb = tB.fetch((int64_t)b * p.L + tb + TT);
+            if (!STATE_ONLY) fc = tC.fetch((int64_t)b * p.L + tb + TT);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < TT; ++s2) {
+            const int t = tb + s2;
+            if (t < t1) {                                               // wave-uniform
+                const size_t row = (size_t)b * p.L + t;
+                float dt = IO<T>::ld(&db[s2]) + bias;
+                if (p.softplus) dt = softplusf_(dt);
+                const float uu = IO<T>::ld(&ub[s2]);
+                const float dtu = dt * uu;
+                float Bv[N];
+                tB.row(cur, s2, Bv);
+                if (STATE_ONLY) {
+                    sd += dt;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
+                } else {
+                    float Cv[N];
+                    tC.row(cur, s2, Cv);
+                    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                    for (int n = 0; n < N; n += 2) {
+                        h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
+                        h[n + 1] = fmaf(fast_exp2(dt * A2[n + 1]), h[n + 1], dtu * Bv[n + 1]);
+                        acc0 = fmaf(h[n], Cv[n], acc0);
+                        acc1 = fmaf(h[n + 1], Cv[n + 1], acc1);
+                    }
+                    float yv = fmaf(Dv, uu, acc0 + acc1);
+                    if (has_z) yv *= siluf_(IO<T>::ld(&zb[s2]));
+                    IO<T>::st(y + row * p.ED + e, yv);
+                }
+            }
+        }
+        if (more) {
+            tB.park(cur ^ 1, fb);
+            if (!STATE_ONLY) tC.park(cur ^ 1, fc);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < TT; ++s2) { ub[s2] = un[s2]; db[s2] = dn[s2]; zb[s2] = zn[s2]; }
     }
     if (STATE_ONLY) {
 #pragma unroll
@@ -117,7 +174,8 @@ __global__ __launch_bounds__(256) void sscan_fwd_kernel(const SScanParams p) {
 }
 
 // K2: hstate[b,c,n,e] (local end state of chunk c) -> start state of chunk c.  REVERSE=true runs the
-// adjoint carry (chunk c receives from chunk c+1).  One lane per (n,e); nchunks sequential steps.
+// adjoint carry (chunk c receives from chunk c+1).  One lane per (n,e); the loads of 8 chunks are batched ahead of the
+// 8 dependent fma steps so the serial chain costs one memory round trip per 8 chunks.
 template <int N, bool REVERSE>
 __global__ __launch_bounds__(256) void sscan_carry_kernel(float* __restrict__ hstate, const float* __restrict__ sdelta,
                                                           const float* __restrict__ A, int ED, int nchunks) {
@@ -127,14 +185,24 @@ __global__ __launch_bounds__(256) void sscan_carry_kernel(float* __restrict__ hs
     const int n = i / ED, e = i - n * ED;
     const float A2 = A[(size_t)e * N + n] * GFE_LOG2E;
     float H = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < nchunks; ++k) {
-        const int c = REVERSE ? nchunks - 1 - k : k;
-        const size_t idx = ((size_t)b * nchunks + c) * N * ED + i;
-        const float loc = hstate[idx];
-        const float sd = sdelta[((size_t)b * nchunks + c) * ED + e];
-        hstate[idx] = H;
-        H = fmaf(fast_exp2(A2 * sd), H, loc);
+    constexpr int G = 8;
+    for (int k0 = 0; k0 < nchunks; k0 += G) {
+        float loc[G], sdv[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int k = min(k0 + j, nchunks - 1);
+            const int c = REVERSE ? nchunks - 1 - k : k;
+            loc[j] = hstate[((size_t)b * nchunks + c) * N * ED + i];
+            sdv[j] = sdelta[((size_t)b * nchunks + c) * ED + e];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (k0 + j < nchunks) {
+                const int c = REVERSE ? nchunks - 1 - (k0 + j) : k0 + j;
+                hstate[((size_t)b * nchunks + c) * N * ED + i] = H;
+                H = fmaf(fast_exp2(A2 * sdv[j]), H, loc[j]);
+            }
+        }
     }
 }
 
@@ -142,7 +210,7 @@ __global__ __launch_bounds__(256) void sscan_carry_kernel(float* __restrict__ hs
 // backward
 // ------------------------------------------------------------------------------------------------
 struct SScanBwdParams {
-    const void* u; const void* delta; const void* z; const void* Bm; const void* Cm; const void* dy;
+    const void* u; const void* delta; const void* z; const float* Bm; const float* Cm; const void* dy;
     const float* A; const float* D; const float* dbias;
     void* du; void* ddelta; void* dz;
     float* dBws; float* dCws;          // (B, L, N) f32, zero-initialised by the caller, atomically accumulated
@@ -154,33 +222,60 @@ struct SScanBwdParams {
     int B, L, ED, T, nchunks, softplus;
 };
 
-// K1': local adjoint of each chunk with zero incoming carry: q <- a_t * (C_t g_t + q), t descending.
+// K1': local adjoint of each chunk with zero incoming carry: q <- a_t * (C_t g_t + q), t descending (16-step register tiles).
 template <typename T, int N>
 __global__ __launch_bounds__(256) void sscan_bwd_state_kernel(const SScanBwdParams p) {
+    constexpr int TT = 16;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (e >= p.ED) return;
     const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
     const T* __restrict__ dl = (const T*)p.delta;
     const T* __restrict__ z = (const T*)p.z;
-    const T* __restrict__ Cm = (const T*)p.Cm;
     const T* __restrict__ dy = (const T*)p.dy;
+    const bool has_z = z != nullptr;
+    extern __shared__ float4 sm4[];
+    constexpr int F4 = RowTile<N, TT>::F4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const RowTile<N, TT> tC{sm4 + wid * 2 * F4, p.Cm, (int64_t)p.B * p.L * (N / 4) - 1, lane, opaque_zero()};
     float A2[N], q[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) { A2[n] = p.A[(size_t)e * N + n] * GFE_LOG2E; q[n] = 0.f; }
     const float bias = p.dbias ? p.dbias[e] : 0.f;
-#pragma unroll 4
-    for (int t = t1 - 1; t >= t0; --t) {
-        const size_t row = (size_t)b * p.L + t;
-        const size_t off = row * p.ED + e;
-        float dt = IO<T>::ld(dl + off) + bias;
-        if (p.softplus) dt = softplusf_(dt);
-        float g = IO<T>::ld(dy + off);
-        if (z) g *= siluf_(IO<T>::ld(z + off));
-        float Cv[N];
-        RowLd<T, N>::ld(Cm + row * N, Cv);
+    T db[TT], gb[TT], zb[TT], dn[TT], gn[TT], zn[TT];
+    // tile tb covers steps tb-TT+1 .. tb (descending use)
+    auto load_tile = [&](int tb, T (&dv)[TT], T (&gv)[TT], T (&zv)[TT]) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) q[n] = fast_exp2(dt * A2[n]) * fmaf(Cv[n], g, q[n]);
+        for (int s2 = 0; s2 < TT; ++s2) {
+            const size_t off = ((size_t)b * p.L + max(tb - s2, t0)) * p.ED + e;
+            dv[s2] = dl[off]; gv[s2] = dy[off];
+            if (has_z) zv[s2] = z[off];
+        }
+    };
+    load_tile(t1 - 1, db, gb, zb);
+    tC.park(0, tC.fetch((int64_t)b * p.L + t1 - TT));        // tile = rows tb-TT+1 .. tb
+    int cur = 0;
+    for (int tb = t1 - 1; tb >= t0; tb -= TT, cur ^= 1) {
+        const bool more = tb - TT >= t0;
+        float4 fc;
+        if (more) { load_tile(tb - TT, dn, gn, zn); fc = tC.fetch((int64_t)b * p.L + tb - 2 * TT + 1); }
+#pragma unroll
+        for (int s2 = 0; s2 < TT; ++s2) {
+            const int t = tb - s2;
+            if (t >= t0) {
+                float dt = IO<T>::ld(&db[s2]) + bias;
+                if (p.softplus) dt = softplusf_(dt);
+                float g = IO<T>::ld(&gb[s2]);
+                if (has_z) g *= siluf_(IO<T>::ld(&zb[s2]));
+                float Cv[N];
+                tC.row(cur, TT - 1 - s2, Cv);
+#pragma unroll
+                for (int n = 0; n < N; ++n) q[n] = fast_exp2(dt * A2[n]) * fmaf(Cv[n], g, q[n]);
+            }
+        }
+        if (more) tC.park(cur ^ 1, fc);
+#pragma unroll
+        for (int s2 = 0; s2 < TT; ++s2) { db[s2] = dn[s2]; gb[s2] = gn[s2]; zb[s2] = zn[s2]; }
     }
     const size_t sbase = ((size_t)b * p.nchunks + c) * N * p.ED + e;
 #pragma unroll
@@ -197,8 +292,12 @@ __device__ __forceinline__ float wave_reduce_vec(float (&v)[N]) {
         const bool up = (lane & half) != 0;
 #pragma unroll
         for (int i = 0; i < half; ++i) {
-            const float keep = up ? v[half + i] : v[i];
-            const float send = up ? v[i] : v[half + i];
+            // both operands are pinned in registers first: left as `up ? v[half+i] : v[i]` LLVM folds the select into a
+            // dynamically indexed array access and lowers it to 16-way v_cmp/v_cndmask chains with SGPR-mask spills
+            float lo = v[i], hi = v[half + i];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
             v[i] = keep + __shfl_xor(send, half, 64);
         }
     }
@@ -209,11 +308,13 @@ __device__ __forceinline__ float wave_reduce_vec(float (&v)[N]) {
 }
 
 // K3': one wave per block (64 channels), chunk of T steps processed as sub-chunks of S steps:
-//   sweep 1 (forward): chunk-start state -> state at every sub-chunk start, parked in LDS
-//   sweep 2 (sub-chunks in reverse): recompute the S states + decays in registers, then run the adjoint.
+//   sweep 1 (forward): chunk-start state -> state at every sub-chunk start, parked in LDS (u/delta in 16-step register tiles)
+//   sweep 2 (sub-chunks in reverse): recompute the S states in registers, then run the adjoint; the u/delta/z/dy values of
+//   the NEXT sub-chunk are already in flight.  The decay exp2(delta*A) is recomputed in the adjoint rather than kept.
 template <typename T, int N, int S>
 __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float ck[];   // [nsub][N][64]
+    constexpr int TT = 16;
     const int lane = threadIdx.x;
     const int e = blockIdx.x * 64 + lane;
     const int c = blockIdx.y, b = blockIdx.z;
@@ -222,12 +323,19 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
     const T* __restrict__ u = (const T*)p.u;
     const T* __restrict__ dl = (const T*)p.delta;
     const T* __restrict__ z = (const T*)p.z;
-    const T* __restrict__ Bm = (const T*)p.Bm;
-    const T* __restrict__ Cm = (const T*)p.Cm;
     const T* __restrict__ dy = (const T*)p.dy;
     T* __restrict__ du = (T*)p.du;
     T* __restrict__ dd = (T*)p.ddelta;
     T* __restrict__ dz = (T*)p.dz;
+    const bool has_z = z != nullptr;
+    // B / C row tiles (aligned to 16 steps from t0) live behind the checkpoints in LDS
+    constexpr int F4 = RowTile<N, TT>::F4;
+    float4* tiles = reinterpret_cast<float4*>(ck + (size_t)((p.T + S - 1) / S) * N * 64);
+    const int64_t last_f4 = (int64_t)p.B * p.L * (N / 4) - 1;
+    const int vz = opaque_zero();
+    const RowTile<N, TT> tB{tiles, p.Bm, last_f4, lane, vz};
+    const RowTile<N, TT> tC{tiles + 2 * F4, p.Cm, last_f4, lane, vz};
+    const int64_t row0 = (int64_t)b * p.L + t0;
 
     float A2[N], h[N];
 #pragma unroll
@@ -243,24 +351,47 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
     const float bias = p.dbias ? p.dbias[e] : 0.f;
     const float Dv = p.D ? p.D[e] : 0.f;
 
-    // sweep 1
-    for (int j = 0; j < nsub; ++j) {
+    // ---- sweep 1: checkpoints at every sub-chunk start (the last sub-chunk needs no advance)
+    {
+        const int tend = t0 + (nsub - 1) * S;           // steps [t0, tend) are advanced
+        T ub[TT], db[TT], un[TT], dn[TT];
+        auto load_tile = [&](int tb, T (&uu)[TT], T (&dv)[TT]) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) ck[(j * N + n) * 64 + lane] = h[n];
-        if (j == nsub - 1) break;
+            for (int s2 = 0; s2 < TT; ++s2) {
+                const size_t off = ((size_t)b * p.L + min(tb + s2, t1 - 1)) * p.ED + e;
+                uu[s2] = u[off]; dv[s2] = dl[off];
+            }
+        };
+        if (tend > t0) { load_tile(t0, ub, db); tB.park(0, tB.fetch(row0)); }
+        int cur = 0;
+        for (int tb = t0; tb < tend; tb += TT, cur ^= 1) {
+            const bool more = tb + TT < tend;
+            float4 fb;
+            if (more) { load_tile(tb + TT, un, dn); fb = tB.fetch((int64_t)b * p.L + tb + TT); }
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int t = t0 + j * S + s;
-            const size_t row = (size_t)b * p.L + t;
-            const size_t off = row * p.ED + e;
-            float dt = IO<T>::ld(dl + off) + bias;
-            if (p.softplus) dt = softplusf_(dt);
-            const float dtu = dt * IO<T>::ld(u + off);
-            float Bv[N];
-            RowLd<T, N>::ld(Bm + row * N, Bv);
+            for (int s2 = 0; s2 < TT; ++s2) {
+                const int t = tb + s2;
+                if (t < tend) {
+                    if ((s2 % S) == 0) {
+                        const int j = (t - t0) / S;
 #pragma unroll
-            for (int n = 0; n < N; ++n) h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
+                        for (int n = 0; n < N; ++n) ck[(j * N + n) * 64 + lane] = h[n];
+                    }
+                    float dt = IO<T>::ld(&db[s2]) + bias;
+                    if (p.softplus) dt = softplusf_(dt);
+                    const float dtu = dt * IO<T>::ld(&ub[s2]);
+                    float Bv[N];
+                    tB.row(cur, s2, Bv);
+#pragma unroll
+                    for (int n = 0; n < N; ++n) h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
+                }
+            }
+            if (more) tB.park(cur ^ 1, fb);
+#pragma unroll
+            for (int s2 = 0; s2 < TT; ++s2) { ub[s2] = un[s2]; db[s2] = dn[s2]; }
         }
+#pragma unroll
+        for (int n = 0; n < N; ++n) ck[((nsub - 1) * N + n) * 64 + lane] = h[n];
     }
 
     float q[N], dAacc[N];
@@ -275,81 +406,99 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
     for (int n = 0; n < N; ++n) dAacc[n] = 0.f;
     float dDacc = 0.f, dbacc = 0.f;
 
-    // sweep 2
+    // ---- sweep 2
+    T uc[S], dc[S], zc[S], gc[S], un2[S], dn2[S], zn2[S], gn2[S];
+    auto load_sub = [&](int j, T (&uu)[S], T (&dv)[S], T (&zz)[S], T (&gg)[S]) {
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+            const size_t off = ((size_t)b * p.L + min(t0 + j * S + s2, t1 - 1)) * p.ED + e;
+            uu[s2] = u[off]; dv[s2] = dl[off]; gg[s2] = dy[off];
+            if (has_z) zz[s2] = z[off];
+        }
+    };
+    load_sub(nsub - 1, uc, dc, zc, gc);
+    constexpr int SPT = TT / S;                       // sub-chunks per row tile
+    {
+        const int k = (nsub - 1) / SPT;
+        tB.park(k & 1, tB.fetch(row0 + (int64_t)k * TT));
+        tC.park(k & 1, tC.fetch(row0 + (int64_t)k * TT));
+    }
+    float4 fb2, fc2;
     for (int j = nsub - 1; j >= 0; --j) {
+        if (j > 0) load_sub(j - 1, un2, dn2, zn2, gn2);
+        const int k = j / SPT, r0 = (j - k * SPT) * S, tbuf = k & 1;
+        if (k > 0 && (j == nsub - 1 || j - k * SPT == SPT - 1)) {      // entering tile k: its predecessor goes out now
+            fb2 = tB.fetch(row0 + (int64_t)(k - 1) * TT);
+            fc2 = tC.fetch(row0 + (int64_t)(k - 1) * TT);
+        }
         const int ts = t0 + j * S;
-        float hs[S][N], as[S][N], dts[S], us[S], sg[S];
+        float hs[S][N], dts[S], us[S], sg[S];
         float h0[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) h0[n] = ck[(j * N + n) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int t = ts + s;
-            const bool live = t < t1;
-            const size_t row = (size_t)b * p.L + (live ? t : t1 - 1);
-            const size_t off = row * p.ED + e;
-            const float draw = IO<T>::ld(dl + off) + bias;
-            float dt = draw;
-            float sgm = 1.f;
+        for (int s2 = 0; s2 < S; ++s2) {
+            const float draw = IO<T>::ld(&dc[s2]) + bias;
+            float dt = draw, sgm = 1.f;
             if (p.softplus) { dt = softplusf_(draw); sgm = draw > 20.f ? 1.f : sigmoidf_(draw); }
-            dts[s] = dt; sg[s] = sgm;
-            us[s] = IO<T>::ld(u + off);
-            const float dtu = dt * us[s];
+            dts[s2] = dt; sg[s2] = sgm;
+            us[s2] = IO<T>::ld(&uc[s2]);
+            const float dtu = dt * us[s2];
             float Bv[N];
-            RowLd<T, N>::ld(Bm + row * N, Bv);
+            tB.row(tbuf, r0 + s2, Bv);
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-                as[s][n] = fast_exp2(dt * A2[n]);
-                const float hp = (s == 0) ? h0[n] : hs[s - 1][n];
-                hs[s][n] = fmaf(as[s][n], hp, dtu * Bv[n]);
+                const float hp = (s2 == 0) ? h0[n] : hs[s2 - 1][n];
+                hs[s2][n] = fmaf(fast_exp2(dt * A2[n]), hp, dtu * Bv[n]);
             }
         }
         float dBrow[S], dCrow[S];
 #pragma unroll
-        for (int s = S - 1; s >= 0; --s) {
-            const int t = ts + s;
-            dBrow[s] = 0.f; dCrow[s] = 0.f;
+        for (int s2 = S - 1; s2 >= 0; --s2) {
+            const int t = ts + s2;
+            dBrow[s2] = 0.f; dCrow[s2] = 0.f;
             if (t < t1) {   // wave-uniform
                 const size_t row = (size_t)b * p.L + t;
                 const size_t off = row * p.ED + e;
                 float Bv[N], Cv[N];
-                RowLd<T, N>::ld(Bm + row * N, Bv);
-                RowLd<T, N>::ld(Cm + row * N, Cv);
-                const float dyv = IO<T>::ld(dy + off);
+                tB.row(tbuf, r0 + s2, Bv);
+                tC.row(tbuf, r0 + s2, Cv);
+                const float dyv = IO<T>::ld(&gc[s2]);
                 float g = dyv;
-                if (z) {
-                    const float zv = IO<T>::ld(z + off);
+                if (has_z) {
+                    const float zv = IO<T>::ld(&zc[s2]);
                     const float sz = sigmoidf_(zv);
-                    float yss = Dv * us[s];
+                    float yss = Dv * us[s2];
 #pragma unroll
-                    for (int n = 0; n < N; ++n) yss = fmaf(hs[s][n], Cv[n], yss);
+                    for (int n = 0; n < N; ++n) yss = fmaf(hs[s2][n], Cv[n], yss);
                     // d/dz [y*z*sigmoid(z)] = y*sigmoid(z)*(1 + z*(1-sigmoid(z)))
                     IO<T>::st(dz + off, dyv * yss * sz * (1.f + zv * (1.f - sz)));
                     g = dyv * zv * sz;
                 }
                 float ddt = 0.f, dub = 0.f;
                 float dBv[N], dCv[N];
-                const float dtu = dts[s] * us[s];
+                const float dtu = dts[s2] * us[s2];
 #pragma unroll
                 for (int n = 0; n < N; ++n) {
+                    const float a = fast_exp2(dts[s2] * A2[n]);
                     const float dh = fmaf(Cv[n], g, q[n]);
-                    const float hp = (s == 0) ? h0[n] : hs[s - 1][n];
-                    const float da = dh * hp * as[s][n];        // dL/d(dt*A) for this (t,n)
-                    dAacc[n] = fmaf(da, dts[s], dAacc[n]);
-                    ddt = fmaf(da, A2[n], ddt);                 // A2 = A*log2e, rescaled below
+                    const float hp = (s2 == 0) ? h0[n] : hs[s2 - 1][n];
+                    const float da = dh * hp * a;                 // dL/d(dt*A) for this (t,n)
+                    dAacc[n] = fmaf(da, dts[s2], dAacc[n]);
+                    ddt = fmaf(da, A2[n], ddt);                   // A2 = A*log2e, rescaled below
                     dub = fmaf(dh, Bv[n], dub);
                     dBv[n] = dh * dtu;
-                    dCv[n] = hs[s][n] * g;
-                    q[n] = as[s][n] * dh;
+                    dCv[n] = hs[s2][n] * g;
+                    q[n] = a * dh;
                 }
-                ddt = ddt * GFE_LN2 + dub * us[s];
-                const float ddraw = ddt * sg[s];
+                ddt = ddt * GFE_LN2 + dub * us[s2];
+                const float ddraw = ddt * sg[s2];
                 IO<T>::st(dd + off, ddraw);
-                IO<T>::st(du + off, fmaf(dub, dts[s], Dv * g));
-                dDacc = fmaf(g, us[s], dDacc);
+                IO<T>::st(du + off, fmaf(dub, dts[s2], Dv * g));
+                dDacc = fmaf(g, us[s2], dDacc);
                 dbacc += ddraw;
-                dBrow[s] = wave_reduce_vec<N>(dBv);
-                dCrow[s] = wave_reduce_vec<N>(dCv);
+                dBrow[s2] = wave_reduce_vec<N>(dBv);
+                dCrow[s2] = wave_reduce_vec<N>(dCv);
             }
         }
         // lane l holds the (t = ts + s, n = l % N) totals for every s; emit S*N contiguous floats per atomic
@@ -368,6 +517,9 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
                 atomicAdd(p.dCws + o, vc);
             }
         }
+        if (k > 0 && j == k * SPT) { tB.park(tbuf ^ 1, fb2); tC.park(tbuf ^ 1, fc2); }   // leaving tile k
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) { uc[s2] = un2[s2]; dc[s2] = dn2[s2]; zc[s2] = zn2[s2]; gc[s2] = gn2[s2]; }
     }
 #pragma unroll
     for (int n = 0; n < N; ++n) atomicAdd(p.dAws + (size_t)n * p.ED + e, dAacc[n]);
@@ -391,12 +543,13 @@ static int pick_chunk(int64_t B, int64_t L, int64_t ED, int req) {
 template <typename T, int N>
 int sscan_fwd_launch(const SScanParams& p, hipStream_t st) {
     const dim3 blk(256), grid((unsigned)ceil_div(p.ED, 256), p.nchunks, p.B);
+    const size_t lds = 4 * 4 * (16 * N / 4) * sizeof(float4);        // 4 waves x (B,C) x 2 buffers x TT*N/4 float4
     if (p.nchunks > 1) {
-        hipLaunchKernelGGL((sscan_fwd_kernel<T, N, true>), grid, blk, 0, st, p);
+        hipLaunchKernelGGL((sscan_fwd_kernel<T, N, true>), grid, blk, lds, st, p);
         hipLaunchKernelGGL((sscan_carry_kernel<N, false>), dim3((unsigned)ceil_div((int64_t)N * p.ED, 256), p.B), blk, 0, st,
                            p.hstate, p.sdelta, p.A, p.ED, p.nchunks);
     }
-    hipLaunchKernelGGL((sscan_fwd_kernel<T, N, false>), grid, blk, 0, st, p);
+    hipLaunchKernelGGL((sscan_fwd_kernel<T, N, false>), grid, blk, lds, st, p);
     return gfe_launch_status();
 }
 
@@ -405,12 +558,12 @@ int sscan_bwd_launch(const SScanBwdParams& p, hipStream_t st) {
     constexpr int S = 4;
     if (p.nchunks > 1) {
         const dim3 blk(256), grid((unsigned)ceil_div(p.ED, 256), p.nchunks, p.B);
-        hipLaunchKernelGGL((sscan_bwd_state_kernel<T, N>), grid, blk, 0, st, p);
+        hipLaunchKernelGGL((sscan_bwd_state_kernel<T, N>), grid, blk, 4 * 2 * (16 * N / 4) * sizeof(float4), st, p);
         hipLaunchKernelGGL((sscan_carry_kernel<N, true>), dim3((unsigned)ceil_div((int64_t)N * p.ED, 256), p.B), blk, 0, st,
                            p.qstate, p.sdelta, p.A, p.ED, p.nchunks);
     }
     const int nsub = (p.T + S - 1) / S;
-    const size_t lds = (size_t)nsub * N * 64 * sizeof(float);
+    const size_t lds = (size_t)nsub * N * 64 * sizeof(float) + 4 * (16 * N / 4) * sizeof(float4);   // checkpoints + B/C row tiles
     if (lds > 160 * 1024) return GFE_ERR_SHAPE;
     static size_t attr_lds = 0;
     if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)sscan_bwd_kernel<T, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
@@ -435,13 +588,13 @@ int gfe_sscan_plan(int64_t B, int64_t L, int64_t ED, int64_t N, int chunk_req, i
     return GFE_OK;
 }
 
-int gfe_selective_scan_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
+int gfe_selective_scan_fwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
                            const float* D, const void* z, const float* delta_bias, void* y,
                            float* hstate, float* sdelta,
                            int64_t B, int64_t L, int64_t ED, int64_t N, int T, int delta_softplus,
                            int dtype, void* stream) {
     GFE_REQUIRE(u && delta && A && Bm && Cm && y, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0, GFE_ERR_SHAPE);
+    GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % 64 == 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(B <= 65535, GFE_ERR_SHAPE);
     SScanParams p;
     p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y;
@@ -463,7 +616,7 @@ int gfe_selective_scan_fwd(const void* u, const void* delta, const float* A, con
     return GFE_ERR_DTYPE;
 }
 
-int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
+int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
                            const float* D, const void* z, const float* delta_bias, const void* dy,
                            void* du, void* ddelta, void* dz,
                            float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,

@@ -35,9 +35,12 @@ class _SelectiveScanTM(torch.autograd.Function):
         N = A.shape[1]
         dt = _common_dtype(u, delta, Bm, Cm, z)
         cast = lambda t: None if t is None else t.detach().to(dt).contiguous()
-        u_, d_, B_, C_, z_ = cast(u), cast(delta), cast(Bm), cast(Cm), cast(z)
+        u_, d_, z_ = cast(u), cast(delta), cast(z)
+        B_, C_ = _f32c(Bm), _f32c(Cm)            # the kernels take B / C rows in f32 (tiny tensors)
         A_, D_, b_ = _f32c(A), _f32c(D), _f32c(delta_bias)
-        need_grad = any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
+        # the backward needs chunk-start states every <= 32 steps (LDS checkpoints); a forward that is not recorded by autograd
+        # (inference, torch.no_grad) uses coarse chunks instead and saves the state traffic
+        need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
         T, nc = sscan_plan(Bsz, L, ED, N, chunk, backward=need_grad)
         hstate = sdelta = None
         if nc > 1:

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 4
+#define GFE_ABI_VERSION 5
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -47,12 +47,12 @@ int gfe_sscan_plan(int64_t B, int64_t L, int64_t ED, int64_t N, int chunk_req, i
 /* Fused selective scan, token-major layout.
  * Replaces cross_atten/mamba.py:265-286 (selective_scan) + :255-256 (softplus(delta+bias)) + :220-222 (y*silu(z)),
  * i.e. the contract of the reference's plug-in `selective_scan_fn` (mamba.py:251) without its transposes.
- *   u, delta, z, y : (B, L, ED) dtype        Bm, Cm : (B, L, N) dtype
+ *   u, delta, z, y : (B, L, ED) dtype        Bm, Cm : (B, L, N) f32 (always: rows are staged per wave in LDS)
  *   A : (ED, N) f32    D, delta_bias : (ED) f32 or NULL    z : NULL => no gate
  *   hstate (B, nchunks, N, ED) f32, sdelta (B, nchunks, ED) f32: workspaces, required when nchunks > 1;
  *   after the call hstate holds the state at the start of every chunk (kept for the backward).
- *   N in {4, 8, 16}.  T = chunk length from gfe_sscan_plan. */
-int gfe_selective_scan_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
+ *   N in {4, 8, 16}, ED % 64 == 0.  T = chunk length from gfe_sscan_plan. */
+int gfe_selective_scan_fwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
                            const float* D, const void* z, const float* delta_bias, void* y,
                            float* hstate, float* sdelta,
                            int64_t B, int64_t L, int64_t ED, int64_t N, int T, int delta_softplus,
@@ -62,7 +62,7 @@ int gfe_selective_scan_fwd(const void* u, const void* delta, const float* A, con
  *   du, ddelta, dz : (B, L, ED) dtype (ddelta is w.r.t. the raw delta when delta_softplus)
  *   dA_ws (N, ED) f32 [transposed], dB_ws, dC_ws (B, L, N) f32, dD_ws, dbias_ws (ED) f32: zeroed, accumulated atomically
  *   hstate, sdelta: as left by the forward run with the same T; qstate: workspace like hstate.  ED % 64 == 0. */
-int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
+int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
                            const float* D, const void* z, const float* delta_bias, const void* dy,
                            void* du, void* ddelta, void* dz,
                            float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
