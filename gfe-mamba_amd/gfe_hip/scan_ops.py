@@ -30,7 +30,7 @@ def _f32c(t):
 
 class _SelectiveScanTM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk):
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk, need_grad):
         Bsz, L, ED = u.shape
         N = A.shape[1]
         dt = _common_dtype(u, delta, Bm, Cm, z)
@@ -38,9 +38,6 @@ class _SelectiveScanTM(torch.autograd.Function):
         u_, d_, z_ = cast(u), cast(delta), cast(z)
         B_, C_ = _f32c(Bm), _f32c(Cm)            # the kernels take B / C rows in f32 (tiny tensors)
         A_, D_, b_ = _f32c(A), _f32c(D), _f32c(delta_bias)
-        # the backward needs chunk-start states every <= 32 steps (LDS checkpoints); a forward that is not recorded by autograd
-        # (inference, torch.no_grad) uses coarse chunks instead and saves the state traffic
-        need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
         T, nc = sscan_plan(Bsz, L, ED, N, chunk, backward=need_grad)
         hstate = sdelta = None
         if nc > 1:
@@ -78,7 +75,7 @@ class _SelectiveScanTM(torch.autograd.Function):
         dA = dA_ws.view(N, ED).t()
         return (to(du, 0), to(dd, 1), to(dA, 2), to(dB_ws.view(Bsz, L, N), 3), to(dC_ws.view(Bsz, L, N), 4),
                 to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,
-                to(db_ws, 7) if b_ is not None else None, None, None)
+                to(db_ws, 7) if b_ is not None else None, None, None, None)
 
 
 def selective_scan_tm(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=False, chunk=0):
@@ -88,7 +85,10 @@ def selective_scan_tm(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delt
     """
     if not u.is_cuda:
         raise RuntimeError("gfe_hip selective scan needs CUDA/HIP tensors (no CPU fallback)")
-    return _SelectiveScanTM.apply(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk)
+    # the backward needs chunk-start states every <= 32 steps (LDS checkpoints); a forward that autograd does not record
+    # (inference, torch.no_grad) uses coarse chunks instead and saves the state traffic
+    need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
+    return _SelectiveScanTM.apply(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk, need_grad)
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False):

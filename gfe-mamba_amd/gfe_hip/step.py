@@ -11,8 +11,28 @@ from .train_ops import Condition, FlatAdam
 
 
 def dp_mean_scale(world_size):
-    """all_reduce(SUM) followed by this scale == gradient of the global-batch mean loss."""
+    """all_reduce(SUM) followed by this scale == gradient of the global-batch mean loss (equal shards)."""
     return 1.0 / world_size
+
+
+def shard_batch(tensors, rank, world_size):
+    """Contiguous equal shards of the leading (batch) dimension: rank r gets rows [r*B/W, (r+1)*B/W)."""
+    out = []
+    for t in tensors:
+        B = t.shape[0]
+        assert B % world_size == 0, "global batch must divide evenly over ranks (BCELoss mean == mean of shard means)"
+        n = B // world_size
+        out.append(t[rank * n:(rank + 1) * n])
+    return out
+
+
+def allreduce_grads_(flat_grad, world_size, group=None):
+    """The step's only collective: SUM all-reduce of the flat gradient buffer (RCCL on GPUs, gloo in the CPU tests).
+    Returns the scale the optimiser must apply (folded into the clip/Adam kernel instead of a separate pass)."""
+    import torch.distributed as dist
+    if world_size > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return dp_mean_scale(world_size)
 
 
 class ClassifyStep:

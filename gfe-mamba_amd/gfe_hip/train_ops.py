@@ -173,12 +173,11 @@ class FlatAdam:
                 p.grad = self.flat_g[int(o):int(o) + s].view(p.shape)
 
     def step(self, world_size=1, group=None):
-        import torch.distributed as dist
-        if world_size > 1:
-            dist.all_reduce(self.flat_g, group=group)                     # SUM over ranks; mean folded into grad_scale
+        from .step import allreduce_grads_
+        scale = allreduce_grads_(self.flat_g, world_size, group)         # SUM over ranks; the mean is folded into grad_scale
         self.t += 1
         self.norm2.zero_()
         call("gfe_clip_adam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.flat_p16),
-             ptr(self.chunks), self.nchunks, ptr(self.norm2), 1.0 / world_size, self.max_norm, self.lr, self.betas[0], self.betas[1],
+             ptr(self.chunks), self.nchunks, ptr(self.norm2), scale, self.max_norm, self.lr, self.betas[0], self.betas[1],
              self.eps, self.t, stream())
         # parameters are rewritten by the kernel (no version bump): the registered bf16 shadows stay current by construction
