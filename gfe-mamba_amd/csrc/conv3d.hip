@@ -8,88 +8,93 @@
 // by describing a convolution as a *tap list*: out[v] = sum_taps W[tap] . x[v + off(tap)].  The transposed conv is
 // 8 such lists, one per output-parity class (1/2/4/8 taps; out[2i] = w1 x[i], out[2i+1] = w2 x[i] + w0 x[i+1] per axis).
 //
-// GEMM view (per block): rows = output channels (MFMA A operand = weights), cols = 256 output voxels (4x8x8 tile,
-// MFMA B operand = activations), K = taps x Cin, walked as 32-channel slabs (one 16x16x32 MFMA K-step per tap).
-//   LDS: activation halo tile [6x10x10 voxels][32 ch] bf16, 64-B voxel stride with XOR-swizzled 16-B chunks (fragment
-//        reads are bank-conflict free, see below), GroupNorm scale/shift applied while staging,
-//        zero padding written as exact zeros (the reference pads AFTER the norm);
-//        weights [taps-per-stage][Cout tile][32] bf16 double-buffered, next stage prefetched to registers under the MFMAs.
-//   Each wave owns one d-plane of the tile: 4 voxel tiles x NT channel tiles of f32x4 accumulators.
-//   Operands are swapped (weights = A) so a lane ends up with 4 consecutive channels of one voxel -> 8-B stores.
-// 2 blocks/CU (<= 80 KB LDS each) so one block's staging overlaps the other's MFMAs.
+// GEMM view (per block): rows = 64 output channels (MFMA A operand = weights), cols = 512 output voxels (8x8x8 tile,
+// MFMA B operand = activations), K = taps x Cin walked as 32-channel slabs (one 16x16x32 MFMA K-step per tap).
+// 8 waves, each owns one d-plane of the tile: 4 voxel tiles x NT channel tiles of f32x4 accumulators.
+//
+// Staging is pure DMA: `buffer_load_dwordx4 ... lds` moves 1 KiB per wave instruction straight from global memory into
+// LDS (per-lane source address, lane-linear destination) -- no VGPR staging, no ds_write, no per-element VALU work:
+//   * activation halo tile [10x10x10 voxels][32 ch] bf16, double-buffered (the next (tile, group, slab) unit lands while
+//     the current one is multiplied); out-of-volume voxels get an out-of-range buffer offset, which the hardware returns as
+//     zeros = the conv's zero padding;
+//   * weight stages [3 taps][64 ch][32] bf16, double-buffered.
+// Both images use 64-B rows with XOR-swizzled 16-B chunks (applied on the SOURCE address; the LDS destination of a DMA is
+// linear), so every ds_read_b128 fragment read is bank-conflict free (tools/lds_bank_model.py).
+// GroupNorm never touches the loop: x_hat = s[b,c]*x + t[b,c] is folded into per-sample weights bf16(W*s_b) and a bias
+// table indexed by the voxel's boundary class (which taps fall outside the volume: the reference pads x_hat with zeros
+// AFTER the norm, so the shift term only counts taps that are inside) -- gfe_conv3d_fold_groupnorm below.
+// Operands are swapped (weights = A) and weight rows are permuted at pack time so a lane ends up with 16 consecutive
+// channels of one voxel -> contiguous 32-B stores.  Persistent blocks walk contiguous tile ranges (1 block per CU).
+//
+// (Round-1 history, measured on the 64->64 @96^3 conv: VGPR-staged v1 671 TFLOP/s; v2 with prefetch registers, swizzled LDS
+// and division-free index math 730-780; ablation showed the non-MFMA instruction stream cost 2x the MFMA time -> this DMA form.)
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void* lds_void_t;
 
 #if defined(GFE_EXP_NOMFMA)   // timing experiment only: everything but the matrix instructions
 #define GFE_MFMA(a, b, c) (c)
 #else
 #define GFE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
-#if defined(GFE_EXP_NOBAR)    // timing experiment only: no per-stage barrier
-#define GFE_STAGE_BARRIER() do {} while (0)
-#else
-#define GFE_STAGE_BARRIER() __syncthreads()
-#endif
 
 namespace {
 
-constexpr int TD = 4, TH = 8, TW = 8;          // output tile (class-grid voxels)
-constexpr int VSTRIDE = 64;                    // bytes per voxel / weight row in LDS (32 bf16, no padding; XOR-swizzled chunks)
-constexpr int PH = TH + 2, PW = TW + 2;        // fixed LDS pitches of the halo tile (rows x columns), whatever the tap extent
-constexpr int A_MAX_VOX = (TD + 2) * PH * PW;
-constexpr int A_BYTES = A_MAX_VOX * VSTRIDE;   // 38,400
-// Bank-conflict-free ds_read_b128 fragments (MI355X: 64 banks x 4 B, 16-lane groups {0-3,12-15,20-27},...; modelled in
-// tools/lds_bank_model.py): the 16-B chunk c of voxel (row lh, col lw) lives at chunk slot c ^ ((lh & 1) << 1); the chunk c
-// of weight row r lives at slot c ^ ((r >> 1) & 3).  Both fragment reads then take the ideal 4 LDS cycles (was 12 / 8 with
-// an 80-B padded stride).
-
-struct ConvTap { int8_t dd, dh, dw; uint8_t pad; };
+constexpr int TD = 8, TH = 8, TW = 8;          // output tile (class-grid voxels)
+constexpr int NWAVES = TD;                     // one wave per output d-plane
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int VSTRIDE = 64;                    // bytes per voxel / weight row in LDS (32 bf16)
+constexpr int PD = TD + 2, PH = TH + 2, PW = TW + 2;      // fixed LDS pitches of the halo tile
+constexpr int A_VOX = PD * PH * PW;            // 1000
+constexpr int A_PIECES = (A_VOX + 15) / 16;    // 1-KiB DMA pieces (16 voxels each): 63
+// DMA issue is split by wave so that each wave's vmcnt tracks ONE stream: waves 0-3 move weight stages (needed every stage),
+// waves 4-7 move the next unit's activation tile (needed once per unit).  A single wave doing both would have to drain the
+// tile (an HBM round trip) every time it waits for its weight pieces: vmcnt retires in order.
+constexpr int DMA_WAVES = NWAVES / 2;
+constexpr int A_PER_WAVE = (A_PIECES + DMA_WAVES - 1) / DMA_WAVES;   // 16
+constexpr int A_BYTES = A_PER_WAVE * DMA_WAVES * 1024;               // 65,536 (the 64th piece is all out-of-range lanes -> zeros)
+constexpr unsigned OOB = 0x80000000u;          // buffer offset beyond num_records -> the load returns zeros
 
 struct ConvParams {
-    const bf16_t* x; const bf16_t* w; const float* gn_scale; const float* gn_shift; const float* bias;
-    const bf16_t* res; bf16_t* y;
+    const bf16_t* x; const bf16_t* w; const float* bias; const float* bias_tab; const bf16_t* res; bf16_t* y;
+    long long w_batch_stride;                  // elements between per-sample weight sets (0: shared)
     int B, D, H, W, Cin, Cout, CoutPad;
     int OD, OH, OW;
-    int ntaps, nslab;
+    int ntaps, nslab, ngroups;
     int lo_d, lo_h, lo_w, LD, LH, LW;
     int ostride, op_d, op_h, op_w, oshift;
     int relu;
     int ntd, nth, ntw, tiles_per_block;
-    int LHW, NV;
-    int toff[27];                             // LDS byte offset of each tap inside the halo tile
-    int txor[27];                             // 32 when the tap shifts the row parity (swizzle term), else 0
+    int toff[27];                              // LDS byte offset of each tap inside the halo tile
+    int txor[27];                              // 32 when the tap shifts the row parity (swizzle term), else 0
 };
 
 struct TilePos { int b, td, th, tw; };
 
-template <int NT, int TPS, bool PIPE, bool REG27>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+template <int NT, int TPS, bool REG27>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer/LDS-DMA builtins)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* sA = smem;
-    uint8_t* sW = smem + A_BYTES;
-    constexpr int WROWS_TAP = NT * 16;                       // weight rows (output channels) per tap
-    constexpr int WSTAGE_BYTES = TPS * WROWS_TAP * VSTRIDE;
-    constexpr int WJ = (WROWS_TAP * 4 + 255) / 256;          // 16-B chunks per thread per tap
-    constexpr int PLANES = TD + 2;                           // d-planes of the halo tile
-    constexpr int AITEMS = 2 * PLANES;                       // 16-B chunks per thread per activation tile
-    constexpr int PLANE_BYTES = PH * PW * VSTRIDE;
+    constexpr int WROWS_TAP = NT * 16;                       // weight rows (output channels of a group) per tap
+    constexpr int WSTAGE_ROWS = TPS * WROWS_TAP;
+    constexpr int W_PIECES = (WSTAGE_ROWS + 15) / 16;        // 1-KiB pieces per stage
+    constexpr int W_PER_WAVE = (W_PIECES + DMA_WAVES - 1) / DMA_WAVES;
+    uint8_t* sA = smem;                                      // 2 x A_BYTES
+    uint8_t* sW = smem + 2 * A_BYTES;                        // 2 x W_PIECES KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    const int cg = blockIdx.y;
     const int ntiles = p.B * p.ntd * p.nth * p.ntw;
-
-    // a block walks a contiguous range of tiles (adjacent in w, then h, d, b: halo lines of the next tile are L2-warm)
     const int tile_begin = blockIdx.x * p.tiles_per_block;
     const int tile_end = min(ntiles, tile_begin + p.tiles_per_block);
-    const int nunits = (tile_end - tile_begin) * p.nslab;   // unit = (tile, 32-channel slab)
+    const int upt = p.ngroups * p.nslab;                     // units per tile: (group, slab)
+    const int nunits = (tile_end - tile_begin) * upt;
     if (nunits <= 0) return;
+    const int nstage = (p.ntaps + TPS - 1) / TPS;
 
-    f32x4 acc[4][NT];
-
-    // per-lane LDS byte offsets of the 4 voxel tiles (tap offset added per tap) and of the weight fragment
+    // ---- fragment read bases
     int abase[4];
 #pragma unroll
     for (int xt = 0; xt < 4; ++xt) {
@@ -97,17 +102,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         abase[xt] = ((wave * PH + lh) * PW + lw) * VSTRIDE + ((lq ^ ((lh & 1) << 1)) * 16);
     }
     const int wbase = lr * VSTRIDE + ((lq ^ ((lr >> 1) & 3)) * 16);
-    const int nstage = (p.ntaps + TPS - 1) / TPS;
 
-    // ---- thread-constant staging coordinates: each thread moves one 16-B chunk of two voxels of every d-plane.
-    // No per-item index arithmetic is left in the loop (constant divisors only, evaluated once).
-    const int chunk = tid & 3;                               // 8-channel chunk inside the 32-channel slab
-    const int v0 = tid >> 2, v1 = 64 + (tid >> 2);           // voxel index inside a PH x PW plane
-    const int lh0 = v0 / PW, lw0 = v0 - lh0 * PW, lh1 = v1 / PW, lw1 = v1 - lh1 * PW;
-    const bool in0 = lh0 < p.LH && lw0 < p.LW;
-    const bool in1 = v1 < PH * PW && lh1 < p.LH && lw1 < p.LW;
-    const int lds0 = (lh0 * PW + lw0) * VSTRIDE + ((chunk ^ ((lh0 & 1) << 1)) * 16);
-    const int lds1 = (lh1 * PW + lw1) * VSTRIDE + ((chunk ^ ((lh1 & 1) << 1)) * 16);
+    // ---- thread-constant DMA coordinates.  Activation piece k = dw + 4*j (dw = wave % 4) moves voxels 16k..16k+15:
+    // lane -> voxel 16k + lane/4, LDS chunk slot lane%4, which must hold data chunk slot ^ ((row & 1) << 1).
+    const int dw = wave & (DMA_WAVES - 1);
+    const bool a_wave = wave >= DMA_WAVES;
+    int acoord[A_PER_WAVE];          // ld | lh << 4 | lw << 8 | (chunk*16) << 12 | valid << 20
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+        const int k = dw + DMA_WAVES * j, v = 16 * k + (lane >> 2);
+        const int ld = v / (PH * PW), rem = v - ld * (PH * PW), lh = rem / PW, lw = rem - lh * PW;
+        const int c = (lane & 3) ^ ((lh & 1) << 1);
+        const bool valid = k < A_PIECES && v < A_VOX && ld < p.LD && lh < p.LH && lw < p.LW;
+        acoord[j] = ld | (lh << 4) | (lw << 8) | ((c * 16) << 12) | ((valid ? 1 : 0) << 20);
+    }
+    // weight piece k = dw + 4*j moves stage rows 16k..16k+15 (row = tap_local*WROWS_TAP + r): lane -> row 16k + lane/4
+    unsigned wvoff[W_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < W_PER_WAVE; ++j) {
+        const int k = dw + DMA_WAVES * j, R = 16 * k + (lane >> 2);
+        const int tl = R / WROWS_TAP, r = R - tl * WROWS_TAP;
+        const int c = (lane & 3) ^ ((r >> 1) & 3);
+        wvoff[j] = (k < W_PIECES && R < WSTAGE_ROWS) ? (unsigned)((tl * p.CoutPad + r) * 64 + c * 16) : OOB;
+    }
 
     TilePos cur;
     {
@@ -116,130 +133,60 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         cur.th = t % p.nth; t /= p.nth;
         cur.td = t % p.ntd; cur.b = t / p.ntd;
     }
-    TilePos nxt = cur;                                       // position of the unit being prefetched
+    TilePos nxt = cur;
     auto advance = [&](TilePos& q) {
         if (++q.tw == p.ntw) { q.tw = 0; if (++q.th == p.nth) { q.th = 0; if (++q.td == p.ntd) { q.td = 0; ++q.b; } } }
     };
 
-    // ---- register staging of one unit's activation halo tile (raw bf16)
-    uint4 areg[AITEMS];
-    unsigned amask = 0;
-    auto aload = [&](const TilePos& q, int slab, int pl0, int pl1) {
+    const size_t sample_elems = (size_t)p.D * p.H * p.W * p.Cin;
+    const unsigned sample_bytes = (unsigned)(sample_elems * 2);
+    const unsigned wset_bytes = (unsigned)((size_t)p.nslab * p.ntaps * p.CoutPad * 64);     // one sample's weights
+
+    // ---- DMA issue
+    auto a_dma = [&](const TilePos& q, int slab, int buf) {
+        const bf16_t* base = p.x + (size_t)q.b * sample_elems;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)sample_bytes, 0x00020000);
         const int d0 = q.td * TD + p.lo_d, h0 = q.th * TH + p.lo_h, w0 = q.tw * TW + p.lo_w;
-        const int cch = slab * 32 + chunk * 8;
-        const bool ch_ok = cch < p.Cin;
-        const int gh0 = h0 + lh0, gw0 = w0 + lw0, gh1 = h0 + lh1, gw1 = w0 + lw1;
-        const bool ok0 = in0 && ch_ok && (unsigned)gh0 < (unsigned)p.H && (unsigned)gw0 < (unsigned)p.W;
-        const bool ok1 = in1 && ch_ok && (unsigned)gh1 < (unsigned)p.H && (unsigned)gw1 < (unsigned)p.W;
-        const int off0 = (gh0 * p.W + gw0) * p.Cin + cch, off1 = (gh1 * p.W + gw1) * p.Cin + cch;
-        const size_t plane = (size_t)p.H * p.W * p.Cin;
-        const bf16_t* base = p.x + (size_t)q.b * p.D * plane;
-        if (pl0 == 0) amask = 0;
 #pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl) {
-            if (pl < pl0 || pl >= pl1) continue;
-            const int gd = d0 + pl;
-            const bool dok = pl < p.LD && (unsigned)gd < (unsigned)p.D;           // wave-uniform
-            areg[2 * pl] = make_uint4(0, 0, 0, 0);
-            areg[2 * pl + 1] = make_uint4(0, 0, 0, 0);
-            if (dok) {
-                const bf16_t* pb = base + (size_t)gd * plane;
-                if (ok0) { areg[2 * pl] = *reinterpret_cast<const uint4*>(pb + off0); amask |= 1u << (2 * pl); }
-                if (ok1) { areg[2 * pl + 1] = *reinterpret_cast<const uint4*>(pb + off1); amask |= 2u << (2 * pl); }
+        for (int j = 0; j < A_PER_WAVE; ++j) {
+            const int k = dw + DMA_WAVES * j;
+            {
+                const int ac = acoord[j];
+                const int gd = d0 + (ac & 15), gh = h0 + ((ac >> 4) & 15), gw = w0 + ((ac >> 8) & 15);
+                const int cb = (ac >> 12) & 0xff;                            // chunk byte offset inside the slab
+                const bool ok = ((ac >> 20) & 1) && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                                (unsigned)gw < (unsigned)p.W && slab * 32 + (cb >> 1) < p.Cin;
+                const unsigned voff = ok ? (unsigned)((((gd * p.H + gh) * p.W + gw) * p.Cin + slab * 32) * 2 + cb) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + buf * A_BYTES + k * 1024), 16, voff, 0, 0, 0);
             }
         }
     };
-    // GroupNorm applied while writing to LDS; out-of-volume voxels stay exact zeros (the reference pads AFTER the norm)
-    auto astore = [&](const TilePos& q, int slab, int pl0, int pl1) {
-        float sc[8], sh[8];
-        const int cch = slab * 32 + chunk * 8;
-        if (p.gn_scale && cch < p.Cin) {
-            const float4* ps = reinterpret_cast<const float4*>(p.gn_scale + (size_t)q.b * p.Cin + cch);
-            const float4* pt = reinterpret_cast<const float4*>(p.gn_shift + (size_t)q.b * p.Cin + cch);
-            const float4 s0 = ps[0], s1 = ps[1], t0 = pt[0], t1 = pt[1];
-            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-            sh[0] = t0.x; sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w; sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;
-        }
+    auto w_dma = [&](int b, int group, int slab, int stage, int buf) {
+        const bf16_t* base = p.w + (size_t)b * p.w_batch_stride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)wset_bytes, 0x00020000);
+        // taps beyond ntaps in the last stage read past the slab (still inside the set, or OOB -> zeros): never multiplied
+        const unsigned soff = (unsigned)((((size_t)slab * p.ntaps + stage * TPS) * p.CoutPad + group * WROWS_TAP) * 64);
 #pragma unroll
-        for (int k = 0; k < AITEMS; ++k) {
-            const int pl = k >> 1;
-            if (pl < pl0 || pl >= pl1) continue;
-            if (pl < p.LD && ((k & 1) ? in1 : in0)) {
-                uint4 v = areg[k];
-                if (p.gn_scale && ((amask >> k) & 1u)) {
-                    v.x = pack_bf16x2(fmaf(bf16lo_to_f32(v.x), sc[0], sh[0]), fmaf(bf16hi_to_f32(v.x), sc[1], sh[1]));
-                    v.y = pack_bf16x2(fmaf(bf16lo_to_f32(v.y), sc[2], sh[2]), fmaf(bf16hi_to_f32(v.y), sc[3], sh[3]));
-                    v.z = pack_bf16x2(fmaf(bf16lo_to_f32(v.z), sc[4], sh[4]), fmaf(bf16hi_to_f32(v.z), sc[5], sh[5]));
-                    v.w = pack_bf16x2(fmaf(bf16lo_to_f32(v.w), sc[6], sh[6]), fmaf(bf16hi_to_f32(v.w), sc[7], sh[7]));
-                }
-                *reinterpret_cast<uint4*>(sA + pl * PLANE_BYTES + ((k & 1) ? lds1 : lds0)) = v;
-            }
+        for (int j = 0; j < W_PER_WAVE; ++j) {
+            const int k = dw + DMA_WAVES * j;
+            if (k < W_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sW + buf * (W_PIECES * 1024) + k * 1024), 16, wvoff[j], soff, 0, 0);
         }
     };
 
-    // ---- weight stages: global [slab][tap][CoutPad][32]; thread-constant (row, chunk) inside a tap
-    constexpr bool DEEP = false;      // 3-stage register weight pipeline: correct, but 52 VGPR spills at NT=4 (615 vs 729 TFLOP/s)
-    constexpr int WSETS = (REG27 && DEEP) ? 3 : 1;
-    uint4 wq[WSETS][TPS * WJ];
-    auto wload = [&](uint4 (&wr)[TPS * WJ], int slab, int stage) {
-        const bf16_t* wslab = p.w + ((size_t)slab * p.ntaps * p.CoutPad + (size_t)cg * WROWS_TAP) * 32;
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl) {
-#if defined(GFE_EXP_WHOT)
-            const int tap = 0 * (stage * TPS + tl);      // timing experiment only: every stage re-reads the same (hot) weights
-#else
-            const int tap = stage * TPS + tl;
-#endif
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) {
-                const int itl = tid + j * 256;
-                wr[tl * WJ + j] = make_uint4(0, 0, 0, 0);
-                if (itl < WROWS_TAP * 4 && tap < p.ntaps)
-                    wr[tl * WJ + j] = *reinterpret_cast<const uint4*>(wslab + ((size_t)tap * p.CoutPad + (itl >> 2)) * 32 + (itl & 3) * 8);
-            }
-        }
-    };
-    auto wstore = [&](const uint4 (&wr)[TPS * WJ], int buf) {
-#if defined(GFE_EXP_NOW)
-        if (buf >= 0) return;                             // timing experiment only: weights are never restaged
-#endif
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl)
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) {
-                const int itl = tid + j * 256, rr = itl >> 2;
-                if (itl < WROWS_TAP * 4)
-                    *reinterpret_cast<uint4*>(sW + buf * WSTAGE_BYTES + (tl * WROWS_TAP + rr) * VSTRIDE + (((itl & 3) ^ ((rr >> 1) & 3)) * 16)) = wr[tl * WJ + j];
-            }
-    };
+    f32x4 acc[4][NT];
 
-    if (PIPE) aload(cur, 0, 0, PLANES);
-    wload(wq[0], 0, 0);
-    if constexpr (REG27 && DEEP) { wload(wq[1], 0, 1); wload(wq[2], 0, 2); }
+    if (a_wave) a_dma(cur, 0, 0); else w_dma(cur.b, 0, 0, 0, 0);
+    int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
 
     for (int u = 0; u < nunits; ++u) {
-        const int slab = u % p.nslab;
-        // registers hold unit u (activations + stage-0 weights); every wave passed the barrier that ended unit u-1
-#if defined(GFE_EXP_NOA)
-        if (u == 0)
-#endif
-        if (PIPE) {
-            astore(cur, slab, 0, PLANES);
-        } else {      // wide variant: no register budget to hold a tile across the MFMA loop -> two batches of 3 planes
-            aload(cur, slab, 0, PLANES / 2); astore(cur, slab, 0, PLANES / 2);
-            aload(cur, slab, PLANES / 2, PLANES); astore(cur, slab, PLANES / 2, PLANES);
-        }
-        wstore(wq[0], 0);
-        __syncthreads();
+        const int ut = u % upt, group = ut / p.nslab, slab = ut - group * p.nslab;
         const bool next_unit = u + 1 < nunits;
-        const int nslab_next = (slab + 1 == p.nslab) ? 0 : slab + 1;
-        if constexpr (REG27 && DEEP) wload(wq[0], slab, 3);   // set 0 was just drained: stage 3 goes out now
-        if (next_unit) {
-            if (nslab_next == 0) advance(nxt);
-#if !defined(GFE_EXP_NOA)
-            if (PIPE) aload(nxt, nslab_next, 0, PLANES);     // in flight under this unit's MFMAs
-#endif
-        }
+        const int ut1 = (ut + 1 == upt) ? 0 : ut + 1;
+        const int group1 = ut1 / p.nslab, slab1 = ut1 - group1 * p.nslab;
+        if (next_unit && ut1 == 0) advance(nxt);
+        const uint8_t* aT = sA + (u & 1) * A_BYTES;
+
         if (slab == 0) {
 #pragma unroll
             for (int xt = 0; xt < 4; ++xt)
@@ -247,168 +194,199 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 for (int ct = 0; ct < NT; ++ct) acc[xt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-        if constexpr (REG27 && DEEP) {
-            // regular 3x3x3, 9 stages = (kd, kh), 3 taps kw = 0..2 each.  Weight pipeline: the loads of stage s+4 are issued
-            // when stage s ends (3 stages ~ 1 us ahead of their ds_write: L2 latency under load is longer than one stage).
-            for (int kd = 0; kd < 3; ++kd) {
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int s = kd * 3 + kh;
-                    if constexpr (!DEEP) {
-                        if (s + 1 < 9) wload(wq[0], slab, s + 1);
-                        else if (next_unit) wload(wq[0], nslab_next, 0);
-                    }
-                    const uint8_t* wb = sW + (s & 1) * WSTAGE_BYTES + wbase;
-                    const int sbase = (kd * PH + kh) * PW * VSTRIDE, sx = (kh & 1) << 5;
-                    int ax[4];
-#pragma unroll
-                    for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
-#pragma unroll
-                    for (int tl = 0; tl < TPS; ++tl) {
-                        bf16x8 xf[4];
-#pragma unroll
-                        for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(sA + ax[xt] + tl * VSTRIDE);
-#pragma unroll
-                        for (int ct = 0; ct < NT; ++ct) {
-                            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
-#pragma unroll
-                            for (int xt = 0; xt < 4; ++xt)
-                                acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
-                        }
-                    }
-                    if constexpr (DEEP) {
-                        // stage s+1 lives in set (kh+1)%3; store it (unless it is the next unit's stage 0, stored at that unit's
-                        // top), then refill the set with stage s+4 (wrapping into the next unit's slab)
-                        const int st1 = s + 1, st4 = s + 4;
-                        if (st1 < 9) wstore(wq[(kh + 1) % WSETS], st1 & 1);
-                        if (st4 < 9) wload(wq[(kh + 1) % WSETS], slab, st4);
-                        else if (next_unit && st4 - 9 < 3) wload(wq[(kh + 1) % WSETS], nslab_next, st4 - 9);
-                    } else {
-                        if (s + 1 < 9) wstore(wq[0], (s + 1) & 1);
-                    }
-                    GFE_STAGE_BARRIER();
-                }
+        for (int s = 0; s < nstage; ++s, ++gstage) {
+            // everything issued so far (this unit's tile, this stage's weights) has landed and is visible to all waves
+#if !defined(GFE_EXP_NOBAR)    // timing experiment only: no per-stage wait + barrier
+            // weight waves drain their pieces every stage; activation waves only where the tile changes hands (stage 0)
+            if (!a_wave || s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): no LDS read of the previous stage is still pending
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");                   // no LDS access is scheduled across the barrier
+#endif
+            // refill the buffers nobody reads any more: next stage's weights, and (once per unit) the next unit's tile
+#if !defined(GFE_EXP_NOW)      // timing experiment only: weights are never restaged
+            if (!a_wave) {
+                if (s + 1 < nstage) w_dma(cur.b, group, slab, s + 1, (gstage + 1) & 1);
+                else if (next_unit) w_dma(nxt.b, group1, slab1, 0, (gstage + 1) & 1);
             }
-        } else {
-            for (int s = 0; s < nstage; ++s) {
-                const bool more = s + 1 < nstage;
-                if (more) wload(wq[0], slab, s + 1);
-                else if (next_unit) wload(wq[0], nslab_next, 0);
-                const uint8_t* wb = sW + (s & 1) * WSTAGE_BYTES + wbase;
-                if constexpr (REG27) {
-                    // regular 3x3x3: stage s = (kd, kh), taps kw = 0..2 -> one base per voxel tile + immediate offsets
-                    const int kd = s / 3, kh = s - kd * 3;
-                    const int sbase = (kd * PH + kh) * PW * VSTRIDE, sx = (kh & 1) << 5;
-                    int ax[4];
+#endif
+#if !defined(GFE_EXP_NOA)      // timing experiment only: the activation tile is never restaged
+            if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1);
+#endif
+
+            const uint8_t* wb = sW + (gstage & 1) * (W_PIECES * 1024) + wbase;
+            if constexpr (REG27) {
+                // regular 3x3x3: stage s = (kd, kh), taps kw = 0..2 -> one base per voxel tile + immediate offsets
+                const int kd = s / 3, kh = s - kd * 3;
+                const int sbase = (kd * PH + kh) * PW * VSTRIDE, sx = (kh & 1) << 5;
+                int ax[4];
 #pragma unroll
-                    for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
+                for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
 #pragma unroll
-                    for (int tl = 0; tl < TPS; ++tl) {
-                        bf16x8 xf[4];
+                for (int tl = 0; tl < TPS; ++tl) {
+                    bf16x8 xf[4];
 #pragma unroll
-                        for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(sA + ax[xt] + tl * VSTRIDE);
+                    for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(aT + ax[xt] + tl * VSTRIDE);
 #pragma unroll
-                        for (int ct = 0; ct < NT; ++ct) {
-                            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
+                    for (int ct = 0; ct < NT; ++ct) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
 #pragma unroll
-                            for (int xt = 0; xt < 4; ++xt)
-                                acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
-                        }
+                        for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
                     }
-                } else {
+                }
+            } else {
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     const int tap = s * TPS + tl;
                     if (tap < p.ntaps) {                          // wave-uniform
-                        const int toff = p.toff[tap], txor = p.txor[tap];     // txor: bit 5 toggles when the tap moves to an odd row
+                        const int toff = p.toff[tap], txor = p.txor[tap];
                         bf16x8 xf[4];
 #pragma unroll
-                        for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(sA + ((abase[xt] + toff) ^ txor));
+                        for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(aT + ((abase[xt] + toff) ^ txor));
 #pragma unroll
                         for (int ct = 0; ct < NT; ++ct) {
                             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
 #pragma unroll
-                            for (int xt = 0; xt < 4; ++xt)
-                                acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
+                            for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
                         }
                     }
                 }
-                }
-                if (more) wstore(wq[0], (s + 1) & 1);
-                GFE_STAGE_BARRIER();
             }
         }
-#if defined(GFE_EXP_NOEPI)
-        if (slab != p.nslab - 1 || u + 1 < nunits) { if (slab == p.nslab - 1) advance(cur); continue; }
-#endif
-        if (slab != p.nslab - 1) continue;
 
-        // ---- epilogue: bias, skip/residual add, ReLU, bf16 store (lane: voxel = lr of tile xt, channels 16*ct + 4*lq + 0..3)
-        const int b = cur.b, d0 = cur.td * TD, h0 = cur.th * TH, w0 = cur.tw * TW;
-        const int cd = d0 + wave;
+#if defined(GFE_EXP_NOEPI)     // timing experiment only: results are never stored
+        if (slab == p.nslab - 1 && u + 1 == nunits) {
+#else
+        if (slab == p.nslab - 1) {
+#endif
+            // ---- epilogue: (GroupNorm shift | bias), skip/residual add, ReLU, bf16 store.  Weight rows were permuted at pack
+            // time (row ct*16 + 4*lq + r <-> channel lq*4*NT + 4*ct + r): this lane owns 4*NT consecutive channels.
+            const int b = cur.b, d0 = cur.td * TD, h0 = cur.th * TH, w0 = cur.tw * TW;
+            const int cd = d0 + wave;
+            const int c0 = group * WROWS_TAP + lq * 4 * NT;
+            if (cd < p.D && c0 < p.Cout) {
 #pragma unroll
-        for (int xt = 0; xt < 4; ++xt) {
-            const int ch_ = h0 + 2 * xt + (lr >> 3), cw_ = w0 + (lr & 7);
-            if (cd >= p.D || ch_ >= p.H || cw_ >= p.W) continue;
-            const int od = p.ostride * cd + p.op_d, oh = p.ostride * ch_ + p.op_h, ow = p.ostride * cw_ + p.op_w;
-            // transposed conv: raw output has 2n-1 planes per axis; class-1 positions past it do not exist
-            if (p.ostride == 2 && (od > 2 * p.D - 2 || oh > 2 * p.H - 2 || ow > 2 * p.W - 2)) continue;
-            const int nd = (p.oshift && od == 0) ? 2 : 1, nh = (p.oshift && oh == 0) ? 2 : 1, nw = (p.oshift && ow == 0) ? 2 : 1;
-            for (int zd = 0; zd < nd; ++zd)
-                for (int zh = 0; zh < nh; ++zh)
-                    for (int zw = 0; zw < nw; ++zw) {
-                        const int dd_ = zd ? 0 : od + p.oshift, dh_ = zh ? 0 : oh + p.oshift, dw_ = zw ? 0 : ow + p.oshift;
-                        if (dd_ >= p.OD || dh_ >= p.OH || dw_ >= p.OW) continue;
-                        const size_t vox = (((size_t)b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_;
-                        // weight rows were permuted at pack time (row ct*16 + 4*lq + r  <->  channel lq*4*NT + 4*ct + r), so this lane
-                        // owns 4*NT CONSECUTIVE output channels of the voxel: one 8*NT-byte contiguous piece (full 128-B rows per voxel)
-                        const int c0 = cg * NT * 16 + lq * 4 * NT;
-                        if (c0 >= p.Cout) continue;
-                        float v[4 * NT];
+                for (int xt = 0; xt < 4; ++xt) {
+                    const int ch_ = h0 + 2 * xt + (lr >> 3), cw_ = w0 + (lr & 7);
+                    if (ch_ >= p.H || cw_ >= p.W) continue;
+                    const int od = p.ostride * cd + p.op_d, oh = p.ostride * ch_ + p.op_h, ow = p.ostride * cw_ + p.op_w;
+                    // transposed conv: raw output has 2n-1 planes per axis; class-1 positions past it do not exist
+                    if (p.ostride == 2 && (od > 2 * p.D - 2 || oh > 2 * p.H - 2 || ow > 2 * p.W - 2)) continue;
+                    float v[4 * NT];
 #pragma unroll
-                        for (int ct = 0; ct < NT; ++ct)
+                    for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[4 * ct + r] = acc[xt][ct][r];
-                        if (p.bias) {
+                        for (int r = 0; r < 4; ++r) v[4 * ct + r] = acc[xt][ct][r];
+                    if (p.bias_tab) {
+                        // boundary class: which neighbours of this voxel fall outside the volume
+                        const int cls = (cd == 0) | ((cd == p.D - 1) << 1) | ((ch_ == 0) << 2) | ((ch_ == p.H - 1) << 3) |
+                                        ((cw_ == 0) << 4) | ((cw_ == p.W - 1) << 5);
+                        const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + ((size_t)b * 64 + cls) * p.CoutPad + c0);
 #pragma unroll
-                            for (int i = 0; i < 4 * NT; ++i) v[i] += p.bias[c0 + i];
+                        for (int i = 0; i < NT; ++i) {
+                            const float4 t = bt[i];
+                            v[4 * i] += t.x; v[4 * i + 1] += t.y; v[4 * i + 2] += t.z; v[4 * i + 3] += t.w;
                         }
-                        const size_t o = vox * p.Cout + c0;
-                        if (p.res) {
-                            const uint2* rp = reinterpret_cast<const uint2*>(p.res + o);
-#pragma unroll
-                            for (int i = 0; i < NT; ++i) {
-                                const uint2 rv = rp[i];
-                                v[4 * i] += bf16lo_to_f32(rv.x); v[4 * i + 1] += bf16hi_to_f32(rv.x);
-                                v[4 * i + 2] += bf16lo_to_f32(rv.y); v[4 * i + 3] += bf16hi_to_f32(rv.y);
-                            }
-                        }
-                        if (p.relu) {
-#pragma unroll
-                            for (int i = 0; i < 4 * NT; ++i) v[i] = fmaxf(v[i], 0.f);
-                        }
-                        uint2* yp = reinterpret_cast<uint2*>(p.y + o);
-#pragma unroll
-                        for (int i = 0; i < NT; ++i) yp[i] = make_uint2(pack_bf16x2(v[4 * i], v[4 * i + 1]), pack_bf16x2(v[4 * i + 2], v[4 * i + 3]));
                     }
+                    if (p.bias) {
+#pragma unroll
+                        for (int i = 0; i < 4 * NT; ++i) v[i] += p.bias[c0 + i];
+                    }
+                    const int nd = (p.oshift && od == 0) ? 2 : 1, nh = (p.oshift && oh == 0) ? 2 : 1, nw = (p.oshift && ow == 0) ? 2 : 1;
+                    for (int zd = 0; zd < nd; ++zd)
+                        for (int zh = 0; zh < nh; ++zh)
+                            for (int zw = 0; zw < nw; ++zw) {
+                                const int dd_ = zd ? 0 : od + p.oshift, dh_ = zh ? 0 : oh + p.oshift, dw_ = zw ? 0 : ow + p.oshift;
+                                if (dd_ >= p.OD || dh_ >= p.OH || dw_ >= p.OW) continue;
+                                const size_t o = ((((size_t)b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_) * p.Cout + c0;
+                                float wv[4 * NT];
+#pragma unroll
+                                for (int i = 0; i < 4 * NT; ++i) wv[i] = v[i];
+                                if (p.res) {
+                                    const uint2* rp = reinterpret_cast<const uint2*>(p.res + o);
+#pragma unroll
+                                    for (int i = 0; i < NT; ++i) {
+                                        const uint2 rv = rp[i];
+                                        wv[4 * i] += bf16lo_to_f32(rv.x); wv[4 * i + 1] += bf16hi_to_f32(rv.x);
+                                        wv[4 * i + 2] += bf16lo_to_f32(rv.y); wv[4 * i + 3] += bf16hi_to_f32(rv.y);
+                                    }
+                                }
+                                if (p.relu) {
+#pragma unroll
+                                    for (int i = 0; i < 4 * NT; ++i) wv[i] = fmaxf(wv[i], 0.f);
+                                }
+                                uint2* yp = reinterpret_cast<uint2*>(p.y + o);
+#pragma unroll
+                                for (int i = 0; i < NT; ++i)
+                                    yp[i] = make_uint2(pack_bf16x2(wv[4 * i], wv[4 * i + 1]), pack_bf16x2(wv[4 * i + 2], wv[4 * i + 3]));
+                            }
+                }
+            }
         }
-        advance(cur);
+        if (ut + 1 == upt) advance(cur);
     }
+#endif
 }
 
-template <int NT, int TPS, bool PIPE, bool REG27>
+// ---- GroupNorm folding -------------------------------------------------------------------------------------------
+// w32: [nslab][ntaps][CoutPad][32] f32 (packed, row-permuted).  Per sample b:
+//   wout[b][slab][tap][row][k] = bf16(w32[slab][tap][row][k] * scale[b][slab*32 + k])
+//   T[b][tap][row]             = sum_{slab,k} w32[slab][tap][row][k] * shift[b][slab*32 + k]
+__global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict__ w32, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, bf16_t* __restrict__ wout, float* __restrict__ T,
+                                                         int nslab, int ntaps, int CoutPad, int Cin) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;            // tap * CoutPad + row
+    if (i >= ntaps * CoutPad) return;
+    float acc = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const size_t o = ((size_t)sl * ntaps * CoutPad + i) * 32;
+        bf16_t* wo = wout + (size_t)b * nslab * ntaps * CoutPad * 32 + o;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const int c = sl * 32 + k;
+            const float w = w32[o + k];
+            const float s = c < Cin ? scale[(size_t)b * Cin + c] : 0.f, t = c < Cin ? shift[(size_t)b * Cin + c] : 0.f;
+            wo[k] = f32_to_bf16(w * s);
+            acc = fmaf(w, t, acc);
+        }
+    }
+    T[(size_t)b * ntaps * CoutPad + i] = acc;
+}
+
+// bias_tab[b][cls][channel] = sum over the taps that stay inside the volume for boundary class cls of T[b][tap][row(channel)]
+__global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict__ T, float* __restrict__ tab, const int8_t* __restrict__ taps,
+                                                        int ntaps, int CoutPad, int NT) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;            // cls * CoutPad + packed row
+    if (i >= 64 * CoutPad) return;
+    const int cls = i / CoutPad, rho = i - cls * CoutPad;
+    float acc = 0.f;
+    for (int t = 0; t < ntaps; ++t) {
+        const int dd = taps[3 * t], dh = taps[3 * t + 1], dw = taps[3 * t + 2];
+        const bool outside = (dd < 0 && (cls & 1)) || (dd > 0 && (cls & 2)) || (dh < 0 && (cls & 4)) || (dh > 0 && (cls & 8)) ||
+                             (dw < 0 && (cls & 16)) || (dw > 0 && (cls & 32));
+        if (!outside) acc += T[((size_t)b * ntaps + t) * CoutPad + rho];
+    }
+    // packed row -> channel (same permutation as the weight packing)
+    const int g = rho / (NT * 16), r = rho - g * (NT * 16);
+    const int ch = g * NT * 16 + ((r >> 2) & 3) * 4 * NT + (r >> 4) * 4 + (r & 3);
+    tab[((size_t)b * 64 + cls) * CoutPad + ch] = acc;
+}
+
+template <int NT, int TPS, bool REG27>
 int conv_launch(const ConvParams& p, hipStream_t st) {
-    const size_t lds = A_BYTES + 2 * (size_t)TPS * NT * 16 * VSTRIDE;
+    constexpr int W_PIECES = (TPS * NT * 16 + 15) / 16;
+    const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024;
     const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw;
     if (tiles > 0x7fffffff) return GFE_ERR_SHAPE;
-    const int groups = p.CoutPad / (NT * 16);
-    // persistent blocks: ~2 resident blocks per CU x 256 CUs, each walking a contiguous tile range
+    // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
-    q.tiles_per_block = (int)ceil_div(tiles * groups, 512);
-    const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block), (unsigned)groups);
+    q.tiles_per_block = (int)ceil_div(tiles, 256);
+    const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, PIPE, REG27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, PIPE, REG27>), grid, dim3(256), lds, st, q);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27>), grid, dim3(NTHREADS), lds, st, q);
     return gfe_launch_status();
 }
 
@@ -419,28 +397,44 @@ extern "C" {
 int gfe_conv3d_cout_pad(int64_t Cout) {
     if (Cout <= 16) return 16;
     if (Cout <= 32) return 32;
-    if (Cout <= 64) return 64;
-    return (int)(ceil_div(Cout, 128) * 128);
+    return (int)(ceil_div(Cout, 64) * 64);
 }
 
-int gfe_conv3d_igemm(const void* x, const void* w_packed, const float* gn_scale, const float* gn_shift, const float* bias,
+int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, const float* gn_shift, void* w_out, float* T_ws,
+                              float* bias_tab, const int8_t* tap_offsets_dev, int64_t B, int64_t Cin, int64_t Cout, int ntaps, void* stream) {
+    GFE_REQUIRE(w_packed_f32 && gn_scale && gn_shift && w_out && T_ws && bias_tab && tap_offsets_dev, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
+    const int cp = gfe_conv3d_cout_pad(Cout), nslab = (int)ceil_div(Cin, 32);
+    const int NT = (cp < 64 ? cp : 64) / 16;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)ntaps * cp, 256), (unsigned)B), dim3(256), 0, st,
+                       w_packed_f32, gn_scale, gn_shift, (bf16_t*)w_out, T_ws, nslab, ntaps, cp, (int)Cin);
+    hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)64 * cp, 256), (unsigned)B), dim3(256), 0, st,
+                       T_ws, bias_tab, tap_offsets_dev, ntaps, cp, NT);
+    return gfe_launch_status();
+}
+
+int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias, const float* bias_tab,
                      const void* res, void* y,
                      int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                      int64_t OD, int64_t OH, int64_t OW,
                      int ntaps, const int8_t* tap_offsets /* host, ntaps x 3 (dd,dh,dw) */,
                      int ostride, int op_d, int op_h, int op_w, int oshift, int relu, void* stream) {
     GFE_REQUIRE(x && w_packed && y && tap_offsets, GFE_ERR_NULL);
-    GFE_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
     GFE_REQUIRE(ostride == 1 || ostride == 2, GFE_ERR_SHAPE);
+    GFE_REQUIRE(D * H * W * Cin * 2 < 0x7fffffffLL, GFE_ERR_SHAPE);             // one sample addressable by a 32-bit buffer offset
     ConvParams p;
-    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.bias = bias;
-    p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = bias; p.bias_tab = bias_tab;
+    p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = w_batch_stride;
     p.B = (int)B; p.D = (int)D; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.CoutPad = gfe_conv3d_cout_pad(Cout);
     p.OD = (int)OD; p.OH = (int)OH; p.OW = (int)OW;
     p.ntaps = ntaps; p.nslab = (int)ceil_div(Cin, 32);
+    const int NT = (p.CoutPad < 64 ? p.CoutPad : 64) / 16;
+    p.ngroups = p.CoutPad / (NT * 16);
+    GFE_REQUIRE((int64_t)p.nslab * ntaps * p.CoutPad * 64 < 0x7fffffffLL, GFE_ERR_SHAPE);
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     for (int t = 0; t < ntaps; ++t) {
         const int8_t* o = tap_offsets + 3 * t;
@@ -452,7 +446,6 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, const float* gn_scale,
     }
     p.lo_d = lo[0]; p.lo_h = lo[1]; p.lo_w = lo[2];
     p.LD = TD + hi[0] - lo[0]; p.LH = TH + hi[1] - lo[1]; p.LW = TW + hi[2] - lo[2];
-    p.LHW = p.LH * p.LW; p.NV = p.LD * p.LHW;
     for (int t = 0; t < ntaps; ++t) {
         const int8_t* o = tap_offsets + 3 * t;
         p.toff[t] = (((o[0] - lo[0]) * PH + (o[1] - lo[1])) * PW + (o[2] - lo[2])) * VSTRIDE;
@@ -470,10 +463,9 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, const float* gn_scale,
     bool reg27 = ntaps == 27 && ostride == 1;
     for (int t = 0; t < ntaps && reg27; ++t)
         reg27 = tap_offsets[3 * t] == t / 9 - 1 && tap_offsets[3 * t + 1] == (t / 3) % 3 - 1 && tap_offsets[3 * t + 2] == t % 3 - 1;
-    if (p.CoutPad == 16) return conv_launch<1, 3, true, false>(p, st);
-    if (p.CoutPad == 32) return conv_launch<2, 3, true, false>(p, st);
-    if (p.CoutPad == 64) return reg27 ? conv_launch<4, 3, true, true>(p, st) : conv_launch<4, 3, true, false>(p, st);
-    return conv_launch<8, 1, false, false>(p, st);
+    if (NT == 1) return conv_launch<1, 3, false>(p, st);
+    if (NT == 2) return conv_launch<2, 3, false>(p, st);
+    return reg27 ? conv_launch<4, 3, true>(p, st) : conv_launch<4, 3, false>(p, st);
 }
 
 }  // extern "C"

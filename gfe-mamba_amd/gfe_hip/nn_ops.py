@@ -36,27 +36,50 @@ def _row_perm(cp):
     """Packed weight row -> output channel.  Inside a group of NT 16-row MFMA tiles, row ct*16 + 4*lq + r carries channel
     lq*4*NT + 4*ct + r, so that an MFMA lane (which owns rows 4*lq..4*lq+3 of every tile) ends up with 4*NT consecutive
     output channels of its voxel and the epilogue stores contiguous 8*NT-byte pieces."""
-    nt = min(cp, 128) // 16
+    nt = min(cp, 64) // 16
     rho = torch.arange(cp)
     g, r = rho // (nt * 16), rho % (nt * 16)
     return g * nt * 16 + ((r >> 2) & 3) * 4 * nt + (r >> 4) * 4 + (r & 3)
 
 
-def _pack(w_tco, cin):
-    """w_tco: (ntaps, Cout, Cin) f32 -> [nslab][ntaps][CoutPad][32] bf16, zero padded, rows permuted (see _row_perm)."""
+def _pack(w_tco, cin, dtype=BF16):
+    """w_tco: (ntaps, Cout, Cin) f32 -> [nslab][ntaps][CoutPad][32] bf16 (or f32), zero padded, rows permuted (see _row_perm)."""
     ntaps, cout, _ = w_tco.shape
     nslab = (cin + 31) // 32
     cp = cout_pad(cout)
     buf = torch.zeros((ntaps, cp, nslab * 32), dtype=torch.float32, device=w_tco.device)
     buf[:, :cout, :cin] = w_tco
     buf = buf[:, _row_perm(cp).to(buf.device)]
-    return buf.view(ntaps, cp, nslab, 32).permute(2, 0, 1, 3).contiguous().to(BF16)
+    return buf.view(ntaps, cp, nslab, 32).permute(2, 0, 1, 3).contiguous().to(dtype)
 
 
-def pack_conv3(weight):
+def pack_conv3(weight, dtype=BF16):
     """nn.Conv3d weight (Cout, Cin, 3, 3, 3) -> packed, tap order = CONV3_TAPS (cross-correlation: offset = k - 1)."""
     cout, cin = weight.shape[:2]
-    return _pack(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(27, cout, cin), cin)
+    return _pack(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(27, cout, cin), cin, dtype)
+
+
+_TAPS_DEV = {}
+
+
+def taps_on_device(taps, device):
+    key = (tuple(taps), str(device))
+    if key not in _TAPS_DEV:
+        _TAPS_DEV[key] = torch.tensor(taps, dtype=torch.int8, device=device).contiguous()
+    return _TAPS_DEV[key]
+
+
+def fold_groupnorm(w_packed_f32, scale, shift, taps, cin, cout):
+    """GroupNorm affine (scale, shift: (B, Cin) f32) folded into the conv: per-sample bf16 weights + boundary-class bias table."""
+    B = scale.shape[0]
+    cp = cout_pad(cout)
+    dev = scale.device
+    wout = torch.empty((B,) + tuple(w_packed_f32.shape), dtype=BF16, device=dev)
+    T = torch.empty((B, len(taps), cp), dtype=torch.float32, device=dev)
+    tab = torch.empty((B, 64, cp), dtype=torch.float32, device=dev)
+    call("gfe_conv3d_fold_groupnorm", ptr(w_packed_f32), ptr(scale), ptr(shift), ptr(wout), ptr(T), ptr(tab),
+         ptr(taps_on_device(taps, dev)), B, cin, cout, len(taps), stream())
+    return wout, tab
 
 
 def pack_conv1(weight):
@@ -84,8 +107,9 @@ def pack_convT(weight):
 
 
 # ---- generator ops --------------------------------------------------------------------------------------------------
-def conv_igemm(x, w_packed, taps, cout, gn=None, bias=None, res=None, relu=False, out=None, transposed=None):
-    """x: (B, D, H, W, Cin) bf16.  transposed: None, or (parity tuple, out tensor (B, 2D, 2H, 2W, Cout)) for one ConvT class."""
+def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu=False, out=None, transposed=None):
+    """x: (B, D, H, W, Cin) bf16.  w_packed: one weight set, or (B, ...) per-sample sets from fold_groupnorm (with bias_tab).
+    transposed: None, or (parity tuple, out tensor (B, 2D, 2H, 2W, Cout)) for one ConvT class."""
     B, D, H, W, cin = x.shape
     assert x.dtype == BF16 and x.is_contiguous()
     tarr, tptr = _i8(taps)
@@ -100,8 +124,8 @@ def conv_igemm(x, w_packed, taps, cout, gn=None, bias=None, res=None, relu=False
         ostride = 2
         oshift = OD - (2 * D - 1)
         assert oshift in (0, 1) and OH == 2 * H - 1 + oshift and OW == 2 * W - 1 + oshift, "unsupported upsampling size"
-    gs, gt = (gn if gn is not None else (None, None))
-    call("gfe_conv3d_igemm", ptr(x), ptr(w_packed), ptr(gs), ptr(gt), ptr(bias), ptr(res), ptr(out),
+    wstride = w_packed.stride(0) if w_packed.dim() == 5 else 0
+    call("gfe_conv3d_igemm", ptr(x), ptr(w_packed), wstride, ptr(bias), ptr(bias_tab), ptr(res), ptr(out),
          B, D, H, W, cin, cout, OD, OH, OW, len(taps), tptr, ostride, par[0], par[1], par[2], oshift, int(relu), stream())
     return out
 

@@ -53,10 +53,12 @@ class SingleConv(nn.Sequential):
     def forward(self, x, residual=None):
         """x: (B, D, H, W, Cin) bf16; optional residual is added before the (forced) ReLU: ResNetBlock tail."""
         gn, conv = self.groupnorm, self.conv
-        w, g, b = self._pack.get([conv.weight, gn.weight, gn.bias],
-                                 lambda: (K.pack_conv3(conv.weight), _f32(gn.weight), _f32(gn.bias)))
-        ss = K.groupnorm_scale_shift(x, g, b, gn.num_groups, gn.eps)
-        return K.conv_igemm(x, w, K.CONV3_TAPS, conv.out_channels, gn=ss, res=residual, relu=self.relu or residual is not None)
+        w32, g, b = self._pack.get([conv.weight, gn.weight, gn.bias],
+                                   lambda: (K.pack_conv3(conv.weight, torch.float32), _f32(gn.weight), _f32(gn.bias)))
+        scale, shift = K.groupnorm_scale_shift(x, g, b, gn.num_groups, gn.eps)
+        # GroupNorm is folded into per-sample weights + a boundary-class bias table: the conv itself streams raw activations
+        wb, tab = K.fold_groupnorm(w32, scale, shift, K.CONV3_TAPS, conv.in_channels, conv.out_channels)
+        return K.conv_igemm(x, wb, K.CONV3_TAPS, conv.out_channels, bias_tab=tab, res=residual, relu=self.relu or residual is not None)
 
 
 class ResNetBlock(nn.Module):

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 5
+#define GFE_ABI_VERSION 6
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -84,29 +84,40 @@ int gfe_pscan_bwd(const void* A, const void* H, const void* gH, void* gA, void* 
  * Group C -- frozen generator (pytorch3dunet/unet3d), channels-last (NDHWC) bf16 activations
  * ------------------------------------------------------------------------------------------- */
 
-/* Padded output-channel count of the packed weight layout used by gfe_conv3d_igemm. Host-only. */
+/* Padded output-channel count of the packed weight layout used by gfe_conv3d_igemm (16, 32, or a multiple of 64). Host-only. */
 int gfe_conv3d_cout_pad(int64_t Cout);
 
-/* Implicit-GEMM convolution described by a tap list: y[v] = sum_t W[t] . x[v + off(t)].
+/* Implicit-GEMM convolution described by a tap list: y[v] = sum_t W[t] . x[v + off(t)]  (+ bias_tab | bias, + res, ReLU).
  * Replaces, depending on the tap list / flags:
- *   SingleConv 'gcr'/'gc' = GroupNorm -> Conv3d k3 p1 no-bias [-> ReLU]  (buildingblocks.py:38-67): 27 taps, gn_scale/shift
+ *   SingleConv 'gcr'/'gc' = GroupNorm -> Conv3d k3 p1 no-bias [-> ReLU]  (buildingblocks.py:38-67): 27 taps, per-sample
+ *     weights + bias_tab produced by gfe_conv3d_fold_groupnorm
  *   ResNetBlock.conv1 = Conv3d k1 + bias (buildingblocks.py:191-196): 1 tap, bias
  *   ResNetBlock tail `out += residual; ReLU` (buildingblocks.py:226-227): res + relu
  *   TransposeConvUpsampling = ConvTranspose3d k3 s2 p1 no-bias -> F.interpolate(nearest, 2n-1 -> 2n) -> `encoder_features + x`
  *   (buildingblocks.py:396-400, 523-537): 8 calls, one per output parity class (ostride 2, op_* parity, oshift 1, res = skip)
  *   x: (B, D, H, W, Cin) bf16.  y, res: (B, OD, OH, OW, Cout) bf16.  Cin % 8 == 0, Cout % 8 == 0.
-  *   w_packed: [ceil(Cin/32)][ntaps][gfe_conv3d_cout_pad(Cout)][32] bf16, zero padded (tap order = tap_offsets order); inside each
- *   group of NT = min(CoutPad,128)/16 tiles, packed row ct*16 + 4*q + r holds output channel q*4*NT + 4*ct + r (gfe_hip/nn_ops.py:_row_perm).
- *   gn_scale, gn_shift: (B, Cin) f32 from gfe_groupnorm_scale_shift, or both NULL.  bias: (Cout) f32 or NULL.
+ *   w_packed: [ceil(Cin/32)][ntaps][CoutPad][32] bf16, zero padded (tap order = tap_offsets order); inside each group of
+ *     NT = min(CoutPad,64)/16 MFMA tiles, packed row ct*16 + 4*q + r holds output channel q*4*NT + 4*ct + r
+ *     (gfe_hip/nn_ops.py:_row_perm).  w_batch_stride: elements between per-sample weight sets, 0 = one set for all samples.
+ *   bias: (Cout) f32 or NULL.  bias_tab: (B, 64, CoutPad) f32 or NULL, indexed by the voxel's boundary class
+ *     (d==0) | (d==D-1)<<1 | (h==0)<<2 | (h==H-1)<<3 | (w==0)<<4 | (w==W-1)<<5.
  *   tap_offsets: HOST pointer, ntaps x 3 int8 (dd, dh, dw) each in [-1, 1].
  *   ostride 1: OD,OH,OW == D,H,W.  ostride 2: output index = 2*i + op_*, shifted by oshift (0/1) with index 0 duplicated
  *   (nearest resize 2n-1 -> 2n: dst j <- src max(j-1, 0)); OD == 2*D - 1 + oshift. */
-int gfe_conv3d_igemm(const void* x, const void* w_packed, const float* gn_scale, const float* gn_shift, const float* bias,
+int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias, const float* bias_tab,
                      const void* res, void* y,
                      int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                      int64_t OD, int64_t OH, int64_t OW,
                      int ntaps, const int8_t* tap_offsets,
                      int ostride, int op_d, int op_h, int op_w, int oshift, int relu, void* stream);
+
+/* Folds GroupNorm(x) = scale[b,c]*x + shift[b,c] (from gfe_groupnorm_scale_shift) into the convolution that consumes it
+ * (create_conv order 'g' before 'c', buildingblocks.py:55-67; zero padding is applied AFTER the norm):
+ *   w_out[b] = bf16(w_packed_f32 * scale[b, cin])                              (B sets in the gfe_conv3d_igemm layout)
+ *   bias_tab[b][class][co] = sum over taps inside the volume for that boundary class of sum_ci W[t][co][ci]*shift[b,ci]
+ * w_packed_f32: the packed layout in f32.  T_ws: (B, ntaps, CoutPad) f32 workspace.  tap_offsets_dev: DEVICE int8 ntaps x 3. */
+int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, const float* gn_shift, void* w_out, float* T_ws,
+                              float* bias_tab, const int8_t* tap_offsets_dev, int64_t B, int64_t Cin, int64_t Cout, int ntaps, void* stream);
 
 /* GroupNorm statistics -> per-(sample, channel) affine: scale = rstd*gamma, shift = beta - mean*rstd*gamma
  * (nn.GroupNorm(G, C), eps, biased variance; buildingblocks.py:55-67).  x: (B, S, C) bf16 channels-last, S = D*H*W.

@@ -66,7 +66,8 @@ def test_groupnorm_conv3_relu_residual(C, shape):
     mean, var = xf.mean(-1), xf.var(-1, unbiased=False)
     sc_ref = (1 / torch.sqrt(var + 1e-5)).repeat_interleave(C // 8, 1) * gamma
     assert rel_err(ss[0], sc_ref) < 1e-4
-    y = K.conv_igemm(xd, K.pack_conv3(w.to(DEV)), K.CONV3_TAPS, C, gn=ss, res=cl(res), relu=True)
+    wb, tab = K.fold_groupnorm(K.pack_conv3(w.to(DEV), torch.float32), ss[0], ss[1], K.CONV3_TAPS, C, C)
+    y = K.conv_igemm(xd, wb, K.CONV3_TAPS, C, bias_tab=tab, res=cl(res), relu=True)
     assert rel_err(ncdhw(y), ref) < TOL
 
 

@@ -15,14 +15,15 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, D, D, D, C, generator=g).to(torch.bfloat16).cuda()
-w = K.pack_conv3((torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5).cuda())
+w32 = K.pack_conv3((torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5).cuda(), torch.float32)
 ss = K.groupnorm_scale_shift(x, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 8)
-y = K.conv_igemm(x, w, K.CONV3_TAPS, C, gn=ss, relu=True)
+w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, C, C)
+y = K.conv_igemm(x, w, K.CONV3_TAPS, C, bias_tab=tab, relu=True)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters):
-    K.conv_igemm(x, w, K.CONV3_TAPS, C, gn=ss, relu=True, out=y)
+    K.conv_igemm(x, w, K.CONV3_TAPS, C, bias_tab=tab, relu=True, out=y)
 e1.record()
 e1.synchronize()
 ms = e0.elapsed_time(e1) / iters
