@@ -42,6 +42,15 @@ typedef __attribute__((address_space(3))) void* lds_void_t;
 
 namespace {
 
+// Buffer descriptor from provably wave-uniform inputs: without the readfirstlanes hipcc cannot prove uniformity and wraps
+// EVERY buffer_load..lds in a waterfall loop (readfirstlane x4, v_cmp_eq_u64, s_and_saveexec, ..., s_cbranch_execnz).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 constexpr int TD = 8, TH = 8, TW = 8;          // output tile (class-grid voxels)
 constexpr int NWAVES = TD;                     // one wave per output d-plane
 constexpr int NTHREADS = NWAVES * 64;
@@ -144,9 +153,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 
     // ---- DMA issue
     auto a_dma = [&](const TilePos& q, int slab, int buf) {
-        const bf16_t* base = p.x + (size_t)q.b * sample_elems;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)sample_bytes, 0x00020000);
-        const int d0 = q.td * TD + p.lo_d, h0 = q.th * TH + p.lo_h, w0 = q.tw * TW + p.lo_w;
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(p.x + (size_t)rfl(q.b) * sample_elems, sample_bytes);
+        const int d0 = rfl(q.td) * TD + p.lo_d, h0 = rfl(q.th) * TH + p.lo_h, w0 = rfl(q.tw) * TW + p.lo_w;
+        const int lds_off = rfl(buf) * A_BYTES;
+        slab = rfl(slab);
 #pragma unroll
         for (int j = 0; j < A_PER_WAVE; ++j) {
             const int k = dw + DMA_WAVES * j;
@@ -157,24 +167,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 const bool ok = ((ac >> 20) & 1) && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
                                 (unsigned)gw < (unsigned)p.W && slab * 32 + (cb >> 1) < p.Cin;
                 const unsigned voff = ok ? (unsigned)((((gd * p.H + gh) * p.W + gw) * p.Cin + slab * 32) * 2 + cb) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + buf * A_BYTES + k * 1024), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + lds_off + k * 1024), 16, voff, 0, 0, 0);
             }
         }
     };
     auto w_dma = [&](int b, int group, int slab, int stage, int buf) {
-        const bf16_t* base = p.w + (size_t)b * p.w_batch_stride;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)wset_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(p.w + (size_t)rfl(b) * p.w_batch_stride, wset_bytes);
         // taps beyond ntaps in the last stage read past the slab (still inside the set, or OOB -> zeros): never multiplied
-        const unsigned soff = (unsigned)((((size_t)slab * p.ntaps + stage * TPS) * p.CoutPad + group * WROWS_TAP) * 64);
+        const unsigned soff = (unsigned)rfl((int)((((size_t)slab * p.ntaps + stage * TPS) * p.CoutPad + group * WROWS_TAP) * 64));
+        const int lds_off = rfl(buf) * (W_PIECES * 1024);
 #pragma unroll
         for (int j = 0; j < W_PER_WAVE; ++j) {
             const int k = dw + DMA_WAVES * j;
             if (k < W_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sW + buf * (W_PIECES * 1024) + k * 1024), 16, wvoff[j], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sW + lds_off + k * 1024), 16, wvoff[j], soff, 0, 0);
         }
     };
 
     f32x4 acc[4][NT];
+    // GroupNorm shift term of interior voxels (boundary class 0): kept in registers per (sample, group) so the epilogue of
+    // interior tiles has no load on its critical path; boundary voxels read their class row from the table
+    float bias0[4 * NT];
+    int bias0_key = -1;
 
     if (a_wave) a_dma(cur, 0, 0); else w_dma(cur.b, 0, 0, 0, 0);
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
@@ -192,6 +206,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             for (int xt = 0; xt < 4; ++xt)
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct) acc[xt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias_tab && bias0_key != cur.b * p.ngroups + group) {       // wave-uniform; lands during the unit's stages
+                bias0_key = cur.b * p.ngroups + group;
+                const int c0b = group * WROWS_TAP + lq * 4 * NT;
+                const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + (size_t)cur.b * 64 * p.CoutPad + (c0b < p.CoutPad ? c0b : 0));
+#pragma unroll
+                for (int i = 0; i < NT; ++i) { const float4 t = bt[i]; bias0[4 * i] = t.x; bias0[4 * i + 1] = t.y; bias0[4 * i + 2] = t.z; bias0[4 * i + 3] = t.w; }
+            }
         }
 
         for (int s = 0; s < nstage; ++s, ++gstage) {
@@ -281,11 +302,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         // boundary class: which neighbours of this voxel fall outside the volume
                         const int cls = (cd == 0) | ((cd == p.D - 1) << 1) | ((ch_ == 0) << 2) | ((ch_ == p.H - 1) << 3) |
                                         ((cw_ == 0) << 4) | ((cw_ == p.W - 1) << 5);
-                        const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + ((size_t)b * 64 + cls) * p.CoutPad + c0);
+                        if (cls == 0) {
 #pragma unroll
-                        for (int i = 0; i < NT; ++i) {
-                            const float4 t = bt[i];
-                            v[4 * i] += t.x; v[4 * i + 1] += t.y; v[4 * i + 2] += t.z; v[4 * i + 3] += t.w;
+                            for (int i = 0; i < 4 * NT; ++i) v[i] += bias0[i];
+                        } else {
+                            const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + ((size_t)b * 64 + cls) * p.CoutPad + c0);
+#pragma unroll
+                            for (int i = 0; i < NT; ++i) {
+                                const float4 t = bt[i];
+                                v[4 * i] += t.x; v[4 * i + 1] += t.y; v[4 * i + 2] += t.z; v[4 * i + 3] += t.w;
+                            }
                         }
                     }
                     if (p.bias) {
