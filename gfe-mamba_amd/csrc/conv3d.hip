@@ -245,15 +245,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
-                    bf16x8 xf[4];
+                    // all 8 fragments of the tap first (one LDS wait per 16 MFMAs), then the MFMA cluster at raised priority
+                    bf16x8 xf[4], wf[NT];
 #pragma unroll
                     for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(aT + ax[xt] + tl * VSTRIDE);
 #pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) {
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
+                    for (int ct = 0; ct < NT; ++ct) wf[ct] = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                        for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf, xf[xt], acc[xt][ct]);
-                    }
+                    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                        for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[ct], xf[xt], acc[xt][ct]);
+                    __builtin_amdgcn_s_setprio(0);
                 }
             } else {
 #pragma unroll
