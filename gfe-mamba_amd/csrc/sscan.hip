@@ -70,8 +70,8 @@ struct RowTile {
 // (3*TT 128-byte wave loads outstanding) while the current one is consumed: with 2-byte lanes that is what it takes to keep
 // ~40 KB per CU in flight (HBM latency x bandwidth); a 4-step unroll left the kernel latency-bound at 8 % of HBM.
 template <typename T, int N, bool STATE_ONLY>
-__global__ __launch_bounds__(256) void sscan_fwd_kernel(const SScanParams p) {
-    constexpr int TT = 16;
+__global__ __launch_bounds__(256, STATE_ONLY ? 4 : 3) void sscan_fwd_kernel(const SScanParams p) {
+    constexpr int TT = 8;       // the kernel is latency-bound: 8-step tiles keep it under 128 VGPRs (4+ waves per SIMD)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (e >= p.ED) return;
@@ -224,8 +224,8 @@ struct SScanBwdParams {
 
 // K1': local adjoint of each chunk with zero incoming carry: q <- a_t * (C_t g_t + q), t descending (16-step register tiles).
 template <typename T, int N>
-__global__ __launch_bounds__(256) void sscan_bwd_state_kernel(const SScanBwdParams p) {
-    constexpr int TT = 16;
+__global__ __launch_bounds__(256, 4) void sscan_bwd_state_kernel(const SScanBwdParams p) {
+    constexpr int TT = 8;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (e >= p.ED) return;
@@ -543,7 +543,7 @@ static int pick_chunk(int64_t B, int64_t L, int64_t ED, int req) {
 template <typename T, int N>
 int sscan_fwd_launch(const SScanParams& p, hipStream_t st) {
     const dim3 blk(256), grid((unsigned)ceil_div(p.ED, 256), p.nchunks, p.B);
-    const size_t lds = 4 * 4 * (16 * N / 4) * sizeof(float4);        // 4 waves x (B,C) x 2 buffers x TT*N/4 float4
+    const size_t lds = 4 * 4 * (8 * N / 4) * sizeof(float4);         // 4 waves x (B,C) x 2 buffers x TT*N/4 float4 (TT = 8)
     if (p.nchunks > 1) {
         hipLaunchKernelGGL((sscan_fwd_kernel<T, N, true>), grid, blk, lds, st, p);
         hipLaunchKernelGGL((sscan_carry_kernel<N, false>), dim3((unsigned)ceil_div((int64_t)N * p.ED, 256), p.B), blk, 0, st,
@@ -558,7 +558,7 @@ int sscan_bwd_launch(const SScanBwdParams& p, hipStream_t st) {
     constexpr int S = 4;
     if (p.nchunks > 1) {
         const dim3 blk(256), grid((unsigned)ceil_div(p.ED, 256), p.nchunks, p.B);
-        hipLaunchKernelGGL((sscan_bwd_state_kernel<T, N>), grid, blk, 4 * 2 * (16 * N / 4) * sizeof(float4), st, p);
+        hipLaunchKernelGGL((sscan_bwd_state_kernel<T, N>), grid, blk, 4 * 2 * (8 * N / 4) * sizeof(float4), st, p);
         hipLaunchKernelGGL((sscan_carry_kernel<N, true>), dim3((unsigned)ceil_div((int64_t)N * p.ED, 256), p.B), blk, 0, st,
                            p.qstate, p.sdelta, p.A, p.ED, p.nchunks);
     }
