@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     const unsigned wset_bytes = (unsigned)((size_t)p.nslab * p.ntaps * p.CoutPad * 64);     // one sample's weights
 
     // ---- DMA issue
-    auto a_dma = [&](const TilePos& q, int slab, int buf) {
+    auto a_dma = [&](const TilePos& q, int slab, int buf, int j0, int j1) {
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(p.x + (size_t)rfl(q.b) * sample_elems, sample_bytes);
         const int d0 = rfl(q.td) * TD + p.lo_d, h0 = rfl(q.th) * TH + p.lo_h, w0 = rfl(q.tw) * TW + p.lo_w;
         const int lds_off = rfl(buf) * A_BYTES;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #pragma unroll
         for (int j = 0; j < A_PER_WAVE; ++j) {
             const int k = dw + DMA_WAVES * j;
-            {
+            if (j >= j0 && j < j1) {                                         // wave-uniform
                 const int ac = acoord[j];
                 const int gd = d0 + (ac & 15), gh = h0 + ((ac >> 4) & 15), gw = w0 + ((ac >> 8) & 15);
                 const int cb = (ac >> 12) & 0xff;                            // chunk byte offset inside the slab
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     float bias0[4 * NT];
     int bias0_key = -1;
 
-    if (a_wave) a_dma(cur, 0, 0); else w_dma(cur.b, 0, 0, 0, 0);
+    if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur.b, 0, 0, 0, 0);
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
 
     for (int u = 0; u < nunits; ++u) {
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             }
 #endif
 #if !defined(GFE_EXP_NOA)      // timing experiment only: the activation tile is never restaged
-            if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1);
+            // issued as one burst in stage 0 (spreading the 16 pieces over the unit's stages measured 6 % slower: every stage pays)
+            if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE);
 #endif
 
             const uint8_t* wb = sW + (gstage & 1) * (W_PIECES * 1024) + wbase;
@@ -369,23 +370,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 __global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict__ w32, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, bf16_t* __restrict__ wout, float* __restrict__ T,
                                                          int nslab, int ntaps, int CoutPad, int Cin) {
+    // one thread per 8 consecutive k of one (slab, tap, row): coalesced 32-B reads / 16-B writes; T accumulated with atomics
     const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;            // tap * CoutPad + row
-    if (i >= ntaps * CoutPad) return;
-    float acc = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) {
-        const size_t o = ((size_t)sl * ntaps * CoutPad + i) * 32;
-        bf16_t* wo = wout + (size_t)b * nslab * ntaps * CoutPad * 32 + o;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const int c = sl * 32 + k;
-            const float w = w32[o + k];
-            const float s = c < Cin ? scale[(size_t)b * Cin + c] : 0.f, t = c < Cin ? shift[(size_t)b * Cin + c] : 0.f;
-            wo[k] = f32_to_bf16(w * s);
-            acc = fmaf(w, t, acc);
-        }
+    const int64_t nrows = (int64_t)nslab * ntaps * CoutPad;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (slab*ntaps*CoutPad + tap*CoutPad + row) * 4 + chunk
+    if (i >= nrows * 4) return;
+    const int64_t rowi = i >> 2;
+    const int chunk = (int)(i & 3);
+    const int sl = (int)(rowi / ((int64_t)ntaps * CoutPad));
+    const int64_t tr = rowi - (int64_t)sl * ntaps * CoutPad;           // tap*CoutPad + row
+    const float4 w0 = *reinterpret_cast<const float4*>(w32 + rowi * 32 + chunk * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w32 + rowi * 32 + chunk * 8 + 4);
+    const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float o[8], acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = sl * 32 + chunk * 8 + k;
+        const float sc = c < Cin ? scale[(size_t)b * Cin + c] : 0.f, t = c < Cin ? shift[(size_t)b * Cin + c] : 0.f;
+        o[k] = w[k] * sc;
+        acc = fmaf(w[k], t, acc);
     }
-    T[(size_t)b * ntaps * CoutPad + i] = acc;
+    *reinterpret_cast<uint4*>(wout + ((size_t)b * nrows + rowi) * 32 + chunk * 8) =
+        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    acc += __shfl_xor(acc, 1, 64);                                     // the 4 chunks of a row sit in adjacent lanes
+    acc += __shfl_xor(acc, 2, 64);
+    if (chunk == 0) atomicAdd(T + (size_t)b * ntaps * CoutPad + tr, acc);
 }
 
 // bias_tab[b][cls][channel] = sum over the taps that stay inside the volume for boundary class cls of T[b][tap][row(channel)]
@@ -441,7 +450,8 @@ int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, 
     const int cp = gfe_conv3d_cout_pad(Cout), nslab = (int)ceil_div(Cin, 32);
     const int NT = (cp < 64 ? cp : 64) / 16;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)ntaps * cp, 256), (unsigned)B), dim3(256), 0, st,
+    (void)hipMemsetAsync(T_ws, 0, (size_t)B * ntaps * cp * sizeof(float), st);
+    hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)nslab * ntaps * cp * 4, 256), (unsigned)B), dim3(256), 0, st,
                        w_packed_f32, gn_scale, gn_shift, (bf16_t*)w_out, T_ws, nslab, ntaps, cp, (int)Cin);
     hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)64 * cp, 256), (unsigned)B), dim3(256), 0, st,
                        T_ws, bias_tab, tap_offsets_dev, ntaps, cp, NT);
