@@ -185,6 +185,12 @@ def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=Non
     M, K = a.shape
     N = b.shape[0]
     assert a.dtype == BF16 and b.dtype == BF16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
+    if split_k == 1 and out is None and out_dtype == torch.float32 and res is None and act == 0 and K >= 1024:
+        # few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (f32 atomics)
+        bm = 64 if (M <= 64 or (M % 128 != 0 and M % 128 <= 64 and M < 1024)) else 128
+        blocks = -(-M // bm) * -(-N // 128)
+        if blocks < 128:
+            split_k = max(1, min(K // 256, 256 // blocks))
     if out is None:
         out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
     call("gfe_gemm_bf16_nt", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),

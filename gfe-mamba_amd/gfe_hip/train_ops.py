@@ -63,7 +63,9 @@ class _LinearFn(torch.autograd.Function):
                 xT16 = K.transpose_bf16(x16)                                              # (K, M)
             dw = _gemm(K.transpose_bf16(dy16), xT16).to(weight.dtype)                     # (N, M) x (K, M)^T
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            d32 = dy2 if (dy2.dtype == torch.float32 and dy2.stride(1) == 1) else dy2.float().contiguous()
+            db = torch.empty(N, dtype=torch.float32, device=d32.device)
+            call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), stream())
         return dx, dw, db, None, None
 
 

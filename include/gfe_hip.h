@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 6
+#define GFE_ABI_VERSION 7
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -205,6 +205,9 @@ int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* d
 int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
                   float* norm2_zeroed, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                   int64_t step, void* stream);
+
+/* out[n] = sum_m x[m][n] for a row-major (M, N) f32 matrix with row stride ld: the bias gradient of every nn.Linear. */
+int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream);
 
 /* Image condition (cross_atten/mamba_transformer.py:89-94): 'b c h w d -> (b c) (h w) d' then transpose(1, 2):
  * out[b][c][r] (bf16, row stride ldo, batch stride out_batch_stride) = in[b][r][c] (f32, contiguous (batch, R, Cc)). */

@@ -85,3 +85,21 @@ def gm(RS, sw):
 for name,RS,sw in (("pad144",144,lambda r,c:c),("pad160",160,lambda r,c:c),("128 c^(r&7)",128,lambda r,c:c^(r&7)),("128 c^((r>>1)&7)",128,lambda r,c:c^((r>>1)&7)),
                    ("128 c^(r>>1&3)",128,lambda r,c:c^((r>>1)&3)),("128 c^((r&1)<<2|(r>>1&3))",128,lambda r,c:c^(((r&1)<<2)|((r>>1)&3)))):
     print(name, gm(RS,sw))
+print("---- convT fused: 16 lanes = 4(h) x 4(w) voxels of a 5x5 plane (pitch PW), tap offsets h0,w0 in {0,1}")
+def act4(PW, s, op, h0, w0, d0=0, PHW=None):
+    def f(l):
+        lr=l&15; lq=l>>4
+        h=(lr>>2)+h0; w=(lr&3)+w0
+        v=(d0*(PHW or 5*PW))+h*PW+w
+        return v*64+op(lq,s(h,w,v))*16
+    return f
+cands={"0":lambda h,w,v:0,"h":lambda h,w,v:h,"2h":lambda h,w,v:2*h,"w":lambda h,w,v:w,"v":lambda h,w,v:v,"v>>1":lambda h,w,v:v>>1,"v>>2":lambda h,w,v:v>>2,
+       "h+w":lambda h,w,v:h+w,"h^(w>>1)":lambda h,w,v:h^(w>>1),"(h>>1)":lambda h,w,v:h>>1,"h+(w>>1)":lambda h,w,v:h+(w>>1),"2h+(w>>1)":lambda h,w,v:2*h+(w>>1)}
+res=[]
+for PW in (5,6,7,8):
+    for n,sf in cands.items():
+        for on,op in ops.items():
+            worst=max(cycles(act4(PW,sf,op,h0,w0,d0,PHW)) for h0 in (0,1) for w0 in (0,1) for d0 in (0,1,2) for PHW in ((5*PW),))
+            res.append((worst,PW,n,on))
+res.sort()
+for r in res[:10]: print(r)
