@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from gfe_hip.scan_ops import selective_scan_fn, selective_scan_tm
-from gfe_hip.train_ops import Linear
+from gfe_hip.train_ops import Linear, dwconv1d_silu, rmsnorm
 
 
 @dataclass
@@ -110,6 +110,8 @@ class MambaBlock(nn.Module):
 
     def _conv_silu(self, x):
         """Depthwise causal conv1d (k = d_conv, left padding) + bias + SiLU on (B, L, ED)  (mamba.py:208-212)."""
+        if x.is_cuda and self.config.d_conv == 4:
+            return dwconv1d_silu(x, self.conv1d.weight, self.conv1d.bias)      # one fused kernel each way
         L, k = x.shape[1], self.config.d_conv
         w = self.conv1d.weight                                   # (ED, 1, k)
         xp = F.pad(x, (0, 0, k - 1, 0))
@@ -179,4 +181,6 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(d_model))
 
     def forward(self, x):
-        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight   # mamba.py:415-416
+        if x.is_cuda:
+            return rmsnorm(x, self.weight, self.eps)
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight   # mamba.py:415-416 (step() on CPU)

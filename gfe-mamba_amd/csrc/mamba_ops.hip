@@ -1,0 +1,150 @@
+// Fused glue of the Mamba block (cross_atten/mamba.py): RMSNorm (:408-418) and the depthwise causal Conv1d + bias + SiLU
+// (:128-131, 208-212), forward and backward.  Tiny tensors ((B*L, 512) / (B, L, 1024) with L = 37): the point is ONE launch
+// per op instead of the 6-20 elementwise/reduction launches an eager formulation costs.  f32 I/O.
+#include "common.h"
+
+namespace {
+
+// ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w ; one wave per row --------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                          float* __restrict__ rstd, int rows, int dim, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * dim;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float v = xr[c]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    const float r = rsqrtf(s / (float)dim + eps);
+    if (lane == 0) rstd[row] = r;
+    float* yr = y + (size_t)row * dim;
+    for (int c = lane; c < dim; c += 64) yr[c] = xr[c] * r * w[c];
+}
+
+// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd (f32 atomics over rows, dw zeroed)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ rstd,
+                                                          const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
+                                                          int rows, int dim) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * dim;
+    const float* gr = dy + (size_t)row * dim;
+    const float r = rstd[row];
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) s = fmaf(gr[c] * w[c], xr[c], s);
+    s = wave_sum(s);
+    const float k = s * r * r / (float)dim;
+    float* dxr = dx + (size_t)row * dim;
+    for (int c = lane; c < dim; c += 64) {
+        const float xv = xr[c], g = gr[c];
+        dxr[c] = r * (g * w[c] - xv * k);
+        atomicAdd(dw + c, g * xv * r);
+    }
+}
+
+// ---- depthwise causal conv1d (kernel KS, left padding KS-1) + bias + SiLU on (B, L, ED); lane = channel --------------------
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int L, int ED) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= ED) return;
+    float wk[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) wk[k] = w[e * KS + k];
+    const float bv = bias ? bias[e] : 0.f;
+    float win[KS];                                    // win[k] = x[t + k - (KS-1)]
+#pragma unroll
+    for (int k = 0; k < KS; ++k) win[k] = 0.f;
+    for (int t = 0; t < L; ++t) {
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) win[k] = win[k + 1];
+        win[KS - 1] = x[((size_t)b * L + t) * ED + e];
+        float pre = bv;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) pre = fmaf(wk[k], win[k], pre);
+        y[((size_t)b * L + t) * ED + e] = pre * sigmoidf_(pre);
+    }
+}
+
+// backward: dpre = dy * silu'(pre); dx[t] = sum_k w[k] * dpre[t + (KS-1) - k]; dw[k] += dpre[t] * x[t + k - (KS-1)]; db += dpre
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
+                                                              float* __restrict__ db, int L, int ED) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= ED) return;
+    float wk[KS], dwacc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { wk[k] = w[e * KS + k]; dwacc[k] = 0.f; }
+    const float bv = bias ? bias[e] : 0.f;
+    float dbacc = 0.f;
+    float win[KS], dp[KS];                            // dp[j] = dpre[t - (KS-1) + j]
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { win[k] = 0.f; dp[k] = 0.f; }
+    for (int t = 0; t < L + KS - 1; ++t) {
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) { win[k] = win[k + 1]; dp[k] = dp[k + 1]; }
+        float d = 0.f;
+        if (t < L) {
+            win[KS - 1] = x[((size_t)b * L + t) * ED + e];
+            float pre = bv;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) pre = fmaf(wk[k], win[k], pre);
+            const float sg = sigmoidf_(pre);
+            d = dy[((size_t)b * L + t) * ED + e] * sg * (1.f + pre * (1.f - sg));
+#pragma unroll
+            for (int k = 0; k < KS; ++k) dwacc[k] = fmaf(d, win[k], dwacc[k]);
+            dbacc += d;
+        } else {
+            win[KS - 1] = 0.f;
+        }
+        dp[KS - 1] = d;
+        // dpre is now known up to step t: dx[t - (KS-1)] = sum_k w[k] * dpre[t - k]
+        const int tx = t - (KS - 1);
+        if (tx >= 0) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], dp[KS - 1 - k], acc);
+            dx[((size_t)b * L + tx) * ED + e] = acc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) atomicAdd(dw + e * KS + k, dwacc[k]);
+    if (db) atomicAdd(db + e, dbacc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t rows, int64_t dim, float eps, void* stream) {
+    GFE_REQUIRE(x && w && y && rstd, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, y, rstd, (int)rows, (int)dim, eps);
+    return gfe_launch_status();
+}
+
+int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_zeroed,
+                    int64_t rows, int64_t dim, void* stream) {
+    GFE_REQUIRE(x && w && rstd && dy && dx && dw_zeroed, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, rstd, dy, dx, dw_zeroed, (int)rows, (int)dim);
+    return gfe_launch_status();
+}
+
+int gfe_dwconv1d_silu_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
+    GFE_REQUIRE(x && w && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((dwconv_silu_fwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (int)L, (int)ED);
+    return gfe_launch_status();
+}
+
+int gfe_dwconv1d_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw_zeroed, float* db_zeroed,
+                          int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
+    GFE_REQUIRE(x && w && dy && dx && dw_zeroed, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((dwconv_silu_bwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, dy, dx,
+                       dw_zeroed, db_zeroed, (int)L, (int)ED);
+    return gfe_launch_status();
+}
+
+}  // extern "C"

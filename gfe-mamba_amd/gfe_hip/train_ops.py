@@ -109,6 +109,63 @@ def mid_linear(mid_in_cl, mid_out_cl, weight, bias):
     return _MidLinearFn.apply(mid_in_cl, mid_out_cl, weight, bias)
 
 
+class _RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        xs = x.shape
+        x2 = x.detach().float().reshape(-1, xs[-1]).contiguous()
+        w_ = w.detach().float().contiguous()
+        y = torch.empty_like(x2)
+        rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x2.device)
+        call("gfe_rmsnorm_fwd", ptr(x2), ptr(w_), ptr(y), ptr(rstd), x2.shape[0], x2.shape[1], float(eps), stream())
+        ctx.save_for_backward(x2, w_, rstd)
+        ctx.xs = xs
+        return y.view(xs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_, rstd = ctx.saved_tensors
+        d = dy.float().reshape(x2.shape).contiguous()
+        dx = torch.empty_like(x2)
+        dw = torch.zeros_like(w_)
+        call("gfe_rmsnorm_bwd", ptr(x2), ptr(w_), ptr(rstd), ptr(d), ptr(dx), ptr(dw), x2.shape[0], x2.shape[1], stream())
+        return dx.view(ctx.xs), dw, None
+
+
+def rmsnorm(x, weight, eps):
+    """x * rsqrt(mean(x^2, -1) + eps) * weight (cross_atten/mamba.py:415-416), one kernel each way."""
+    return _RMSNormFn.apply(x, weight, eps)
+
+
+class _DwConvSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        B, L, ED = x.shape
+        x_ = x.detach().float().contiguous()
+        w_ = w.detach().float().contiguous()
+        b_ = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty_like(x_)
+        call("gfe_dwconv1d_silu_fwd", ptr(x_), ptr(w_), ptr(b_), ptr(y), B, L, ED, w_.shape[-1], stream())
+        ctx.save_for_backward(x_, w_, b_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_, w_, b_ = ctx.saved_tensors
+        B, L, ED = x_.shape
+        d = dy.float().contiguous()
+        dx = torch.empty_like(x_)
+        dw = torch.zeros_like(w_)
+        db = None if b_ is None else torch.zeros_like(b_)
+        call("gfe_dwconv1d_silu_bwd", ptr(x_), ptr(w_), ptr(b_), ptr(d), ptr(dx), ptr(dw), ptr(db), B, L, ED, w_.shape[-1], stream())
+        return dx, dw, db
+
+
+def dwconv1d_silu(x, conv_weight, conv_bias):
+    """silu(depthwise causal conv1d(x) + bias) on (B, L, ED) (cross_atten/mamba.py:208-212)."""
+    return _DwConvSiluFn.apply(x, conv_weight, conv_bias)
+
+
 class Condition:
     """bf16 image condition of Cross_mamba_both (mamba_transformer.py:89-94) in the two layouts the K/V GEMMs read:
     cond (B*keys, d_cross) for the forward, condT (d_cross, B*keys) for the weight gradient."""

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 7
+#define GFE_ABI_VERSION 8
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -205,6 +205,18 @@ int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* d
 int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
                   float* norm2_zeroed, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                   int64_t step, void* stream);
+
+/* RMSNorm (cross_atten/mamba.py:408-418): y = x * rsqrt(mean(x^2, -1) + eps) * w over (rows, dim) f32; rstd (rows) is kept for
+ * the backward: dx = rstd*(dy*w - x*rstd^2*mean(dy*w*x)), dw_zeroed += sum_rows dy*x*rstd (f32 atomics). */
+int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t rows, int64_t dim, float eps, void* stream);
+int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_zeroed,
+                    int64_t rows, int64_t dim, void* stream);
+
+/* Depthwise causal Conv1d(k = 4, padding = 3, [:L]) + bias + SiLU on (B, L, ED) f32 (cross_atten/mamba.py:128-131, 208-212);
+ * w: (ED, 1, 4) as nn.Conv1d.weight, bias (ED) or NULL.  Backward: dx, and dw_zeroed / db_zeroed accumulated over the batch. */
+int gfe_dwconv1d_silu_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
+int gfe_dwconv1d_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw_zeroed, float* db_zeroed,
+                          int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
 
 /* out[n] = sum_m x[m][n] for a row-major (M, N) f32 matrix with row stride ld: the bias gradient of every nn.Linear. */
 int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream);
