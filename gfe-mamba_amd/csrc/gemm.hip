@@ -22,11 +22,103 @@ struct GemmParams {
     int64_t lda, ldb, ldc, ldres;
     int M, N, K, ksplit;      // ksplit: K range per blockIdx.z (multiple of BK)
     int out_f32, res_f32, act, atomic;
+    int a_mode, b_mode;       // bit 0: f32 source (rounded to bf16 on load); bit 1: reduction-major source,
+                              // element (row, k) at base[k * ld + row] (the operand of a dgrad / wgrad, no transpose pass)
 };
+
+// 8 operand elements for one register item of a ROWS x 64 tile, kept RAW in registers (an f32 source is rounded when the item is
+// written to LDS, so the global loads stay in flight under the MFMAs of the current tile).  K-major source: 8 consecutive k of one
+// row (item = row*8 + chunk); reduction-major source: 8 consecutive rows of one k (item = k * ROWS/8 + row chunk), kept in that
+// order in LDS and transposed by the fragment read (ds_read_b64_tr_b16).
+struct RawItem { uint4 lo, hi; };      // bf16 source: lo only; f32 source: lo = elements 0-3, hi = 4-7
+
+template <int ROWS, int MODE>
+__device__ __forceinline__ RawItem gen_load(const void* base, int64_t ld, int row0, int nrows, int k0, int kend, int it) {
+    constexpr bool F32 = MODE & 1, TR = MODE & 2;
+    RawItem o; o.lo = make_uint4(0, 0, 0, 0); o.hi = make_uint4(0, 0, 0, 0);
+    if constexpr (!TR) {
+        const int r = row0 + (it >> 3), k = k0 + (it & 7) * 8;
+        if (r < nrows && k < kend) {
+            if constexpr (F32) {
+                const uint4* q = reinterpret_cast<const uint4*>((const float*)base + (size_t)r * ld + k);
+                o.lo = q[0]; o.hi = q[1];
+            } else {
+                o.lo = *reinterpret_cast<const uint4*>((const bf16_t*)base + (size_t)r * ld + k);
+            }
+        }
+    } else {
+        constexpr int RC = ROWS / 8;
+        const int k = k0 + it / RC, r = row0 + (it % RC) * 8;
+        if (k < kend && r < nrows) {
+            if (r + 8 <= nrows) {
+                if constexpr (F32) {
+                    const uint4* q = reinterpret_cast<const uint4*>((const float*)base + (size_t)k * ld + r);
+                    o.lo = q[0]; o.hi = q[1];
+                } else {
+                    o.lo = *reinterpret_cast<const uint4*>((const bf16_t*)base + (size_t)k * ld + r);
+                }
+            } else {                                   // ragged last row chunk
+                uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (r + e < nrows) {
+                        if constexpr (F32) w[e] = ((const uint32_t*)base)[(size_t)k * ld + r + e];
+                        else w[e >> 1] |= (uint32_t)((const bf16_t*)base)[(size_t)k * ld + r + e] << ((e & 1) * 16);
+                    }
+                }
+                o.lo = make_uint4(w[0], w[1], w[2], w[3]); o.hi = make_uint4(w[4], w[5], w[6], w[7]);
+            }
+        }
+    }
+    return o;
+}
+
+// chunk swizzle of a reduction-major LDS tile (row = k, ROWS*2 bytes per k-row)
+template <int ROWS>
+__device__ __forceinline__ int tr_swz(int k) {
+    if constexpr (ROWS == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);          // 256-B k-rows: 16 chunks, every row starts on bank 0
+    else return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);                          // 128-B k-rows: k & 1 already picks the bank half
+}
+
+template <int ROWS, int MODE>
+__device__ __forceinline__ void gen_store(uint8_t* s, int it, const RawItem& raw) {
+    constexpr bool F32 = MODE & 1, TR = MODE & 2;
+    uint4 v = raw.lo;
+    if constexpr (F32) {
+        v = make_uint4(pack_bf16x2(__uint_as_float(raw.lo.x), __uint_as_float(raw.lo.y)), pack_bf16x2(__uint_as_float(raw.lo.z), __uint_as_float(raw.lo.w)),
+                       pack_bf16x2(__uint_as_float(raw.hi.x), __uint_as_float(raw.hi.y)), pack_bf16x2(__uint_as_float(raw.hi.z), __uint_as_float(raw.hi.w)));
+    }
+    if constexpr (!TR) {
+        *reinterpret_cast<uint4*>(s + (it >> 3) * RS + (((it & 7) ^ ((it >> 3) & 7)) * 16)) = v;
+    } else {
+        // reduction-major tile keeps its memory order in LDS: [64 k][ROWS] bf16, 16-B chunk c of k-row k at slot c ^ tr_swz(k)
+        constexpr int RC = ROWS / 8;
+        const int k = it / RC, c = it % RC;
+        *reinterpret_cast<uint4*>(s + k * (ROWS * 2) + ((c ^ tr_swz<ROWS>(k)) * 16)) = v;
+    }
+}
+
+// MFMA 16x16x32 operand fragment (lane: row col0 + lr, k = kk0 + 0..7 where kk0 already includes 8*lq) out of a reduction-major
+// tile: two ds_read_b64_tr_b16 -- per 16-lane group the hardware gathers a 4(k) x 16(row) block and hands lane i column i.
+// Lane 4q+p of the group supplies the address of k-row q, rows 4p..4p+3 (cdna_hip_programming.md T10).  The swizzle puts the
+// 8 k-rows x 32 B that one 32-lane half touches on 64 distinct banks.  EXEC must be all ones (it is: no divergence in the main loop).
+template <int ROWS>
+__device__ __forceinline__ bf16x8 tr_frag(const uint8_t* tile, int col0, int kk0, int lr) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    const int q = lr >> 2, pp = lr & 3;
+    const int c = (col0 >> 3) + (pp >> 1);
+    const int k0 = kk0 + q, k1 = k0 + 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + k0 * (ROWS * 2) + ((c ^ tr_swz<ROWS>(k0)) * 16) + 8 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + k1 * (ROWS * 2) + ((c ^ tr_swz<ROWS>(k1)) * 16) + 8 * (pp & 1)));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int BM>
+template <int BM, int AM, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int A_BYTES = BM * RS, B_BYTES = BN * RS, STAGE = A_BYTES + B_BYTES;
@@ -46,29 +138,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[A_ITEMS], rb[B_ITEMS];
+    RawItem ra[A_ITEMS], rb[B_ITEMS];
     auto gload = [&](int kt) {
         const int k0 = kbeg + kt * BK;
 #pragma unroll
-        for (int i = 0; i < A_ITEMS; ++i) {
-            const int it = tid + i * 256, row = it >> 3, c = it & 7;
-            const int m = m0 + row, k = k0 + c * 8;
-            ra[i] = (m < p.M && k < kend) ? *reinterpret_cast<const uint4*>(p.A + (size_t)m * p.lda + k) : make_uint4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < A_ITEMS; ++i) ra[i] = gen_load<BM, AM>(p.A, p.lda, m0, p.M, k0, kend, tid + i * 256);
 #pragma unroll
-        for (int i = 0; i < B_ITEMS; ++i) {
-            const int it = tid + i * 256, row = it >> 3, c = it & 7;
-            const int n = n0 + row, k = k0 + c * 8;
-            rb[i] = (n < p.N && k < kend) ? *reinterpret_cast<const uint4*>(p.B + (size_t)n * p.ldb + k) : make_uint4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < B_ITEMS; ++i) rb[i] = gen_load<BN, BMODE>(p.B, p.ldb, n0, p.N, k0, kend, tid + i * 256);
     };
     auto lstore = [&](int buf) {
         uint8_t* sa = smem + buf * STAGE;
         uint8_t* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_ITEMS; ++i) { const int it = tid + i * 256; *reinterpret_cast<uint4*>(sa + (it >> 3) * RS + (((it & 7) ^ ((it >> 3) & 7)) * 16)) = ra[i]; }
+        for (int i = 0; i < A_ITEMS; ++i) gen_store<BM, AM>(sa, tid + i * 256, ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_ITEMS; ++i) { const int it = tid + i * 256; *reinterpret_cast<uint4*>(sb + (it >> 3) * RS + (((it & 7) ^ ((it >> 3) & 7)) * 16)) = rb[i]; }
+        for (int i = 0; i < B_ITEMS; ++i) gen_store<BN, BMODE>(sb, tid + i * 256, rb[i]);
     };
 
     if (nk > 0) { gload(0); lstore(0); }
@@ -76,15 +160,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
-        const uint8_t* sa = smem + (kt & 1) * STAGE + (wm * (BM / 2) + lr) * RS;
-        const uint8_t* sb = smem + (kt & 1) * STAGE + A_BYTES + (wn * 64 + lr) * RS;
+        const uint8_t* ta = smem + (kt & 1) * STAGE;
+        const uint8_t* tb = ta + A_BYTES;
+        const uint8_t* sa = ta + (wm * (BM / 2) + lr) * RS;
+        const uint8_t* sb = tb + (wn * 64 + lr) * RS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 bf[4], af[MT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * RS + (((ks * 4 + lq) ^ (lr & 7)) * 16));
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (BMODE & 2) bf[j] = tr_frag<BN>(tb, wn * 64 + j * 16, ks * 32 + lq * 8, lr);
+                else bf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * RS + (((ks * 4 + lq) ^ (lr & 7)) * 16));
+            }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RS + (((ks * 4 + lq) ^ (lr & 7)) * 16));
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (AM & 2) af[i] = tr_frag<BM>(ta, wm * (BM / 2) + i * 16, ks * 32 + lq * 8, lr);
+                else af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RS + (((ks * 4 + lq) ^ (lr & 7)) * 16));
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -175,14 +267,42 @@ __global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ in, 
     }
 }
 
-template <int BM>
+template <int BM, int AM, int BMODE>
 int gemm_launch(const GemmParams& p, int nsplit, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * RS;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, AM, BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     const dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.M, BM), (unsigned)nsplit);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, AM, BMODE>), grid, dim3(256), lds, st, p);
     return gfe_launch_status();
+}
+
+template <int AM, int BMODE>
+int gemm_launch_bm(const GemmParams& p, int nsplit, hipStream_t st) {
+    const bool small = p.M <= 64 || (p.M % 128 != 0 && p.M % 128 <= 64 && p.M < 1024);
+    return small ? gemm_launch<64, AM, BMODE>(p, nsplit, st) : gemm_launch<128, AM, BMODE>(p, nsplit, st);
+}
+
+template <int AM>
+int gemm_launch_b(const GemmParams& p, int nsplit, hipStream_t st) {
+    switch (p.b_mode) {
+        case 0: return gemm_launch_bm<AM, 0>(p, nsplit, st);
+        case 1: return gemm_launch_bm<AM, 1>(p, nsplit, st);
+        case 2: return gemm_launch_bm<AM, 2>(p, nsplit, st);
+        default: return gemm_launch_bm<AM, 3>(p, nsplit, st);
+    }
+}
+
+int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
+    int64_t ks = ceil_div(ceil_div((int64_t)p.K, split_k), BK) * BK;
+    const int nsplit = (int)ceil_div((int64_t)p.K, ks);
+    p.ksplit = (int)ks; p.atomic = nsplit > 1;
+    switch (p.a_mode) {
+        case 0: return gemm_launch_b<0>(p, nsplit, st);
+        case 1: return gemm_launch_b<1>(p, nsplit, st);
+        case 2: return gemm_launch_b<2>(p, nsplit, st);
+        default: return gemm_launch_b<3>(p, nsplit, st);
+    }
 }
 
 }  // namespace
@@ -200,12 +320,27 @@ int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.res = res;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
-    int64_t ks = ceil_div(ceil_div(K, split_k), BK) * BK;
-    const int nsplit = (int)ceil_div(K, ks);
-    p.ksplit = (int)ks; p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.atomic = nsplit > 1;
-    hipStream_t st = (hipStream_t)stream;
-    if (M <= 64 || (M % 128 != 0 && M % 128 <= 64 && M < 1024)) return gemm_launch<64>(p, nsplit, st);
-    return gemm_launch<128>(p, nsplit, st);
+    p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.a_mode = p.b_mode = 0;
+    return gemm_dispatch(p, split_k, (hipStream_t)stream);
+}
+
+int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t ldb, int b_mode, void* C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
+                int act, int out_f32, int split_k, void* stream) {
+    GFE_REQUIRE(A && B && C, GFE_ERR_NULL);
+    GFE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0, GFE_ERR_SHAPE);
+    GFE_REQUIRE(M <= 0x7fffffff && N <= 0x7fffffff && K <= 0x7fffffff, GFE_ERR_SHAPE);
+    GFE_REQUIRE((unsigned)a_mode < 4 && (unsigned)b_mode < 4, GFE_ERR_SHAPE);
+    // 16-byte vector loads: ld a multiple of 8 (bf16) / 4 (f32); a K-major operand also needs K % 8 == 0
+    GFE_REQUIRE(lda % ((a_mode & 1) ? 4 : 8) == 0 && ldb % ((b_mode & 1) ? 4 : 8) == 0, GFE_ERR_SHAPE);
+    GFE_REQUIRE(((a_mode & 2) && (b_mode & 2)) || K % 8 == 0, GFE_ERR_SHAPE);
+    GFE_REQUIRE(split_k >= 1 && (split_k == 1 || (out_f32 && !res && act == 0)), GFE_ERR_SHAPE);
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.res = res;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.a_mode = a_mode; p.b_mode = b_mode;
+    return gemm_dispatch(p, split_k, (hipStream_t)stream);
 }
 
 int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream) {

@@ -180,23 +180,48 @@ def fold_mid(x, md1=8, inverse=False, shape=None):
 
 
 # ---- GEMM / ViT ops ---------------------------------------------------------------------------------------------------
+def _auto_split_k(M, N, K):
+    """few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (f32 atomics)"""
+    bm = 64 if (M <= 64 or (M % 128 != 0 and M % 128 <= 64 and M < 1024)) else 128
+    blocks = -(-M // bm) * -(-N // 128)
+    return max(1, min(K // 256, 256 // blocks)) if blocks < 128 else 1
+
+
 def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=None):
     """a: (M, K) bf16 (row stride allowed), b: (N, K) bf16 -> (M, N).  y = act(a b^T + bias) + res."""
     M, K = a.shape
     N = b.shape[0]
     assert a.dtype == BF16 and b.dtype == BF16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
     if split_k == 1 and out is None and out_dtype == torch.float32 and res is None and act == 0 and K >= 1024:
-        # few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (f32 atomics)
-        bm = 64 if (M <= 64 or (M % 128 != 0 and M % 128 <= 64 and M < 1024)) else 128
-        blocks = -(-M // bm) * -(-N // 128)
-        if blocks < 128:
-            split_k = max(1, min(K // 256, 256 // blocks))
+        split_k = _auto_split_k(M, N, K)
     if out is None:
         out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
     call("gfe_gemm_bf16_nt", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),
          ptr(res), 0 if res is None else res.stride(0), int(res is not None and res.dtype == torch.float32),
          act, int(out.dtype == torch.float32), split_k, stream())
     return out
+
+
+def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1):
+    """C (M, N) = op(a) op(b)^T with bf16|f32 operands read in place (gfe_gemm_ex): `a_t` / `b_t` say that the operand is stored
+    reduction-major, i.e. a is (K, M) / b is (K, N) in memory."""
+    M, K = (a.shape[1], a.shape[0]) if a_t else a.shape
+    N = b.shape[1] if b_t else b.shape[0]
+    assert (b.shape[0] if b_t else b.shape[1]) == K and a.stride(1) == 1 and b.stride(1) == 1
+    mode = lambda t, tr: int(t.dtype == torch.float32) | (2 if tr else 0)
+    assert a.dtype in (BF16, torch.float32) and b.dtype in (BF16, torch.float32)
+    if split_k == 1 and out_dtype == torch.float32 and K >= 1024:
+        split_k = _auto_split_k(M, N, K)
+    out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
+    call("gfe_gemm_ex", ptr(a), a.stride(0), mode(a, a_t), ptr(b), b.stride(0), mode(b, b_t), ptr(out), out.stride(0), M, N, K,
+         ptr(bias), None, 0, 0, 0, int(out_dtype == torch.float32), split_k, stream())
+    return out
+
+
+def _ex_ok(t):
+    """operand usable in place by gemm_ex: 2-D, unit inner stride, 16-byte aligned rows"""
+    al = 4 if t.dtype == torch.float32 else 8
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % al == 0 and t.data_ptr() % 16 == 0 and t.dtype in (BF16, torch.float32)
 
 
 def transpose_bf16(x):

@@ -35,35 +35,59 @@ def _gemm(a16, b16, bias=None):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b.  Optional precomputed bf16 operands: x16 (M, K) and xT16 (K, M) for inputs that are reused."""
+    """y = x W^T + b.  Optional precomputed bf16 operands: x16 (M, K) and xT16 (K, M) for inputs that are reused.
+
+    Fast path (every Linear of the real model): the GEMM reads f32 activations / gradients in place and reads W or dy / x
+    reduction-major for dgrad / wgrad (gfe_gemm_ex), so a Linear costs 1 launch forward and 3 backward.  Shapes the vector
+    loads cannot take (K % 8, N % 8: tiny test widths, the 1-wide logit layer) go through cast + transpose + zero padding."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, x16, xT16):
         N, Kd = weight.shape
         xs = x.shape
-        if x16 is None:
-            x16 = K.cast(x.detach().reshape(-1, Kd).float(), BF16)
-        y = _gemm(x16, _w16(weight), None if bias is None else bias.detach().float().contiguous())
-        ctx.save_for_backward(x16, xT16, weight)
-        ctx.meta = (xs, bias is not None, x.dtype)
+        w16 = _w16(weight)
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        xin = x16 if x16 is not None else x.detach().reshape(-1, Kd)
+        if xin.dtype not in (BF16, torch.float32):
+            xin = xin.float()
+        fast = Kd % 8 == 0 and N % 8 == 0 and K._ex_ok(xin) and K._ex_ok(w16)
+        if fast:
+            y = K.gemm_ex(xin, False, w16, False, bias=b32)
+            ctx.save_for_backward(xin, xT16, weight)
+        else:
+            if x16 is None:
+                x16 = K.cast(x.detach().reshape(-1, Kd).float(), BF16)
+            y = _gemm(x16, w16, b32)
+            ctx.save_for_backward(x16, xT16, weight)
+        ctx.meta = (xs, bias is not None, x.dtype, fast)
         return y.reshape(xs[:-1] + (N,))
 
     @staticmethod
     def backward(ctx, dy):
-        x16, xT16, weight = ctx.saved_tensors
-        xs, has_bias, xdt = ctx.meta
+        xin, xT16, weight = ctx.saved_tensors
+        xs, has_bias, xdt, fast = ctx.meta
         N, Kd = weight.shape
         dy2 = dy.reshape(-1, N)
-        dy16 = K.cast(dy2.float(), BF16)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = _gemm(dy16, K.transpose_bf16(_w16(weight))).reshape(xs).to(xdt)          # (M, N) x (K, N)^T
-        if ctx.needs_input_grad[1]:
-            if xT16 is None:
-                xT16 = K.transpose_bf16(x16)                                              # (K, M)
-            dw = _gemm(K.transpose_bf16(dy16), xT16).to(weight.dtype)                     # (N, M) x (K, M)^T
+        d32 = dy2 if (dy2.dtype == torch.float32 and dy2.stride(1) == 1) else dy2.float().contiguous()
+        if fast and K._ex_ok(d32):
+            if ctx.needs_input_grad[0]:
+                dx = K.gemm_ex(d32, False, _w16(weight), True).reshape(xs).to(xdt)        # dy (M, N) . W (N, K) read reduction-major
+            if ctx.needs_input_grad[1]:
+                if xT16 is not None:
+                    dw = K.gemm_ex(d32, True, xT16, False).to(weight.dtype)               # dy^T . (K, M)^T
+                else:
+                    dw = K.gemm_ex(d32, True, xin, True).to(weight.dtype)                 # dy^T . x, both read reduction-major
+        else:
+            x16 = xin if xin.dtype == BF16 else K.cast(xin, BF16)
+            dy16 = K.cast(d32, BF16)
+            if ctx.needs_input_grad[0]:
+                dx = _gemm(dy16, K.transpose_bf16(_w16(weight))).reshape(xs).to(xdt)      # (M, N) x (K, N)^T
+            if ctx.needs_input_grad[1]:
+                if xT16 is None:
+                    xT16 = K.transpose_bf16(x16)                                          # (K, M)
+                dw = _gemm(K.transpose_bf16(dy16), xT16).to(weight.dtype)                 # (N, M) x (K, M)^T
         if has_bias and ctx.needs_input_grad[2]:
-            d32 = dy2 if (dy2.dtype == torch.float32 and dy2.stride(1) == 1) else dy2.float().contiguous()
             db = torch.empty(N, dtype=torch.float32, device=d32.device)
             call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), stream())
         return dx, dw, db, None, None

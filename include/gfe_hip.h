@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 8
+#define GFE_ABI_VERSION 9
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -150,6 +150,17 @@ int gfe_fold_mid(const void* src, void* dst, int64_t B, int64_t D, int64_t H, in
 int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
                      int act, int out_f32, int split_k, void* stream);
+
+/* The same GEMM with per-operand source modes, so that the backward of a Linear needs no cast / transpose pass:
+ *   mode bit 0: the operand is f32 in memory (rounded to bf16 while it is staged; ld % 4 == 0 instead of % 8);
+ *   mode bit 1: the operand is reduction-major, element (row, k) at base[k * ld + row]  (A: row = m, B: row = n).
+ * Forward  y = x W^T      : A = x (f32, mode 1),          B = W16 (mode 0)
+ * dgrad    dx = dy W      : A = dy (f32, mode 1),         B = W16 as (N,K) read reduction-major (mode 2)
+ * wgrad    dW = dy^T x    : A = dy (f32, mode 3),         B = x (f32, mode 3); the reduction length M is then unconstrained.
+ * K % 8 == 0 unless both operands are reduction-major.  Everything else as gfe_gemm_bf16_nt. */
+int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t ldb, int b_mode, void* C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
+                int act, int out_f32, int split_k, void* stream);
 
 /* out[b][c][r] = in[b][r][c], bf16 (operand re-layout for dgrad / wgrad). */
 int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream);

@@ -175,3 +175,29 @@ def test_full_96_step_vs_reference_fixture():
     """T2 / BASELINE config 1: the full-size model on 2 volumes of 96^3 (reference run on CPU in the build container)."""
     fx = golden("t2_full96_step.npz")
     _check_step_fixture(fx, dict(f_maps=(64, 128, 256)), (96, 96, 96), 512, 6, 8, 21, tol_fwd=2e-2, tol_grad=1e-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(296, 512, 512), (37, 2048, 512), (1536, 512, 1152), (300, 64, 1024), (5, 8, 8)])
+def test_gemm_ex_modes(M, N, K):
+    """gfe_gemm_ex: every operand mode (bf16|f32, K-major|reduction-major) against an f32 matmul of the bf16-rounded operands."""
+    from gfe_hip import nn_ops as K_
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).cuda()
+    b = torch.randn(N, K, generator=g).cuda()
+    ref = a.bfloat16().float() @ b.bfloat16().float().t()
+    for a_f32 in (False, True):
+        for b_f32 in (False, True):
+            for a_t in (False, True):
+                for b_t in (False, True):
+                    if K % 8 and not (a_t and b_t):
+                        continue
+                    if (a_t and M % (4 if a_f32 else 8)) or (b_t and N % (4 if b_f32 else 8)):
+                        continue                 # row stride of a reduction-major operand must keep 16-byte alignment
+                    aa = a if a_f32 else a.bfloat16()
+                    bb = b if b_f32 else b.bfloat16()
+                    aa = aa.t().contiguous() if a_t else aa
+                    bb = bb.t().contiguous() if b_t else bb
+                    out = K_.gemm_ex(aa, a_t, bb, b_t)
+                    err = (out - ref).abs().max().item()
+                    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (a_f32, b_f32, a_t, b_t, err)
