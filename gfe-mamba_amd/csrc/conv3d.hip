@@ -51,6 +51,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base,
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: row_ror:8, row_ror:4, then quad xor 2 / xor 1
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+    return v;
+}
+
 constexpr int TD = 8, TH = 8, TW = 8;          // output tile (class-grid voxels)
 constexpr int NWAVES = TD;                     // one wave per output d-plane
 constexpr int NTHREADS = NWAVES * 64;
@@ -75,6 +84,7 @@ struct ConvParams {
     int lo_d, lo_h, lo_w, LD, LH, LW;
     int ostride, op_d, op_h, op_w, oshift;
     int relu;
+    float* stats; int stats_nblk, stats_slot0;  // GroupNorm partials of the OUTPUT: (B, stats_nblk, 2, Cout) f32, slot = slot0 + tile-in-sample
     int ntd, nth, ntw, tiles_per_block;
     int toff[27];                              // LDS byte offset of each tap inside the halo tile
     int txor[27];                              // 32 when the tap shifts the row parity (swizzle term), else 0
@@ -82,7 +92,7 @@ struct ConvParams {
 
 struct TilePos { int b, td, th, tw; };
 
-template <int NT, int TPS, bool REG27>
+template <int NT, int TPS, bool REG27, bool STATS>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer/LDS-DMA builtins)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     constexpr int W_PER_WAVE = (W_PIECES + DMA_WAVES - 1) / DMA_WAVES;
     uint8_t* sA = smem;                                      // 2 x A_BYTES
     uint8_t* sW = smem + 2 * A_BYTES;                        // 2 x W_PIECES KiB
+    float* sRed = reinterpret_cast<float*>(smem + 2 * A_BYTES + 2 * W_PIECES * 1024);   // [NWAVES][2][WROWS_TAP] GroupNorm partials of a tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
@@ -194,6 +205,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     // interior tiles has no load on its critical path; boundary voxels read their class row from the table
     float bias0[4 * NT];
     int bias0_key = -1;
+    float gs[STATS ? 4 * NT : 1], gq[STATS ? 4 * NT : 1];     // GroupNorm partials of the stored output, see the epilogue
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+    }
 
     if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur.b, 0, 0, 0, 0);
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             for (int xt = 0; xt < 4; ++xt)
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct) acc[xt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias_tab && bias0_key != cur.b * p.ngroups + group) {       // wave-uniform; lands during the unit's stages
+            if (!STATS && p.bias_tab && bias0_key != cur.b * p.ngroups + group) {       // wave-uniform; lands during the unit's stages
                 bias0_key = cur.b * p.ngroups + group;
                 const int c0b = group * WROWS_TAP + lq * 4 * NT;
                 const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + (size_t)cur.b * 64 * p.CoutPad + (c0b < p.CoutPad ? c0b : 0));
@@ -294,6 +310,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             const int b = cur.b, d0 = cur.td * TD, h0 = cur.th * TH, w0 = cur.tw * TW;
             const int cd = d0 + wave;
             const int c0 = group * WROWS_TAP + lq * 4 * NT;
+            // GroupNorm partials of what this tile stores (the next layer normalises it): per-channel sum / sum of squares
+            // of the ROUNDED values, so the statistics describe exactly the tensor the consumer reads.  The per-lane sums persist
+            // across the block's tiles and are reduced / stored only when the (sample, channel group) changes or the block ends.
             if (cd < p.D && c0 < p.Cout) {
 #pragma unroll
                 for (int xt = 0; xt < 4; ++xt) {
@@ -302,30 +321,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                     const int od = p.ostride * cd + p.op_d, oh = p.ostride * ch_ + p.op_h, ow = p.ostride * cw_ + p.op_w;
                     // transposed conv: raw output has 2n-1 planes per axis; class-1 positions past it do not exist
                     if (p.ostride == 2 && (od > 2 * p.D - 2 || oh > 2 * p.H - 2 || ow > 2 * p.W - 2)) continue;
-                    float v[4 * NT];
-#pragma unroll
-                    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * ct + r] = acc[xt][ct][r];
+                    // finish the tile in place (the accumulators are dead afterwards): 4 channels at a time keeps the epilogue's
+                    // temporaries at one f32x4 -- with the GroupNorm partials live a 16-wide copy spills
                     if (p.bias_tab) {
                         // boundary class: which neighbours of this voxel fall outside the volume
                         const int cls = (cd == 0) | ((cd == p.D - 1) << 1) | ((ch_ == 0) << 2) | ((ch_ == p.H - 1) << 3) |
                                         ((cw_ == 0) << 4) | ((cw_ == p.W - 1) << 5);
-                        if (cls == 0) {
+                        if (!STATS && cls == 0) {           // (with the GroupNorm partials live, bias0 would not fit in registers)
 #pragma unroll
-                            for (int i = 0; i < 4 * NT; ++i) v[i] += bias0[i];
+                            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[xt][i][r] += bias0[4 * i + r];
                         } else {
                             const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + ((size_t)b * 64 + cls) * p.CoutPad + c0);
 #pragma unroll
                             for (int i = 0; i < NT; ++i) {
                                 const float4 t = bt[i];
-                                v[4 * i] += t.x; v[4 * i + 1] += t.y; v[4 * i + 2] += t.z; v[4 * i + 3] += t.w;
+                                acc[xt][i][0] += t.x; acc[xt][i][1] += t.y; acc[xt][i][2] += t.z; acc[xt][i][3] += t.w;
                             }
                         }
                     }
                     if (p.bias) {
 #pragma unroll
-                        for (int i = 0; i < 4 * NT; ++i) v[i] += p.bias[c0 + i];
+                        for (int i = 0; i < NT; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[xt][i][r] += p.bias[c0 + 4 * i + r];
                     }
                     const int nd = (p.oshift && od == 0) ? 2 : 1, nh = (p.oshift && oh == 0) ? 2 : 1, nw = (p.oshift && ow == 0) ? 2 : 1;
                     for (int zd = 0; zd < nd; ++zd)
@@ -334,27 +354,61 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                                 const int dd_ = zd ? 0 : od + p.oshift, dh_ = zh ? 0 : oh + p.oshift, dw_ = zw ? 0 : ow + p.oshift;
                                 if (dd_ >= p.OD || dh_ >= p.OH || dw_ >= p.OW) continue;
                                 const size_t o = ((((size_t)b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_) * p.Cout + c0;
-                                float wv[4 * NT];
-#pragma unroll
-                                for (int i = 0; i < 4 * NT; ++i) wv[i] = v[i];
+                                uint2 rv[NT];
                                 if (p.res) {
                                     const uint2* rp = reinterpret_cast<const uint2*>(p.res + o);
 #pragma unroll
-                                    for (int i = 0; i < NT; ++i) {
-                                        const uint2 rv = rp[i];
-                                        wv[4 * i] += bf16lo_to_f32(rv.x); wv[4 * i + 1] += bf16hi_to_f32(rv.x);
-                                        wv[4 * i + 2] += bf16lo_to_f32(rv.y); wv[4 * i + 3] += bf16hi_to_f32(rv.y);
-                                    }
-                                }
-                                if (p.relu) {
-#pragma unroll
-                                    for (int i = 0; i < 4 * NT; ++i) wv[i] = fmaxf(wv[i], 0.f);
+                                    for (int i = 0; i < NT; ++i) rv[i] = rp[i];
                                 }
                                 uint2* yp = reinterpret_cast<uint2*>(p.y + o);
 #pragma unroll
-                                for (int i = 0; i < NT; ++i)
-                                    yp[i] = make_uint2(pack_bf16x2(wv[4 * i], wv[4 * i + 1]), pack_bf16x2(wv[4 * i + 2], wv[4 * i + 3]));
+                                for (int i = 0; i < NT; ++i) {
+                                    float w0_ = acc[xt][i][0], w1_ = acc[xt][i][1], w2_ = acc[xt][i][2], w3_ = acc[xt][i][3];
+                                    if (p.res) {
+                                        w0_ += bf16lo_to_f32(rv[i].x); w1_ += bf16hi_to_f32(rv[i].x);
+                                        w2_ += bf16lo_to_f32(rv[i].y); w3_ += bf16hi_to_f32(rv[i].y);
+                                    }
+                                    if (p.relu) { w0_ = fmaxf(w0_, 0.f); w1_ = fmaxf(w1_, 0.f); w2_ = fmaxf(w2_, 0.f); w3_ = fmaxf(w3_, 0.f); }
+                                    const uint2 pk = make_uint2(pack_bf16x2(w0_, w1_), pack_bf16x2(w2_, w3_));
+                                    yp[i] = pk;
+                                    if constexpr (STATS) {
+                                        const float r0 = bf16lo_to_f32(pk.x), r1 = bf16hi_to_f32(pk.x), r2 = bf16lo_to_f32(pk.y), r3 = bf16hi_to_f32(pk.y);
+                                        gs[4 * i] += r0; gs[4 * i + 1] += r1; gs[4 * i + 2] += r2; gs[4 * i + 3] += r3;
+                                        gq[4 * i] = fmaf(r0, r0, gq[4 * i]); gq[4 * i + 1] = fmaf(r1, r1, gq[4 * i + 1]);
+                                        gq[4 * i + 2] = fmaf(r2, r2, gq[4 * i + 2]); gq[4 * i + 3] = fmaf(r3, r3, gq[4 * i + 3]);
+                                    }
+                                }
                             }
+                }
+            }
+            if constexpr (STATS) {
+                // flush when the next epilogue belongs to another (sample, channel group) or there is none: block-uniform
+                const bool flush = !next_unit || p.ngroups > 1 || nxt.b != cur.b;
+                if (flush) {
+                    // 16 voxel lanes of a DPP row -> one value; 8 d-plane waves -> LDS; one plain store per (slot, channel, stat)
+#pragma unroll
+                    for (int i = 0; i < 4 * NT; ++i) { gs[i] = row16_sum(gs[i]); gq[i] = row16_sum(gq[i]); }
+                    if (lr == 0) {
+                        float4* r0 = reinterpret_cast<float4*>(sRed + (wave * 2) * WROWS_TAP + lq * 4 * NT);
+                        float4* r1 = reinterpret_cast<float4*>(sRed + (wave * 2 + 1) * WROWS_TAP + lq * 4 * NT);
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) {
+                            r0[i] = make_float4(gs[4 * i], gs[4 * i + 1], gs[4 * i + 2], gs[4 * i + 3]);
+                            r1[i] = make_float4(gq[4 * i], gq[4 * i + 1], gq[4 * i + 2], gq[4 * i + 3]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4 * NT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+                    __syncthreads();
+                    if (tid < 2 * WROWS_TAP) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int wv_ = 0; wv_ < NWAVES; ++wv_) t += sRed[wv_ * 2 * WROWS_TAP + tid];
+                        const int st = tid / WROWS_TAP, c = group * WROWS_TAP + (tid - st * WROWS_TAP);
+                        // the slot of the LAST tile that went into the sums: unique per flush; slots never written stay zero (caller-zeroed)
+                        const int slot = p.stats_slot0 + (cur.td * p.nth + cur.th) * p.ntw + cur.tw;
+                        if (c < p.Cout) p.stats[(((size_t)b * p.stats_nblk + slot) * 2 + st) * p.Cout + c] = t;
+                    }
                 }
             }
         }
@@ -417,10 +471,10 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     tab[((size_t)b * 64 + cls) * CoutPad + ch] = acc;
 }
 
-template <int NT, int TPS, bool REG27>
+template <int NT, int TPS, bool REG27, bool STATS>
 int conv_launch(const ConvParams& p, hipStream_t st) {
     constexpr int W_PIECES = (TPS * NT * 16 + 15) / 16;
-    const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024;
+    const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * NT * 16 * sizeof(float);
     const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw;
     if (tiles > 0x7fffffff) return GFE_ERR_SHAPE;
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
@@ -428,14 +482,16 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     q.tiles_per_block = (int)ceil_div(tiles, 256);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27>), grid, dim3(NTHREADS), lds, st, q);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27, STATS>), grid, dim3(NTHREADS), lds, st, q);
     return gfe_launch_status();
 }
 
 }  // namespace
 
 extern "C" {
+
+int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W) { return (int)(ceil_div(D, TD) * ceil_div(H, TH) * ceil_div(W, TW)); }
 
 int gfe_conv3d_cout_pad(int64_t Cout) {
     if (Cout <= 16) return 16;
@@ -463,7 +519,8 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
                      int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                      int64_t OD, int64_t OH, int64_t OW,
                      int ntaps, const int8_t* tap_offsets /* host, ntaps x 3 (dd,dh,dw) */,
-                     int ostride, int op_d, int op_h, int op_w, int oshift, int relu, void* stream) {
+                     int ostride, int op_d, int op_h, int op_w, int oshift, int relu,
+                     float* stats_ws, int64_t stats_nblk, int64_t stats_slot0, void* stream) {
     GFE_REQUIRE(x && w_packed && y && tap_offsets, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
@@ -502,14 +559,21 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
         GFE_REQUIRE(OD == 2 * D - 1 + oshift && OH == 2 * H - 1 + oshift && OW == 2 * W - 1 + oshift, GFE_ERR_SHAPE);
     }
     p.ntd = (int)ceil_div(D, TD); p.nth = (int)ceil_div(H, TH); p.ntw = (int)ceil_div(W, TW);
+    p.stats = stats_ws; p.stats_nblk = (int)stats_nblk; p.stats_slot0 = (int)stats_slot0;
+    if (stats_ws) GFE_REQUIRE(stats_slot0 >= 0 && stats_slot0 + (int64_t)p.ntd * p.nth * p.ntw <= stats_nblk && stats_nblk <= 0x7fffffff, GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     // regular 3x3x3 tap list in canonical order -> immediate-offset fast path
     bool reg27 = ntaps == 27 && ostride == 1;
     for (int t = 0; t < ntaps && reg27; ++t)
         reg27 = tap_offsets[3 * t] == t / 9 - 1 && tap_offsets[3 * t + 1] == (t / 3) % 3 - 1 && tap_offsets[3 * t + 2] == t % 3 - 1;
-    if (NT == 1) return conv_launch<1, 3, false>(p, st);
-    if (NT == 2) return conv_launch<2, 3, false>(p, st);
-    return reg27 ? conv_launch<4, 3, true>(p, st) : conv_launch<4, 3, false>(p, st);
+    if (stats_ws) {
+        if (NT == 1) return conv_launch<1, 3, false, true>(p, st);
+        if (NT == 2) return conv_launch<2, 3, false, true>(p, st);
+        return reg27 ? conv_launch<4, 3, true, true>(p, st) : conv_launch<4, 3, false, true>(p, st);
+    }
+    if (NT == 1) return conv_launch<1, 3, false, false>(p, st);
+    if (NT == 2) return conv_launch<2, 3, false, false>(p, st);
+    return reg27 ? conv_launch<4, 3, true, false>(p, st) : conv_launch<4, 3, false, false>(p, st);
 }
 
 }  // extern "C"

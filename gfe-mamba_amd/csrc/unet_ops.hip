@@ -119,6 +119,61 @@ __global__ __launch_bounds__(256) void conv_in1_kernel(const TI* __restrict__ x,
     }
 }
 
+// the same with the GroupNorm partials of y (sum / sum of squares of the rounded outputs per channel): block (blk, b) owns voxels
+// [blk*vpb, (blk+1)*vpb) of sample b and writes slot blk -- the layout gn_partial_kernel produces, without re-reading y
+template <typename TI>
+__global__ __launch_bounds__(256) void conv_in1_stats_kernel(const TI* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             bf16_t* __restrict__ y, float* __restrict__ ws, int64_t S, int C, int vpb, int nblk) {
+    extern __shared__ float lds[];               // [2][C]
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int CP = C >> 3;
+    const int c = tid % CP, vl = tid / CP, VI = 256 / CP;
+    for (int i = tid; i < 2 * C; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    float wc[8], bc[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wc[j] = w[c * 8 + j]; bc[j] = bias[c * 8 + j]; s[j] = 0.f; q[j] = 0.f; }
+    const int64_t v0 = (int64_t)blk * vpb;
+    const int64_t v1 = v0 + vpb < S ? v0 + vpb : S;
+    for (int64_t v = v0 + vl; v < v1; v += VI) {
+        const float xv = IO<TI>::ld(x + (size_t)b * S + v);
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pk[j] = pack_bf16x2(fmaf(wc[2 * j], xv, bc[2 * j]), fmaf(wc[2 * j + 1], xv, bc[2 * j + 1]));
+            const float r0 = bf16lo_to_f32(pk[j]), r1 = bf16hi_to_f32(pk[j]);
+            s[2 * j] += r0; s[2 * j + 1] += r1; q[2 * j] = fmaf(r0, r0, q[2 * j]); q[2 * j + 1] = fmaf(r1, r1, q[2 * j + 1]);
+        }
+        *reinterpret_cast<uint4*>(y + ((size_t)b * S + v) * C + c * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    // fixed-order merge of the VI voxel lanes of a channel chunk (deterministic, unlike LDS float atomics)
+    float* red = lds + 2 * C;                    // [VI][2][C]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(vl * 2) * C + c * 8 + j] = s[j]; red[(vl * 2 + 1) * C + c * 8 + j] = q[j]; }
+    __syncthreads();
+    float* o = ws + ((size_t)b * nblk + blk) * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) {
+        float t = 0.f;
+        for (int k = 0; k < VI; ++k) t += red[k * 2 * C + i];
+        o[i] = t;
+    }
+}
+
+// folds nblk partial slots 32-ways: out[b][r] = sum of slots r, r+32, ... (fixed order)
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblk, int ncol) {
+    const int b = blockIdx.y, r = blockIdx.x;
+    for (int c = threadIdx.x; c < ncol; c += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = r;
+        for (; k + 96 < nblk; k += 128) {
+            a0 += ws[((size_t)b * nblk + k) * ncol + c];      a1 += ws[((size_t)b * nblk + k + 32) * ncol + c];
+            a2 += ws[((size_t)b * nblk + k + 64) * ncol + c]; a3 += ws[((size_t)b * nblk + k + 96) * ncol + c];
+        }
+        for (; k < nblk; k += 32) a0 += ws[((size_t)b * nblk + k) * ncol + c];
+        out[((size_t)b * 32 + r) * ncol + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 // ---- C -> 1 pointwise conv with bias (final_conv), output f32; 16-B lanes, C/8 lanes per voxel ------------------
 __global__ __launch_bounds__(256) void conv_out1_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, float bias,
                                                         float* __restrict__ y, int64_t nvox, int C) {
@@ -188,6 +243,38 @@ int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* be
                        (const bf16_t*)x, ws, S, (int)C, vpb, nblk);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G) * sizeof(double), st,
                        ws, gamma, beta, scale, shift, S, (int)C, (int)G, nblk, eps);
+    return gfe_launch_status();
+}
+
+int gfe_groupnorm_from_partials(const float* ws, int64_t nblk, const float* gamma, const float* beta, float* scale, float* shift,
+                                float* ws2, int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream) {
+    GFE_REQUIRE(ws && gamma && beta && scale && shift, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && S > 0 && nblk > 0 && nblk <= 0x7fffffff && C > 0 && G > 0 && C % G == 0 && G <= 256 && 2 * C <= 1024, GFE_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    if (nblk > 128) {
+        GFE_REQUIRE(ws2, GFE_ERR_NULL);
+        hipLaunchKernelGGL(gn_reduce_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, ws, ws2, (int)nblk, (int)(2 * C));
+        ws = ws2; nblk = 32;
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G) * sizeof(double), st,
+                       ws, gamma, beta, scale, shift, S, (int)C, (int)G, (int)nblk, eps);
+    return gfe_launch_status();
+}
+
+int gfe_conv_in1_nblk(int64_t S) { return (int)ceil_div(S, 2048); }
+
+int gfe_conv_in1_stats(const void* x, const float* w, const float* bias, void* y, float* stats_ws, int64_t B, int64_t S, int64_t C,
+                       int in_dtype, void* stream) {
+    GFE_REQUIRE(x && w && bias && y && stats_ws, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && S > 0 && C >= 8 && C % 8 == 0 && (256 % (C / 8)) == 0 && C <= 512, GFE_ERR_SHAPE);
+    const int nblk = gfe_conv_in1_nblk(S), vpb = 2048;
+    const size_t lds = (2 * C + (256 / (C / 8)) * 2 * C) * sizeof(float);
+    const dim3 grid((unsigned)nblk, (unsigned)B);
+    if (in_dtype == GFE_F32)
+        hipLaunchKernelGGL((conv_in1_stats_kernel<float>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)x, w, bias, (bf16_t*)y, stats_ws, S, (int)C, vpb, nblk);
+    else if (in_dtype == GFE_BF16)
+        hipLaunchKernelGGL((conv_in1_stats_kernel<bf16_t>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, w, bias, (bf16_t*)y, stats_ws, S, (int)C, vpb, nblk);
+    else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }
 

@@ -107,9 +107,21 @@ def pack_convT(weight):
 
 
 # ---- generator ops --------------------------------------------------------------------------------------------------
-def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu=False, out=None, transposed=None):
+def conv_tiles(D, H, W):
+    return lib().gfe_conv3d_tiles(D, H, W)
+
+
+def new_gn_partials(B, nblk, C, device):
+    """Zeroed workspace a producer fills with the GroupNorm partials of its output (gfe_hip.h: stats_ws): the conv kernel
+    writes only the slots where one of its persistent blocks changes sample / ends, the rest must read as zero."""
+    return torch.zeros((B, nblk, 2, C), dtype=torch.float32, device=device)
+
+
+def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu=False, out=None, transposed=None, stats=None):
     """x: (B, D, H, W, Cin) bf16.  w_packed: one weight set, or (B, ...) per-sample sets from fold_groupnorm (with bias_tab).
-    transposed: None, or (parity tuple, out tensor (B, 2D, 2H, 2W, Cout)) for one ConvT class."""
+    transposed: None, or (parity tuple, out tensor (B, 2D, 2H, 2W, Cout)) for one ConvT class.
+    stats: None | True | (ws, slot0): write the GroupNorm partials of the output; True allocates them and tags the result
+    (`out.gn_partials`) so the next SingleConv skips its statistics pass."""
     B, D, H, W, cin = x.shape
     assert x.dtype == BF16 and x.is_contiguous()
     tarr, tptr = _i8(taps)
@@ -125,8 +137,16 @@ def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu
         oshift = OD - (2 * D - 1)
         assert oshift in (0, 1) and OH == 2 * H - 1 + oshift and OW == 2 * W - 1 + oshift, "unsupported upsampling size"
     wstride = w_packed.stride(0) if w_packed.dim() == 5 else 0
+    ws, slot0 = None, 0
+    if stats is True:
+        ws = new_gn_partials(B, conv_tiles(D, H, W), cout, x.device)
+    elif stats is not None:
+        ws, slot0 = stats
     call("gfe_conv3d_igemm", ptr(x), ptr(w_packed), wstride, ptr(bias), ptr(bias_tab), ptr(res), ptr(out),
-         B, D, H, W, cin, cout, OD, OH, OW, len(taps), tptr, ostride, par[0], par[1], par[2], oshift, int(relu), stream())
+         B, D, H, W, cin, cout, OD, OH, OW, len(taps), tptr, ostride, par[0], par[1], par[2], oshift, int(relu),
+         ptr(ws), 0 if ws is None else ws.shape[1], slot0, stream())
+    if stats is True:
+        out.gn_partials = ws
     return out
 
 
@@ -134,6 +154,13 @@ def groupnorm_scale_shift(x, gamma, beta, groups, eps=1e-5):
     """x: (B, ..., C) bf16 channels-last -> (scale, shift) each (B, C) f32."""
     B, C = x.shape[0], x.shape[-1]
     S = x.numel() // (B * C)
+    part = getattr(x, "gn_partials", None)
+    if part is not None:                         # the producer of x already reduced it tile by tile
+        nblk = part.shape[1]
+        ss = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+        ws2 = torch.empty((B, 32, 2, C), dtype=torch.float32, device=x.device) if nblk > 128 else None
+        call("gfe_groupnorm_from_partials", ptr(part), nblk, ptr(gamma), ptr(beta), ptr(ss[0]), ptr(ss[1]), ptr(ws2), B, S, C, groups, eps, stream())
+        return ss[0], ss[1]
     vpb, nblk = ctypes.c_int(), ctypes.c_int()
     lib().gfe_groupnorm_plan(S, ctypes.byref(vpb), ctypes.byref(nblk))
     ws = torch.empty((B, nblk.value, 2, C), dtype=torch.float32, device=x.device)
@@ -149,11 +176,17 @@ def maxpool2(x):
     return y
 
 
-def conv_in1(x, w, bias):
-    """x: (B, 1, D, H, W) f32|bf16 contiguous -> (B, D, H, W, C) bf16."""
+def conv_in1(x, w, bias, stats=False):
+    """x: (B, 1, D, H, W) f32|bf16 contiguous -> (B, D, H, W, C) bf16; stats: also the GroupNorm partials (`y.gn_partials`)."""
     B, _, D, H, W = x.shape
     C = w.numel()
     y = torch.empty((B, D, H, W, C), dtype=BF16, device=x.device)
+    if stats and 256 % (C // 8) == 0 and C <= 512:
+        S = D * H * W
+        ws = new_gn_partials(B, lib().gfe_conv_in1_nblk(S), C, x.device)
+        call("gfe_conv_in1_stats", ptr(x), ptr(w), ptr(bias), ptr(y), ptr(ws), B, S, C, dtype_code(x.dtype), stream())
+        y.gn_partials = ws
+        return y
     call("gfe_conv_in1", ptr(x), ptr(w), ptr(bias), ptr(y), B * D * H * W, C, dtype_code(x.dtype), stream())
     return y
 

@@ -50,15 +50,17 @@ class SingleConv(nn.Sequential):
         self.relu = 'r' in order
         self._pack = _PackCache()
 
-    def forward(self, x, residual=None):
-        """x: (B, D, H, W, Cin) bf16; optional residual is added before the (forced) ReLU: ResNetBlock tail."""
+    def forward(self, x, residual=None, stats=False):
+        """x: (B, D, H, W, Cin) bf16; optional residual is added before the (forced) ReLU: ResNetBlock tail.
+        stats: the output feeds another SingleConv -> its GroupNorm partials are produced by this conv's epilogue."""
         gn, conv = self.groupnorm, self.conv
         w32, g, b = self._pack.get([conv.weight, gn.weight, gn.bias],
                                    lambda: (K.pack_conv3(conv.weight, torch.float32), _f32(gn.weight), _f32(gn.bias)))
         scale, shift = K.groupnorm_scale_shift(x, g, b, gn.num_groups, gn.eps)
         # GroupNorm is folded into per-sample weights + a boundary-class bias table: the conv itself streams raw activations
         wb, tab = K.fold_groupnorm(w32, scale, shift, K.CONV3_TAPS, conv.in_channels, conv.out_channels)
-        return K.conv_igemm(x, wb, K.CONV3_TAPS, conv.out_channels, bias_tab=tab, res=residual, relu=self.relu or residual is not None)
+        return K.conv_igemm(x, wb, K.CONV3_TAPS, conv.out_channels, bias_tab=tab, res=residual, relu=self.relu or residual is not None,
+                            stats=True if stats else None)
 
 
 class ResNetBlock(nn.Module):
@@ -83,13 +85,13 @@ class ResNetBlock(nn.Module):
             return x
         if c1.in_channels == 1:
             w, b = self._pack.get([c1.weight, c1.bias], lambda: (_f32(c1.weight).view(-1), _f32(c1.bias)))
-            return K.conv_in1(x, w, b)
+            return K.conv_in1(x, w, b, stats=True)
         w, b = self._pack.get([c1.weight, c1.bias], lambda: (K.pack_conv1(c1.weight), _f32(c1.bias)))
-        return K.conv_igemm(x, w, [(0, 0, 0)], c1.out_channels, bias=b)
+        return K.conv_igemm(x, w, [(0, 0, 0)], c1.out_channels, bias=b, stats=True)
 
     def forward(self, x):
-        r = self.lift(x)
-        o = self.conv2(r)
+        r = self.lift(x)                                  # r and o carry their GroupNorm partials (written by the producing kernel)
+        o = self.conv2(r, stats=True)
         return self.conv3(o, residual=r)
 
 
@@ -129,8 +131,13 @@ class TransposeConvUpsampling(nn.Module):
         ct = self.upsample.conv_transposed
         classes = self._pack.get([ct.weight], lambda: K.pack_convT(ct.weight))
         out = torch.empty_like(encoder_features)
-        for par, (w, taps) in classes.items():
-            K.conv_igemm(x, w, taps, ct.out_channels, res=encoder_features, transposed=(par, out))
+        B, D, H, W, _ = x.shape
+        tiles = K.conv_tiles(D, H, W)
+        ws = K.new_gn_partials(B, 8 * tiles, ct.out_channels, x.device)    # the 8 parity classes fill disjoint slot ranges
+        for i, (par, (w, taps)) in enumerate(classes.items()):
+            K.conv_igemm(x, w, taps, ct.out_channels, res=encoder_features, transposed=(par, out), stats=(ws, i * tiles))
+        assert len(classes) == 8
+        out.gn_partials = ws
         return out
 
 

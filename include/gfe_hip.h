@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 9
+#define GFE_ABI_VERSION 10
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -103,13 +103,24 @@ int gfe_conv3d_cout_pad(int64_t Cout);
  *     (d==0) | (d==D-1)<<1 | (h==0)<<2 | (h==H-1)<<3 | (w==0)<<4 | (w==W-1)<<5.
  *   tap_offsets: HOST pointer, ntaps x 3 int8 (dd, dh, dw) each in [-1, 1].
  *   ostride 1: OD,OH,OW == D,H,W.  ostride 2: output index = 2*i + op_*, shifted by oshift (0/1) with index 0 duplicated
- *   (nearest resize 2n-1 -> 2n: dst j <- src max(j-1, 0)); OD == 2*D - 1 + oshift. */
+ *   (nearest resize 2n-1 -> 2n: dst j <- src max(j-1, 0)); OD == 2*D - 1 + oshift.
+ *   stats_ws (or NULL): GroupNorm partials of the tensor this call STORES, for the GroupNorm of the next SingleConv -- saves
+ *   re-reading y.  Layout (B, stats_nblk, 2, Cout) f32, ZEROED by the caller: [.,slot,0,c] = sum, [.,slot,1,c] = sum of squares of
+ *   the rounded bf16 outputs.  A persistent block keeps per-lane sums over its run of 8x8x8 tiles and stores them (plain stores,
+ *   fixed order: deterministic) when its run leaves the sample / channel group or ends, into slot = stats_slot0 + index inside
+ *   the sample of the run's last tile (< gfe_conv3d_tiles); all other slots stay zero.  Calls that build one tensor together
+ *   (the 8 parity classes of a transposed conv) use disjoint slot ranges;
+ *   consume with gfe_groupnorm_from_partials. */
 int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias, const float* bias_tab,
                      const void* res, void* y,
                      int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                      int64_t OD, int64_t OH, int64_t OW,
                      int ntaps, const int8_t* tap_offsets,
-                     int ostride, int op_d, int op_h, int op_w, int oshift, int relu, void* stream);
+                     int ostride, int op_d, int op_h, int op_w, int oshift, int relu,
+                     float* stats_ws, int64_t stats_nblk, int64_t stats_slot0, void* stream);
+
+/* Number of 8x8x8 output tiles per sample of gfe_conv3d_igemm on a (D, H, W) class grid = partial slots one call writes. Host-only. */
+int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W);
 
 /* Folds GroupNorm(x) = scale[b,c]*x + shift[b,c] (from gfe_groupnorm_scale_shift) into the convolution that consumes it
  * (create_conv order 'g' before 'c', buildingblocks.py:55-67; zero padding is applied AFTER the norm):
@@ -126,11 +137,21 @@ int gfe_groupnorm_plan(int64_t S, int* vox_per_block, int* nblk);
 int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float* scale, float* shift, float* ws,
                               int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream);
 
+/* The same affine from partials a producer already wrote (gfe_conv3d_igemm / gfe_conv_in1 `stats_ws`): ws (B, nblk, 2, C) f32
+ * per-slot channel sums / sums of squares over disjoint voxel sets covering all S voxels.  ws2: (B, 32, 2, C) f32 scratch
+ * (used when nblk > 128: a first kernel folds the slots 32-ways in parallel). */
+int gfe_groupnorm_from_partials(const float* ws, int64_t nblk, const float* gamma, const float* beta, float* scale, float* shift,
+                                float* ws2, int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream);
+
 /* MaxPool3d(kernel 2, stride 2) (buildingblocks.py:284): (B, D, H, W, C) -> (B, D/2, H/2, W/2, C) bf16. */
 int gfe_maxpool3d_2(const void* x, void* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, void* stream);
 
 /* encoders.0.basic_module.conv1: Conv3d(1, C, 1) + bias (buildingblocks.py:191-196). x: (nvox) f32|bf16 -> y: (nvox, C) bf16. */
 int gfe_conv_in1(const void* x, const float* w, const float* bias, void* y, int64_t nvox, int64_t C, int in_dtype, void* stream);
+/* Same, per sample, additionally writing the GroupNorm partials of y: stats_ws (B, nblk, 2, C) f32 with nblk = gfe_conv_in1_nblk(S). */
+int gfe_conv_in1_nblk(int64_t S);
+int gfe_conv_in1_stats(const void* x, const float* w, const float* bias, void* y, float* stats_ws, int64_t B, int64_t S, int64_t C,
+                       int in_dtype, void* stream);
 
 /* final_conv: Conv3d(C, 1, 1) + bias (pytorch3dunet/unet3d/model.py:123,162). x: (nvox, C) bf16 -> y: (nvox) f32. */
 int gfe_conv_out1(const void* x, const float* w, float bias, float* y, int64_t nvox, int64_t C, void* stream);

@@ -186,3 +186,34 @@ def test_generator_reduced_vs_reference_fixture():
     o_in, o_out, o_pet = O.generator(x, sd, vit_heads=2, vit_depth=2)
     assert rel_err(o_pet, tt(fx["pet"])) < 1e-4
     assert rel_err(pet, o_pet) < 3e-2
+
+
+@pytest.mark.parametrize("C,shape", [(64, (2, 16, 16, 24)), (16, (1, 8, 9, 7)), (128, (2, 8, 8, 16))])
+def test_fused_groupnorm_partials_match_the_statistics_pass(C, shape):
+    """GroupNorm partials written by the producing kernel (conv epilogue, 1->C conv, transposed-conv classes) give the same
+    (scale, shift) as the separate statistics pass over the stored tensor (gfe_groupnorm_scale_shift)."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(C)
+    B, D, H, W = shape
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+
+    def check(y):
+        assert getattr(y, "gn_partials", None) is not None
+        s1, t1 = K.groupnorm_scale_shift(y, gamma, beta, 8)
+        plain = y.clone()                                   # no attribute -> statistics pass over the tensor
+        s0, t0 = K.groupnorm_scale_shift(plain, gamma, beta, 8)
+        assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
+
+    x = torch.randn(B, D, H, W, C, generator=g).to(BF).to(DEV)
+    w = torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+    check(K.conv_igemm(x, K.pack_conv3(w.to(DEV), BF), K.CONV3_TAPS, C, relu=True, stats=True))                 # REG27 path
+    w1 = torch.randn(C, C, 1, 1, 1, generator=g) / C ** 0.5
+    check(K.conv_igemm(x, K.pack_conv1(w1.to(DEV)), [(0, 0, 0)], C, bias=torch.randn(C, generator=g).to(DEV), stats=True))
+    vol = torch.randn(B, 1, D, H, W, generator=g).to(DEV)
+    check(K.conv_in1(vol, torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV), stats=True))
+    # transposed conv + resize + skip through the module (8 parity classes, disjoint slot ranges)
+    from pytorch3dunet.unet3d.buildingblocks import TransposeConvUpsampling
+    up = TransposeConvUpsampling(C, C).to(DEV)
+    skip = torch.randn(B, 2 * D, 2 * H, 2 * W, C, generator=g).to(BF).to(DEV)
+    with torch.no_grad():
+        check(up(skip, x))
