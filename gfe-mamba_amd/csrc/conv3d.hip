@@ -354,29 +354,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                                 const int dd_ = zd ? 0 : od + p.oshift, dh_ = zh ? 0 : oh + p.oshift, dw_ = zw ? 0 : ow + p.oshift;
                                 if (dd_ >= p.OD || dh_ >= p.OH || dw_ >= p.OW) continue;
                                 const size_t o = ((((size_t)b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_) * p.Cout + c0;
-                                uint2 rv[NT];
+                                // 16-byte accesses: the lane's channels c0 + 8*h .. + 7 are accumulator tiles 2h and 2h + 1
+                                constexpr int NV = NT >= 2 ? NT / 2 : 1;           // vectors per voxel (NT == 1: one 8-byte vector)
+                                uint4 rv[NV];
                                 if (p.res) {
-                                    const uint2* rp = reinterpret_cast<const uint2*>(p.res + o);
+                                    if constexpr (NT >= 2) {
+                                        const uint4* rp = reinterpret_cast<const uint4*>(p.res + o);
 #pragma unroll
-                                    for (int i = 0; i < NT; ++i) rv[i] = rp[i];
+                                        for (int h = 0; h < NV; ++h) rv[h] = rp[h];
+                                    } else {
+                                        const uint2 t = *reinterpret_cast<const uint2*>(p.res + o);
+                                        rv[0] = make_uint4(t.x, t.y, 0, 0);
+                                    }
                                 }
-                                uint2* yp = reinterpret_cast<uint2*>(p.y + o);
 #pragma unroll
-                                for (int i = 0; i < NT; ++i) {
-                                    float w0_ = acc[xt][i][0], w1_ = acc[xt][i][1], w2_ = acc[xt][i][2], w3_ = acc[xt][i][3];
-                                    if (p.res) {
-                                        w0_ += bf16lo_to_f32(rv[i].x); w1_ += bf16hi_to_f32(rv[i].x);
-                                        w2_ += bf16lo_to_f32(rv[i].y); w3_ += bf16hi_to_f32(rv[i].y);
+                                for (int h = 0; h < NV; ++h) {
+                                    uint32_t pk[4] = {0, 0, 0, 0};
+                                    const uint32_t rw[4] = {rv[h].x, rv[h].y, rv[h].z, rv[h].w};
+#pragma unroll
+                                    for (int j = 0; j < (NT >= 2 ? 2 : 1); ++j) {
+                                        const int i = 2 * h + j;
+                                        float w0_ = acc[xt][i][0], w1_ = acc[xt][i][1], w2_ = acc[xt][i][2], w3_ = acc[xt][i][3];
+                                        if (p.res) {
+                                            w0_ += bf16lo_to_f32(rw[2 * j]); w1_ += bf16hi_to_f32(rw[2 * j]);
+                                            w2_ += bf16lo_to_f32(rw[2 * j + 1]); w3_ += bf16hi_to_f32(rw[2 * j + 1]);
+                                        }
+                                        if (p.relu) { w0_ = fmaxf(w0_, 0.f); w1_ = fmaxf(w1_, 0.f); w2_ = fmaxf(w2_, 0.f); w3_ = fmaxf(w3_, 0.f); }
+                                        pk[2 * j] = pack_bf16x2(w0_, w1_); pk[2 * j + 1] = pack_bf16x2(w2_, w3_);
+                                        if constexpr (STATS) {
+                                            const float r0 = bf16lo_to_f32(pk[2 * j]), r1 = bf16hi_to_f32(pk[2 * j]);
+                                            const float r2 = bf16lo_to_f32(pk[2 * j + 1]), r3 = bf16hi_to_f32(pk[2 * j + 1]);
+                                            gs[4 * i] += r0; gs[4 * i + 1] += r1; gs[4 * i + 2] += r2; gs[4 * i + 3] += r3;
+                                            gq[4 * i] = fmaf(r0, r0, gq[4 * i]); gq[4 * i + 1] = fmaf(r1, r1, gq[4 * i + 1]);
+                                            gq[4 * i + 2] = fmaf(r2, r2, gq[4 * i + 2]); gq[4 * i + 3] = fmaf(r3, r3, gq[4 * i + 3]);
+                                        }
                                     }
-                                    if (p.relu) { w0_ = fmaxf(w0_, 0.f); w1_ = fmaxf(w1_, 0.f); w2_ = fmaxf(w2_, 0.f); w3_ = fmaxf(w3_, 0.f); }
-                                    const uint2 pk = make_uint2(pack_bf16x2(w0_, w1_), pack_bf16x2(w2_, w3_));
-                                    yp[i] = pk;
-                                    if constexpr (STATS) {
-                                        const float r0 = bf16lo_to_f32(pk.x), r1 = bf16hi_to_f32(pk.x), r2 = bf16lo_to_f32(pk.y), r3 = bf16hi_to_f32(pk.y);
-                                        gs[4 * i] += r0; gs[4 * i + 1] += r1; gs[4 * i + 2] += r2; gs[4 * i + 3] += r3;
-                                        gq[4 * i] = fmaf(r0, r0, gq[4 * i]); gq[4 * i + 1] = fmaf(r1, r1, gq[4 * i + 1]);
-                                        gq[4 * i + 2] = fmaf(r2, r2, gq[4 * i + 2]); gq[4 * i + 3] = fmaf(r3, r3, gq[4 * i + 3]);
-                                    }
+                                    if constexpr (NT >= 2) reinterpret_cast<uint4*>(p.y + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                                    else *reinterpret_cast<uint2*>(p.y + o) = make_uint2(pk[0], pk[1]);
                                 }
                             }
                 }
