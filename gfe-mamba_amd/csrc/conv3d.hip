@@ -92,6 +92,13 @@ struct ConvParams {
 
 struct TilePos { int b, td, th, tw; };
 
+#if defined(GFE_EXP_STAMP)     // diagnostic build only: in-kernel cycle stamps of one block (tools/conv_stamps.py); never in the product library
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define GFE_STAMP(slot) do { if (stamp_on && lane == 0 && stamp_i < 4096) { g_stamp_buf[(wave * 4096 + stamp_i) * 2] = (slot); g_stamp_buf[(wave * 4096 + stamp_i) * 2 + 1] = __builtin_amdgcn_s_memtime(); ++stamp_i; } } while (0)
+#else
+#define GFE_STAMP(slot) do {} while (0)
+#endif
+
 template <int NT, int TPS, bool REG27, bool STATS>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer/LDS-DMA builtins)
@@ -118,6 +125,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     const int nunits = (tile_end - tile_begin) * upt;
     if (nunits <= 0) return;
     const int nstage = (p.ntaps + TPS - 1) / TPS;
+#if defined(GFE_EXP_STAMP)
+    const bool stamp_on = g_stamp_buf != nullptr && blockIdx.x == 101;
+    int stamp_i = 0;
+#endif
 
     // ---- fragment read bases
     int abase[4];
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     }
 
     if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur.b, 0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
 
     for (int u = 0; u < nunits; ++u) {
@@ -238,13 +250,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 
         for (int s = 0; s < nstage; ++s, ++gstage) {
             // everything issued so far (this unit's tile, this stage's weights) has landed and is visible to all waves
+            GFE_STAMP(1);
 #if !defined(GFE_EXP_NOBAR)    // timing experiment only: no per-stage wait + barrier
-            // weight waves drain their pieces every stage; activation waves only where the tile changes hands (stage 0)
-            if (!a_wave || s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // weight waves drain their pieces every stage but the first: at s == 0 everything a wave had issued (weights of this
+            // stage, the unit's tile) was drained BEFORE the previous unit's epilogue (below), so that epilogue's stores stay in
+            // flight across this barrier instead of being waited for (vmcnt retires in order)
+            if (!a_wave && s > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): no LDS read of the previous stage is still pending
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");                   // no LDS access is scheduled across the barrier
 #endif
+            GFE_STAMP(2);
             // refill the buffers nobody reads any more: next stage's weights, and (once per unit) the next unit's tile
 #if !defined(GFE_EXP_NOW)      // timing experiment only: weights are never restaged
             if (!a_wave) {
@@ -253,10 +269,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             }
 #endif
 #if !defined(GFE_EXP_NOA)      // timing experiment only: the activation tile is never restaged
-            // issued as one burst in stage 0 (spreading the 16 pieces over the unit's stages measured 6 % slower: every stage pays)
+            // issued as one burst in stage 0 by the four activation waves.  Measured alternatives, all slower on 64->64 @96^3 (1.58 ms):
+            // 2 pieces per stage (1.93), every wave 1/8 of the tile in "its" stage (1.79), all DMA on the weight waves (1.67), block-
+            // staggered burst stage (no change), and an address-arithmetic-free burst with the tile origin in the scalar offset
+            // (2.11: the 64 misses then sit in front of the next stages' weight pieces in the CU's in-order vector-memory path)
             if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE);
 #endif
 
+            GFE_STAMP(3);
             const uint8_t* wb = sW + (gstage & 1) * (W_PIECES * 1024) + wbase;
             if constexpr (REG27) {
                 // regular 3x3x3: stage s = (kd, kh), taps kw = 0..2 -> one base per voxel tile + immediate offsets
@@ -265,20 +285,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 int ax[4];
 #pragma unroll
                 for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
+                // software pipeline over the stage's taps: the 8 fragment reads of tap t+1 are in flight while the 16 MFMAs of tap t
+                // issue (two register sets), so only the first tap of a stage exposes the LDS latency
+                bf16x8 xf[STATS ? 1 : 2][4], wf[STATS ? 1 : 2][NT];
+                auto frag_load = [&](int tl, int set) {
+#pragma unroll
+                    for (int xt = 0; xt < 4; ++xt) xf[set][xt] = *reinterpret_cast<const bf16x8*>(aT + ax[xt] + tl * VSTRIDE);
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) wf[set][ct] = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
+                };
+                constexpr bool PIPE = !STATS;         // the second register set does not fit beside the GroupNorm partials (spills)
+                if constexpr (PIPE) { frag_load(0, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
-                    // all 8 fragments of the tap first (one LDS wait per 16 MFMAs), then the MFMA cluster at raised priority
-                    bf16x8 xf[4], wf[NT];
-#pragma unroll
-                    for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(aT + ax[xt] + tl * VSTRIDE);
-#pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) wf[ct] = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
+                    const int set = PIPE ? (tl & 1) : 0;
+                    if constexpr (PIPE) { if (tl + 1 < TPS) frag_load(tl + 1, (tl + 1) & 1); }
+                    else frag_load(tl, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                        for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[ct], xf[xt], acc[xt][ct]);
+                        for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[set][ct], xf[set][xt], acc[xt][ct]);
                     __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
@@ -299,6 +329,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 }
             }
         }
+
+        GFE_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // see the stage barrier: nothing but the epilogue's stores crosses the unit boundary
 
 #if defined(GFE_EXP_NOEPI)     // timing experiment only: results are never stored
         if (slab == p.nslab - 1 && u + 1 == nunits) {
@@ -426,6 +459,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 }
             }
         }
+        GFE_STAMP(5);
         if (ut + 1 == upt) advance(cur);
     }
 #endif
@@ -506,6 +540,10 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
 extern "C" {
 
 int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W) { return (int)(ceil_div(D, TD) * ceil_div(H, TH) * ceil_div(W, TW)); }
+
+#if defined(GFE_EXP_STAMP)
+int gfe_debug_set_stamp_buffer(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -4; }
+#endif
 
 int gfe_conv3d_cout_pad(int64_t Cout) {
     if (Cout <= 16) return 16;
