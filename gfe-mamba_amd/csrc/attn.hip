@@ -1,0 +1,222 @@
+// Flash-style fused attention forward for gfx950: O = softmax(Q K^T * scale) V per (batch, head), head dim 64, any sequence
+// length (vit_pytorch_diy/vit_3d.py:47-57; the 1729-token synthetic 3-D ViT of SURVEY 8-d).  bf16 MFMA 32x32x16, f32 softmax.
+//
+// Block = 4 waves, 128 query rows (32 per wave); K/V tiles of 64 keys stream through a 2-deep LDS ring (register-prefetched: the
+// global loads of tile t+1 fly under the MFMAs of tile t), one barrier per tile.
+// Everything a lane owns belongs to ONE query row q = lane & 31 (both products are computed transposed):
+//   S^T = K Q^T : A = K tile rows (ds_read_b128 from the swizzled [key][d] image), B = Q fragments kept in registers.
+//                 C: lane (q, hi = lane >> 5) holds keys (r&3) + 8(r>>2) + 4hi of each 32-key block -> row max / row sum are
+//                 in-lane reductions plus ONE exchange with lane ^ 32.
+//   O^T = V^T P^T: A = V^T fragments read straight out of the row-major [key][d] V tile with ds_read_b64_tr_b16 (hardware
+//                 transpose), B = P packed to bf16; the two halves of a 16-key slot are exchanged with v_permlane32_swap.
+//                 C: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi (+32) of ITS row -> the online-softmax rescale is a per-lane
+//                 scalar, no cross-lane traffic at all.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+namespace {
+
+constexpr int AD = 64;            // head dim
+constexpr int QW = 32;            // query rows per wave
+constexpr int ANW = 4;            // waves per block
+constexpr int KT = 64;            // keys per tile
+constexpr int TILE_BYTES = KT * AD * 2;     // 8 KiB
+
+struct AttnParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    int64_t q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row;    // element strides
+    int H, n;
+    float c;                      // scale * log2(e): scores are kept in log2 units
+};
+
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// K image: 128-B rows, 16-B chunk c of row r at slot c ^ (r & 7) (conflict-free ds_read_b128 of 32 rows x 2 chunks)
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) * 16); }
+// V image: 128-B rows; chunk c of key-row r at slot c ^ (((r >> 1) & 1) << 2): the 4 key-rows x 64 B one half-wave gathers with
+// ds_read_b64_tr_b16 then cover 64 distinct banks
+__device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) * 16); }
+
+__global__ __launch_bounds__(ANW * 64, 2) void attn_fwd_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * TILE_BYTES];      // K[2], V[2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * (ANW * QW) + wave * QW;
+    const bf16_t* kb = p.k + (size_t)b * p.k_batch + h * AD;
+    const bf16_t* vb = p.v + (size_t)b * p.v_batch + h * AD;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds d = 16*ds + 8*hi + 0..7
+    bf16x8 qf[4];
+    {
+        const int q = q0 + ql;
+        const bf16_t* qp = p.q + (size_t)b * p.q_batch + (size_t)(q < p.n ? q : 0) * p.q_row + h * AD + 8 * hi;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            uint4 t = *reinterpret_cast<const uint4*>(qp + 16 * ds);
+            if (q >= p.n) t = make_uint4(0, 0, 0, 0);
+            qf[ds] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;          // running max (log2 units) and this lane's share of the row sum
+
+    const int ntile = (p.n + KT - 1) / KT;
+    uint4 rk[2], rv[2];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+            const int key = t * KT + row;
+            if (key < p.n) {
+                rk[i] = *reinterpret_cast<const uint4*>(kb + (size_t)key * p.k_row + c * 8);
+                rv[i] = *reinterpret_cast<const uint4*>(vb + (size_t)key * p.v_row + c * 8);
+            } else {
+                rk[i] = make_uint4(0, 0, 0, 0); rv[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        uint8_t* sk = smem + buf * TILE_BYTES;
+        uint8_t* sv = smem + (2 + buf) * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4*>(sk + k_off(row, c)) = rk[i];
+            *reinterpret_cast<uint4*>(sv + v_off(row, c)) = rv[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const bool more = t + 1 < ntile;
+        if (more) gload(t + 1);
+        const uint8_t* sk = smem + (t & 1) * TILE_BYTES;
+        const uint8_t* sv = smem + (2 + (t & 1)) * TILE_BYTES;
+
+        // ---- S^T = K Q^T: two 32-key blocks x four 16-wide d steps
+        f32x16 s[2];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(32 * kb2 + ql, 2 * ds + hi));
+                s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb2], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over this tile's 64 keys (this lane: 32 of them, lane ^ 32: the others)
+        if (t == ntile - 1 && (p.n & (KT - 1))) {                      // ragged last tile: keys >= n do not exist
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * KT + 32 * kb2 + crow(r, hi) >= p.n) s[kb2][r] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb2][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * p.c);                       // finite: every tile holds at least one real key
+        const float alpha = fast_exp2(m - m_new);
+        m = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = fast_exp2(fmaf(s[kb2][r], p.c, -m_new));
+                s[kb2][r] = e; psum += e;
+            }
+        lsum = fmaf(lsum, alpha, psum);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+        // ---- P -> bf16 B operands.  16-key slot ks = 2*kb2 + tt: lane hi=0 must hold keys 0..7 of the slot, hi=1 keys 8..15;
+        // it owns {0..3, 8..11} + 4hi -> one v_permlane32_swap per word pair exchanges the misplaced halves.
+        bf16x8 pb[4];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const uint32_t w0 = pack_bf16x2(s[kb2][8 * tt], s[kb2][8 * tt + 1]), w1 = pack_bf16x2(s[kb2][8 * tt + 2], s[kb2][8 * tt + 3]);
+                const uint32_t w2 = pack_bf16x2(s[kb2][8 * tt + 4], s[kb2][8 * tt + 5]), w3 = pack_bf16x2(s[kb2][8 * tt + 6], s[kb2][8 * tt + 7]);
+                const auto x0 = __builtin_amdgcn_permlane32_swap(w0, w2, false, false);
+                const auto x1 = __builtin_amdgcn_permlane32_swap(w1, w3, false, false);
+                const uint4 u = make_uint4(x0[0], x1[0], x0[1], x1[1]);
+                pb[2 * kb2 + tt] = __builtin_bit_cast(bf16x8, u);
+            }
+        // ---- O^T += V^T P^T: two 32-wide d blocks x four 16-key slots; A fragments by transposing reads of the [key][d] tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                // 16-lane group g = lane >> 4: d columns 32*db + 16*(g & 1) .. +15, keys 16*ks + 8*(g >> 1) + {0..3 | 4..7}
+                const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+                const int key0 = 16 * ks + 8 * (g >> 1) + qq;
+                const int chunk = 4 * db + 2 * (g & 1) + (pp >> 1);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0, chunk) + 8 * (pp & 1)));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0 + 4, chunk) + 8 * (pp & 1)));
+                union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+                u.h.a = lo; u.h.b = hi4;
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pb[ks], oacc[db], 0, 0, 0);
+            }
+        }
+        if (more) lstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (q, hi) holds d = 32*db + crow(r, hi) of its row
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + ql;
+    if (q < p.n) {
+        bf16_t* op = p.o + (size_t)b * p.o_batch + (size_t)q * p.o_row + h * AD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = 32 * db + 8 * r4 + 4 * hi;
+                *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf16x2(oacc[db][4 * r4] * inv, oacc[db][4 * r4 + 1] * inv),
+                                                               pack_bf16x2(oacc[db][4 * r4 + 2] * inv, oacc[db][4 * r4 + 3] * inv));
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t n, int64_t dh,
+                      int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
+                      int64_t o_batch, int64_t o_row, float scale, void* stream) {
+    GFE_REQUIRE(q && k && v && o, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && H > 0 && n > 0 && dh == AD && B * H <= 65535 && n <= 0x7fffffff, GFE_ERR_SHAPE);
+    GFE_REQUIRE(q_row % 8 == 0 && k_row % 8 == 0 && v_row % 8 == 0 && o_row % 4 == 0, GFE_ERR_SHAPE);       // 16-byte loads, 8-byte stores
+    GFE_REQUIRE(q_batch % 8 == 0 && k_batch % 8 == 0 && v_batch % 8 == 0 && o_batch % 4 == 0, GFE_ERR_SHAPE);
+    AttnParams p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
+    p.q_batch = q_batch; p.q_row = q_row; p.k_batch = k_batch; p.k_row = k_row; p.v_batch = v_batch; p.v_row = v_row;
+    p.o_batch = o_batch; p.o_row = o_row; p.H = (int)H; p.n = (int)n; p.c = scale * GFE_LOG2E;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)ceil_div(n, ANW * QW), (unsigned)(B * H)), dim3(ANW * 64), 0, (hipStream_t)stream, p);
+    return gfe_launch_status();
+}
+
+}  // extern "C"

@@ -293,6 +293,16 @@ def layernorm(x, gamma, beta, rows, length, out_dtype, in_map=None, out_map=None
     return out
 
 
+def attention_fwd(q, k, v, B, H, n, dh, scale):
+    """Flash-style attention for long sequences (gfe_attention_fwd): q/k/v (B*n, >= H*dh) bf16 views with a common layout
+    (row strides allowed), dh == 64 -> (B*n, H*dh) bf16."""
+    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    o = torch.empty((B * n, H * dh), dtype=BF16, device=q.device)
+    call("gfe_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), B, H, n, dh, n * q.stride(0), q.stride(0), n * k.stride(0), k.stride(0),
+         n * v.stride(0), v.stride(0), n * H * dh, H * dh, float(scale), stream())
+    return o
+
+
 def attention_small(q, k, v, B, H, nq, nk, dh, scale):
     """q: (B*nq, >=H*dh) view, k/v: (B*nk, ...) views (row strides allowed) -> (B*nq, H*dh) bf16."""
     o = torch.empty((B * nq, H * dh), dtype=BF16, device=q.device)

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 10
+#define GFE_ABI_VERSION 11
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -206,6 +206,13 @@ int gfe_layernorm(const void* x, void* y, const float* gamma, const float* beta,
 int gfe_attention_small(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dh,
                         int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
                         int64_t o_batch, int64_t o_row, float scale, void* stream);
+
+/* The same product for long sequences (flash-style: K/V tiles of 64 keys, online softmax, bf16 MFMA 32x32x16, f32 statistics):
+ * the attention of vit_pytorch_diy/vit_3d.py:47-57 (SURVEY 8-d synthetic 3-D ViT, n = 1729).  dh == 64, any n >= 1; q/k/v/o
+ * addressed as in gfe_attention_small (row strides multiples of 8 elements for q/k/v, 4 for o). */
+int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t n, int64_t dh,
+                      int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
+                      int64_t o_batch, int64_t o_row, float scale, void* stream);
 
 /* from_patch_embedding's Linear over the token axis (vit.py:104-106): y[b][j][:] = sum_i W[j][i] x[b][i][:] + bias[j].
  * x: (B, nin, dim) f32|bf16, W: (nout, nin) f32, y: (B, nout, dim) bf16. */

@@ -217,3 +217,19 @@ def test_fused_groupnorm_partials_match_the_statistics_pass(C, shape):
     skip = torch.randn(B, 2 * D, 2 * H, 2 * W, C, generator=g).to(BF).to(DEV)
     with torch.no_grad():
         check(up(skip, x))
+
+
+@pytest.mark.parametrize("B,H,n", [(2, 8, 1729), (1, 2, 64), (1, 3, 65), (2, 1, 127), (1, 2, 300), (1, 1, 1)])
+def test_flash_attention_vs_softmax_reference(B, H, n):
+    """gfe_attention_fwd (MFMA, online softmax) against softmax(q k^T / sqrt(d)) v in f64 on the same bf16 inputs
+    (vit_3d.py:47-57): ragged last key tile, ragged last query block, single token."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(n)
+    dh = 64
+    qkv = (torch.randn(B * n, 3 * H * dh, generator=g) * 1.5).to(BF).to(DEV)
+    inner = H * dh
+    o = K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, n, dh, dh ** -0.5)
+    q, k, v = [t.double().view(B, n, H, dh).transpose(1, 2) for t in qkv.cpu().chunk(3, dim=-1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * n, inner)
+    assert rel_err(o, ref) < TOL, rel_err(o, ref)
+    assert (o.float().cpu() - ref.float()).abs().max() < 0.05
