@@ -131,7 +131,10 @@ __global__ __launch_bounds__(ANW * 64, 2) void attn_fwd_kernel(const AttnParams 
         for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb2][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
+            const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
+        }
         const float m_new = fmaxf(m, mx * p.c);                       // finite: every tile holds at least one real key
         const float alpha = fast_exp2(m - m_new);
         m = m_new;
@@ -144,10 +147,12 @@ __global__ __launch_bounds__(ANW * 64, 2) void attn_fwd_kernel(const AttnParams 
                 s[kb2][r] = e; psum += e;
             }
         lsum = fmaf(lsum, alpha, psum);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {              // wave-uniform: once the row maxima settle nothing is rescaled
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
 
         // ---- P -> bf16 B operands.  16-key slot ks = 2*kb2 + tt: lane hi=0 must hold keys 0..7 of the slot, hi=1 keys 8..15;
         // it owns {0..3, 8..11} + 4hi -> one v_permlane32_swap per word pair exchanges the misplaced halves.

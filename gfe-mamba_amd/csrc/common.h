@@ -25,8 +25,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
+// one v_cvt_pk_bf16_f32 for the pair (the scalar casts above cost two converts plus a shift/or to merge)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
