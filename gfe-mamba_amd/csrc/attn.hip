@@ -1,8 +1,8 @@
 // Flash-style fused attention forward for gfx950: O = softmax(Q K^T * scale) V per (batch, head), head dim 64, any sequence
 // length (vit_pytorch_diy/vit_3d.py:47-57; the 1729-token synthetic 3-D ViT of SURVEY 8-d).  bf16 MFMA 32x32x16, f32 softmax.
 //
-// Block = 4 waves, 128 query rows (32 per wave); K/V tiles of 64 keys stream through a 2-deep LDS ring (register-prefetched: the
-// global loads of tile t+1 fly under the MFMAs of tile t), one barrier per tile.
+// Block = 8 waves, 256 query rows (32 per wave); K/V tiles of 64 keys stream through a 2-deep LDS ring filled by LDS-DMA (the pieces
+// of tile t+1 fly under the MFMAs of tile t), one barrier per tile; the softmax advances 32 keys at a time (16 score registers).
 // Everything a lane owns belongs to ONE query row q = lane & 31 (both products are computed transposed):
 //   S^T = K Q^T : A = K tile rows (ds_read_b128 from the swizzled [key][d] image), B = Q fragments kept in registers.
 //                 C: lane (q, hi = lane >> 5) holds keys (r&3) + 8(r>>2) + 4hi of each 32-key block -> row max / row sum are
@@ -17,12 +17,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_t;
 
 namespace {
 
 constexpr int AD = 64;            // head dim
 constexpr int QW = 32;            // query rows per wave
-constexpr int ANW = 4;            // waves per block
+#ifndef GFE_ATTN_WAVES
+#define GFE_ATTN_WAVES 8
+#endif
+constexpr int ANW = GFE_ATTN_WAVES;            // waves per block
 constexpr int KT = 64;            // keys per tile
 constexpr int TILE_BYTES = KT * AD * 2;     // 8 KiB
 
@@ -41,7 +45,8 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((
 // ds_read_b64_tr_b16 then cover 64 distinct banks
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) * 16); }
 
-__global__ __launch_bounds__(ANW * 64, 2) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ANW * 64, 16 / ANW) void attn_fwd_kernel(const AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer / LDS-DMA builtins)
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * TILE_BYTES];      // K[2], V[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, hi = lane >> 5;
@@ -71,120 +76,106 @@ __global__ __launch_bounds__(ANW * 64, 2) void attn_fwd_kernel(const AttnParams 
     float m = -INFINITY, lsum = 0.f;          // running max (log2 units) and this lane's share of the row sum
 
     const int ntile = (p.n + KT - 1) / KT;
-    uint4 rk[2], rv[2];
-    auto gload = [&](int t) {
+    // K/V tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, no staging registers): lane L of a piece fills
+    // LDS slot L&7 of row L>>3, so it fetches the source chunk that the image's swizzle assigns to that slot.  Keys >= n lie beyond
+    // num_records of the descriptor -> the hardware writes zeros.
+    const unsigned row_bytes_k = (unsigned)(p.k_row * 2), row_bytes_v = (unsigned)(p.v_row * 2);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((unsigned)(p.n - 1) * row_bytes_k + AD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((unsigned)(p.n - 1) * row_bytes_v + AD * 2), 0x00020000);
+    auto dma = [&](int t, int buf) {
+        // 16 pieces per tile pair (8 K + 8 V), 4 per wave: piece pc = wave + 4*i covers rows 8*pc .. 8*pc+7 of K (i < 2) or V
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-            const int key = t * KT + row;
-            if (key < p.n) {
-                rk[i] = *reinterpret_cast<const uint4*>(kb + (size_t)key * p.k_row + c * 8);
-                rv[i] = *reinterpret_cast<const uint4*>(vb + (size_t)key * p.v_row + c * 8);
-            } else {
-                rk[i] = make_uint4(0, 0, 0, 0); rv[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-        uint8_t* sk = smem + buf * TILE_BYTES;
-        uint8_t* sv = smem + (2 + buf) * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4*>(sk + k_off(row, c)) = rk[i];
-            *reinterpret_cast<uint4*>(sv + v_off(row, c)) = rv[i];
+        for (int i = 0; i < 8 / ANW; ++i) {
+            const int pc = wave + ANW * i, row = 8 * pc + (lane >> 3), slot = lane & 7;
+            const unsigned key = (unsigned)(t * KT + row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t)(smem + buf * TILE_BYTES + pc * 1024), 16,
+                                                     key * row_bytes_k + ((slot ^ (row & 7)) * 16), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t)(smem + (2 + buf) * TILE_BYTES + pc * 1024), 16,
+                                                     key * row_bytes_v + ((slot ^ (((row >> 1) & 1) << 2)) * 16), 0, 0, 0);
         }
     };
 
-    gload(0);
-    lstore(0);
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
-        const bool more = t + 1 < ntile;
-        if (more) gload(t + 1);
+        if (t + 1 < ntile) dma(t + 1, (t + 1) & 1);                  // lands under this tile's MFMAs; nobody reads that buffer any more
         const uint8_t* sk = smem + (t & 1) * TILE_BYTES;
         const uint8_t* sv = smem + (2 + (t & 1)) * TILE_BYTES;
+        const bool ragged = t == ntile - 1 && (p.n & (KT - 1));
 
-        // ---- S^T = K Q^T: two 32-key blocks x four 16-wide d steps
-        f32x16 s[2];
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2) {
+            // ---- S^T = K Q^T for a 32-key block: four 16-wide d steps
+            f32x16 s;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(32 * kb2 + ql, 2 * ds + hi));
-                s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb2], 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s, 0, 0, 0);
             }
-        }
-        // ---- online softmax over this tile's 64 keys (this lane: 32 of them, lane ^ 32: the others)
-        if (t == ntile - 1 && (p.n & (KT - 1))) {                      // ragged last tile: keys >= n do not exist
-#pragma unroll
-            for (int kb2 = 0; kb2 < 2; ++kb2)
+            // ---- online softmax over the block's 32 keys (this lane: 16 of them, lane ^ 32: the others)
+            if (ragged) {                                                // keys >= n do not exist
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (t * KT + 32 * kb2 + crow(r, hi) >= p.n) s[kb2][r] = -INFINITY;
-        }
-        float mx = s[0][0];
+                    if (t * KT + 32 * kb2 + crow(r, hi) >= p.n) s[r] = -INFINITY;
+            }
+            float mx = s[0];
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb2][r]);
-        {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
-            const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
-        }
-        const float m_new = fmaxf(m, mx * p.c);                       // finite: every tile holds at least one real key
-        const float alpha = fast_exp2(m - m_new);
-        m = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
+                const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
+            }
+            const float m_new = fmaxf(m, mx * p.c);                   // -inf only for an all-masked block (then every p is 0)
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = fast_exp2(m - m_use);
+            m = m_new;
+            float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = fast_exp2(fmaf(s[kb2][r], p.c, -m_new));
-                s[kb2][r] = e; psum += e;
+                const float e = fast_exp2(fmaf(s[r], p.c, -m_use));
+                s[r] = e; psum += e;
             }
-        lsum = fmaf(lsum, alpha, psum);
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {              // wave-uniform: once the row maxima settle nothing is rescaled
+            lsum = fmaf(lsum, alpha, psum);
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {          // wave-uniform: once the row maxima settle nothing is rescaled
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-        }
-
-        // ---- P -> bf16 B operands.  16-key slot ks = 2*kb2 + tt: lane hi=0 must hold keys 0..7 of the slot, hi=1 keys 8..15;
-        // it owns {0..3, 8..11} + 4hi -> one v_permlane32_swap per word pair exchanges the misplaced halves.
-        bf16x8 pb[4];
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+            // ---- P -> bf16 B operands.  16-key slot tt of the block: lane hi=0 must hold keys 0..7 of the slot, hi=1 keys 8..15;
+            // it owns {0..3, 8..11} + 4hi -> one v_permlane32_swap per word pair exchanges the misplaced halves.
+            bf16x8 pb[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const uint32_t w0 = pack_bf16x2(s[kb2][8 * tt], s[kb2][8 * tt + 1]), w1 = pack_bf16x2(s[kb2][8 * tt + 2], s[kb2][8 * tt + 3]);
-                const uint32_t w2 = pack_bf16x2(s[kb2][8 * tt + 4], s[kb2][8 * tt + 5]), w3 = pack_bf16x2(s[kb2][8 * tt + 6], s[kb2][8 * tt + 7]);
+                const uint32_t w0 = pack_bf16x2(s[8 * tt], s[8 * tt + 1]), w1 = pack_bf16x2(s[8 * tt + 2], s[8 * tt + 3]);
+                const uint32_t w2 = pack_bf16x2(s[8 * tt + 4], s[8 * tt + 5]), w3 = pack_bf16x2(s[8 * tt + 6], s[8 * tt + 7]);
                 const auto x0 = __builtin_amdgcn_permlane32_swap(w0, w2, false, false);
                 const auto x1 = __builtin_amdgcn_permlane32_swap(w1, w3, false, false);
                 const uint4 u = make_uint4(x0[0], x1[0], x0[1], x1[1]);
-                pb[2 * kb2 + tt] = __builtin_bit_cast(bf16x8, u);
+                pb[tt] = __builtin_bit_cast(bf16x8, u);
             }
-        // ---- O^T += V^T P^T: two 32-wide d blocks x four 16-key slots; A fragments by transposing reads of the [key][d] tile
+            // ---- O^T += V^T P^T: two 32-wide d blocks x the block's two 16-key slots; A fragments by transposing reads of [key][d]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+            for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                // 16-lane group g = lane >> 4: d columns 32*db + 16*(g & 1) .. +15, keys 16*ks + 8*(g >> 1) + {0..3 | 4..7}
-                const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-                const int key0 = 16 * ks + 8 * (g >> 1) + qq;
-                const int chunk = 4 * db + 2 * (g & 1) + (pp >> 1);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0, chunk) + 8 * (pp & 1)));
-                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0 + 4, chunk) + 8 * (pp & 1)));
-                union { struct { s16x4 a, b; } h; bf16x8 v; } u;
-                u.h.a = lo; u.h.b = hi4;
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pb[ks], oacc[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) {
+                    // 16-lane group g = lane >> 4: d columns 32*db + 16*(g & 1) .. +15, keys 16*ks + 8*(g >> 1) + {0..3 | 4..7}
+                    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+                    const int key0 = 32 * kb2 + 16 * tt + 8 * (g >> 1) + qq;
+                    const int chunk = 4 * db + 2 * (g & 1) + (pp >> 1);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0, chunk) + 8 * (pp & 1)));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0 + 4, chunk) + 8 * (pp & 1)));
+                    union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+                    u.h.a = lo; u.h.b = hi4;
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pb[tt], oacc[db], 0, 0, 0);
+                }
             }
         }
-        if (more) lstore((t + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile landed (this wave's pieces); the barrier makes all of it visible
         __syncthreads();
     }
 
@@ -203,6 +194,7 @@ __global__ __launch_bounds__(ANW * 64, 2) void attn_fwd_kernel(const AttnParams 
                                                                pack_bf16x2(oacc[db][4 * r4 + 2] * inv, oacc[db][4 * r4 + 3] * inv));
             }
     }
+#endif
 }
 
 }  // namespace

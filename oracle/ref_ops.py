@@ -295,6 +295,31 @@ def vit_mid(img, sd, pre, patch, heads, depth):
     return unpatchify(x, patch, H // patch, c)                       # :109
 
 
+def patchify3d(video, pf, p1, p2):
+    """'b c (f pf) (h p1) (w p2) -> b (f h w) (p1 p2 pf c)' (vit_pytorch_diy/vit_3d.py:93)."""
+    b, c, F_, H, W = video.shape
+    f, h, w = F_ // pf, H // p1, W // p2
+    return video.view(b, c, f, pf, h, p1, w, p2).permute(0, 2, 4, 6, 5, 7, 3, 1).reshape(b, f * h * w, p1 * p2 * pf * c)
+
+
+def vit3d(video, sd, pre, frame_patch, patch, heads, depth, pool="cls"):
+    """vit_3d.ViT.forward (vit_3d.py:113-128), eval mode: no final transformer norm, cls / mean pool, mlp_head."""
+    b = video.shape[0]
+    x = patchify3d(video, frame_patch, patch, patch)
+    x = _ln(x, sd, pre + "to_patch_embedding.1.")
+    x = _linear(x, sd, pre + "to_patch_embedding.2.")
+    x = _ln(x, sd, pre + "to_patch_embedding.3.")
+    tokens = x
+    n = x.shape[1]
+    x = torch.cat((sd[pre + "cls_token"].expand(b, -1, -1), x), dim=1)
+    x = x + sd[pre + "pos_embedding"][:, :n + 1]
+    for l in range(depth):
+        x = vit_attention(x, sd, f"{pre}transformer.layers.{l}.0.", heads) + x
+        x = vit_feedforward(x, sd, f"{pre}transformer.layers.{l}.1.") + x
+    x = x.mean(dim=1) if pool == "mean" else x[:, 0]
+    return _linear(_ln(x, sd, pre + "mlp_head.0."), sd, pre + "mlp_head.1."), tokens
+
+
 def nearest_resize(x, size):
     """F.interpolate(x, size) default nearest (buildingblocks.py:523-531): dst i <- src floor(i*in/out)."""
     for dim, s in zip((2, 3, 4), size):

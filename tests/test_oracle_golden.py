@@ -101,6 +101,16 @@ def test_vit():
     assert rel_err(out, tt(fx["out"])) < TOL
 
 
+def test_vit3d():
+    for tag, pf, p in (("a", 8, 8), ("b", 8, 4)):
+        fx = golden(f"t0_vit3d_{tag}.npz")
+        sd = sub_sd(fx, "sd.")
+        out, tok = O.vit3d(tt(fx["x"]), sd, "", frame_patch=pf, patch=p, heads=2, depth=2)
+        assert rel_err(tok, tt(fx["tokens"])) < TOL and rel_err(out, tt(fx["out"])) < TOL
+        out_mean, _ = O.vit3d(tt(fx["x"]), sd, "", frame_patch=pf, patch=p, heads=2, depth=2, pool="mean")
+        assert rel_err(out_mean, tt(fx["out_mean"])) < TOL
+
+
 def test_index_maps_bit_exact():
     fx = golden("t0_index_maps.npz")
     for name, shp in (("native", (40, 40, 24)), ("g96", (24, 24, 24)), ("g128", (32, 32, 32)), ("g32", (8, 8, 8))):

@@ -233,3 +233,20 @@ def test_flash_attention_vs_softmax_reference(B, H, n):
     ref = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * n, inner)
     assert rel_err(o, ref) < TOL, rel_err(o, ref)
     assert (o.float().cpu() - ref.float()).abs().max() < 0.05
+
+
+@pytest.mark.parametrize("tag,kw", [("a", dict(image_size=16, image_patch_size=8, frames=16, frame_patch_size=8, channels=2)),
+                                    ("b", dict(image_size=16, image_patch_size=4, frames=48, frame_patch_size=8, channels=1))])
+def test_vit3d_vs_reference_fixture(tag, kw):
+    """vit_3d.ViT twin (flash-attention kernel inside) against outputs of the reference module (vit_3d.py:78-128)."""
+    from vit_pytorch_diy.vit_3d import ViT
+    fx = golden(f"t0_vit3d_{tag}.npz")
+    m = ViT(num_classes=3, dim=128, depth=2, heads=2, dim_head=64, mlp_dim=256, pool="cls", **kw)
+    m.load_state_dict(sub_sd(fx, "sd."))
+    m = m.to(DEV).eval()
+    x = tt(fx["x"]).to(DEV)
+    with torch.no_grad():
+        assert rel_err(m.tokens(x), tt(fx["tokens"])) < TOL
+        assert rel_err(m(x), tt(fx["out"])) < 2e-2
+        m.pool = "mean"
+        assert rel_err(m(x), tt(fx["out_mean"])) < 2e-2

@@ -48,8 +48,9 @@ def import_reference():
     import pytorch3dunet.unet3d.model as r_model
     import pytorch3dunet.unet3d.buildingblocks as r_bb
     import vit_pytorch_diy.vit as r_vit
+    import vit_pytorch_diy.vit_3d as r_vit3d
     return types.SimpleNamespace(pscan=r_pscan, mamba=r_mamba, xattn=r_xattn, ft=r_ft, mt=r_mt, cls=r_cls,
-                                 model=r_model, bb=r_bb, vit=r_vit)
+                                 model=r_model, bb=r_bb, vit=r_vit, vit3d=r_vit3d)
 
 
 def npy(t):
@@ -199,6 +200,21 @@ def t0(R, out):
     fx.update({"sd." + k: npy(v) for k, v in sd.items()})
     fx.update(x=npy(xi), out=npy(vit(xi)), tokens=npy(vit.to_patch_embedding(xi)))
     np.savez_compressed(os.path.join(out, "t0_vit.npz"), **fx)
+
+    # --- vit_3d.ViT (the synthetic MFMA-attention row of SURVEY 8-d, reduced): 2 channels, 16^3 volume, 8^3 patches, 9 tokens,
+    # plus a 16x16x48 volume with 4x4x8 patches (97 tokens: more than one key tile, ragged)
+    for tag, kw, shape in (("a", dict(image_size=16, image_patch_size=8, frames=16, frame_patch_size=8, channels=2), (2, 2, 16, 16, 16)),
+                           ("b", dict(image_size=16, image_patch_size=4, frames=48, frame_patch_size=8, channels=1), (1, 1, 48, 16, 16))):
+        fx = {}
+        v3 = R.vit3d.ViT(num_classes=3, dim=128, depth=2, heads=2, dim_head=64, mlp_dim=256, pool="cls", **kw).eval()
+        sd = load_det(v3, seed=9, prefix="t0vit3d" + tag + ".")
+        xi = rnd_det("vit3d.x" + tag, shape)
+        fx.update({"sd." + k: npy(v) for k, v in sd.items()})
+        tok = v3.to_patch_embedding(xi)
+        fx.update(x=npy(xi), out=npy(v3(xi)), tokens=npy(tok))
+        v3.pool = "mean"
+        fx.update(out_mean=npy(v3(xi)))
+        np.savez_compressed(os.path.join(out, "t0_vit3d_" + tag + ".npz"), **fx)
 
     # --- pure index maps, as exact integers
     from einops import rearrange
