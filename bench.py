@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- measures BASELINE.json's metric on MI355X and prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan|vit3d]
 
 workload `step` (default): one classify_mamba training step (frozen generator fwd + head fwd/bwd + per-parameter
 clip + Adam) on a synthetic batch of 8 volumes of 96^3 per GPU (BASELINE config 5's per-GPU share == config 3 + bwd).
 workload `scan`: BASELINE config 2, the fused selective scan alone (L=4096, ED=1024, N=16, bf16), fwd+bwd.
+workload `vit3d`: the synthetic 3-D ViT of SURVEY 8-d (96^3, 8^3 patches -> 1729 tokens, dim 512, depth 4, 8 heads x 64), forward;
+its roofline object is the flash-attention kernel against the bf16 MFMA peak.
 
 For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU (RCCL).  The timed region is
 bracketed by barrier + synchronize on both sides; the reported time is the max over ranks.
@@ -108,12 +110,63 @@ class ScanWorkload:
                 "sample": f"oracle/scan_ref.c, B=1 L=4096, {ch}/{self.ED} channels, forward only, scaled to ED={self.ED}"}
 
 
+class Vit3dWorkload:
+    """SURVEY 8-d "MFMA 3D-ViT attention row": vit_3d.ViT(image_size=96, image_patch_size=8, frames=96, frame_patch_size=8,
+    channels=1, dim=512, depth=4, heads=8, dim_head=64, mlp_dim=2048, num_classes=1), B volumes of 96^3, bf16 GEMM/attention
+    operands, deterministic random-init weights.  Synthetic: the reference never instantiates this module."""
+    name = "vit_3d.ViT forward, 96^3 / 8^3 patches = 1729 tokens, dim 512 depth 4 heads 8x64 (synthetic, SURVEY 8-d)"
+
+    def __init__(self, batch):
+        import gfe_hip.det_init as det
+        from vit_pytorch_diy.vit_3d import ViT
+        self.B = batch
+        m = ViT(image_size=96, image_patch_size=8, frames=96, frame_patch_size=8, channels=1, dim=512, depth=4, heads=8,
+                dim_head=64, mlp_dim=2048, num_classes=1)
+        m.load_state_dict(det.det_state_dict(m.state_dict(), seed=21, prefix="vit3d."))
+        self.m = m.cuda().eval()
+        g = torch.Generator().manual_seed(0)
+        self.x = torch.randn(batch, 1, 96, 96, 96, generator=g).clamp_(-1, 1).cuda()
+        self.units = batch
+        self.n, self.H, self.dh = 1729, 8, 64
+
+    def step(self):
+        with torch.no_grad():
+            return self.m(self.x)
+
+    def roofline(self, iters=50):
+        from gfe_hip import nn_ops as K
+        B, n, H, dh = self.B, self.n, self.H, self.dh
+        g = torch.Generator().manual_seed(1)
+        qkv = torch.randn(B * n, 3 * H * dh, generator=g).to(torch.bfloat16).cuda()
+        inner = H * dh
+        f = lambda: K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, n, dh, dh ** -0.5)
+        f()
+        ms = time_region(f, iters)
+        flops = 4.0 * B * H * n * n * dh                 # SURVEY 8-d: attention FLOPs per layer = 4 B h n^2 d
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)",
+                "launch_ms": round(ms, 4), "algorithmic_flops": flops}
+
+    def cpu_baseline(self):
+        """oracle.ref_ops.vit3d (torch CPU restatement of vit_3d.py:113-128) on ONE volume."""
+        from oracle import ref_ops as O
+        sd = {k: v.detach().float().cpu() for k, v in self.m.state_dict().items()}
+        x = self.x[:1].cpu()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.vit3d(x, sd, "", frame_patch=8, patch=8, heads=8, depth=4)
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 3), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle.ref_ops.vit3d, 1 volume of 96^3, fp32, torch CPU"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan"])
+    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d"])
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (volumes for `step`, sequences for `scan`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -132,6 +185,11 @@ def main():
         wl = ScanWorkload(a.batch)
         steps, warmup = a.steps or 50, a.warmup if a.warmup is not None else 10
         metric, unit, dtype = "selective-scan tokens/sec (L=4096 ED=1024 N=16 bf16) fwd+bwd", "tokens/s", "bf16"
+        cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
+    elif a.workload == "vit3d":
+        wl = Vit3dWorkload(a.batch)
+        steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 5
+        metric, unit, dtype = "3-D ViT volumes/sec (96^3, 1729 tokens, bf16) forward [synthetic MFMA-attention row]", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
     else:
         from gfe_hip.step_bench import StepWorkload
