@@ -111,11 +111,17 @@ __global__ __launch_bounds__(ANW * 64, 16 / ANW) void attn_fwd_kernel(const Attn
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            bf16x8 kf[4];
 #pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(32 * kb2 + ql, 2 * ds + hi));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s, 0, 0, 0);
-            }
+            for (int ds = 0; ds < 4; ++ds) kf[ds] = *reinterpret_cast<const bf16x8*>(sk + k_off(32 * kb2 + ql, 2 * ds + hi));
+#if defined(GFE_ATTN_PRIO)
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
+#if defined(GFE_ATTN_PRIO)
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // ---- online softmax over the block's 32 keys (this lane: 16 of them, lane ^ 32: the others)
             if (ragged) {                                                // keys >= n do not exist
 #pragma unroll
