@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void interleave_rows_kernel(const float* __res
 }
 
 // column sums of a row-major (M, N) f32 matrix (bias gradients): block = 256 threads covers 64 columns x 4 row-strips
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int64_t ld) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int64_t ld, int accumulate) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
     float acc = 0.f;
@@ -184,17 +184,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         for (int r = strip; r < M; r += 4) acc += x[(size_t)r * ld + c];
     red[strip][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (strip == 0 && c < N) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (strip == 0 && c < N) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream) {
+int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream) {
     GFE_REQUIRE(x && out, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && M <= 0x7fffffff && N <= 0x7fffffff, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, x, out, (int)M, (int)N, ld);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, x, out, (int)M, (int)N, ld, accumulate);
     return gfe_launch_status();
 }
 

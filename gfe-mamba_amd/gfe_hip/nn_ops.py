@@ -235,9 +235,10 @@ def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=Non
     return out
 
 
-def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1):
+def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1, accum_into=None):
     """C (M, N) = op(a) op(b)^T with bf16|f32 operands read in place (gfe_gemm_ex): `a_t` / `b_t` say that the operand is stored
-    reduction-major, i.e. a is (K, M) / b is (K, N) in memory."""
+    reduction-major, i.e. a is (K, M) / b is (K, N) in memory.  accum_into: f32 (M, N) tensor the product is ADDED to (a
+    gradient buffer): through the residual epilogue, or directly by the split-K atomics."""
     M, K = (a.shape[1], a.shape[0]) if a_t else a.shape
     N = b.shape[1] if b_t else b.shape[0]
     assert (b.shape[0] if b_t else b.shape[1]) == K and a.stride(1) == 1 and b.stride(1) == 1
@@ -245,9 +246,15 @@ def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1):
     assert a.dtype in (BF16, torch.float32) and b.dtype in (BF16, torch.float32)
     if split_k == 1 and out_dtype == torch.float32 and K >= 1024:
         split_k = _auto_split_k(M, N, K)
-    out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
+    res = None
+    if accum_into is not None:
+        assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and accum_into.stride(1) == 1 and bias is None
+        out = accum_into
+        res = None if split_k > 1 else accum_into
+    else:
+        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
     call("gfe_gemm_ex", ptr(a), a.stride(0), mode(a, a_t), ptr(b), b.stride(0), mode(b, b_t), ptr(out), out.stride(0), M, N, K,
-         ptr(bias), None, 0, 0, 0, int(out_dtype == torch.float32), split_k, stream())
+         ptr(bias), ptr(res), 0 if res is None else res.stride(0), int(res is not None), 0, int(out.dtype == torch.float32), split_k, stream())
     return out
 
 

@@ -21,6 +21,16 @@ def _w16(weight):
     return K.cast(weight.detach().float(), BF16)
 
 
+def _grad_slot(param):
+    """The parameter's gradient buffer if a backward may add into it directly (f32, dense, same shape): FlatAdam hands every
+    parameter a view of its flat gradient buffer, zeroed at the start of the step, so the wgrad kernels accumulate in place and
+    autograd's per-parameter AccumulateGrad add/copy launches (~90 per step) disappear.  None -> return the gradient to autograd."""
+    g = param.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != param.shape or not g.is_cuda:
+        return None
+    return g
+
+
 def _gemm(a16, b16, bias=None):
     """(M, K) x (N, K)^T -> (M, N) f32; zero-pads K to a multiple of 8 and N to a multiple of 4 (tiny test widths only)."""
     Kd, N = a16.shape[1], b16.shape[0]
@@ -60,6 +70,7 @@ class _LinearFn(torch.autograd.Function):
             y = _gemm(x16, w16, b32)
             ctx.save_for_backward(x16, xT16, weight)
         ctx.meta = (xs, bias is not None, x.dtype, fast)
+        ctx.bias_ref, ctx.w_ref = bias, weight
         return y.reshape(xs[:-1] + (N,))
 
     @staticmethod
@@ -74,10 +85,12 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = K.gemm_ex(d32, False, _w16(weight), True).reshape(xs).to(xdt)        # dy (M, N) . W (N, K) read reduction-major
             if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.w_ref)                                              # accumulate straight into weight.grad
                 if xT16 is not None:
-                    dw = K.gemm_ex(d32, True, xT16, False).to(weight.dtype)               # dy^T . (K, M)^T
+                    dw = K.gemm_ex(d32, True, xT16, False, accum_into=slot)               # dy^T . (K, M)^T
                 else:
-                    dw = K.gemm_ex(d32, True, xin, True).to(weight.dtype)                 # dy^T . x, both read reduction-major
+                    dw = K.gemm_ex(d32, True, xin, True, accum_into=slot)                 # dy^T . x, both read reduction-major
+                dw = None if slot is not None else dw.to(weight.dtype)
         else:
             x16 = xin if xin.dtype == BF16 else K.cast(xin, BF16)
             dy16 = K.cast(d32, BF16)
@@ -88,8 +101,11 @@ class _LinearFn(torch.autograd.Function):
                     xT16 = K.transpose_bf16(x16)                                          # (K, M)
                 dw = _gemm(K.transpose_bf16(dy16), xT16).to(weight.dtype)                 # (N, M) x (K, M)^T
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(N, dtype=torch.float32, device=d32.device)
-            call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), stream())
+            slot = _grad_slot(ctx.bias_ref)
+            db = slot if slot is not None else torch.empty(N, dtype=torch.float32, device=d32.device)
+            call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), int(slot is not None), stream())
+            if slot is not None:
+                db = None
         return dx, dw, db, None, None
 
 
@@ -143,7 +159,7 @@ class _RMSNormFn(torch.autograd.Function):
         rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x2.device)
         call("gfe_rmsnorm_fwd", ptr(x2), ptr(w_), ptr(y), ptr(rstd), x2.shape[0], x2.shape[1], float(eps), stream())
         ctx.save_for_backward(x2, w_, rstd)
-        ctx.xs = xs
+        ctx.xs, ctx.w_ref = xs, w
         return y.view(xs)
 
     @staticmethod
@@ -151,9 +167,10 @@ class _RMSNormFn(torch.autograd.Function):
         x2, w_, rstd = ctx.saved_tensors
         d = dy.float().reshape(x2.shape).contiguous()
         dx = torch.empty_like(x2)
-        dw = torch.zeros_like(w_)
+        slot = _grad_slot(ctx.w_ref)
+        dw = slot if slot is not None else torch.zeros_like(w_)
         call("gfe_rmsnorm_bwd", ptr(x2), ptr(w_), ptr(rstd), ptr(d), ptr(dx), ptr(dw), x2.shape[0], x2.shape[1], stream())
-        return dx.view(ctx.xs), dw, None
+        return dx.view(ctx.xs), (None if slot is not None else dw), None
 
 
 def rmsnorm(x, weight, eps):
@@ -171,6 +188,7 @@ class _DwConvSiluFn(torch.autograd.Function):
         y = torch.empty_like(x_)
         call("gfe_dwconv1d_silu_fwd", ptr(x_), ptr(w_), ptr(b_), ptr(y), B, L, ED, w_.shape[-1], stream())
         ctx.save_for_backward(x_, w_, b_)
+        ctx.w_ref, ctx.b_ref = w, bias
         return y
 
     @staticmethod
@@ -179,10 +197,11 @@ class _DwConvSiluFn(torch.autograd.Function):
         B, L, ED = x_.shape
         d = dy.float().contiguous()
         dx = torch.empty_like(x_)
-        dw = torch.zeros_like(w_)
-        db = None if b_ is None else torch.zeros_like(b_)
+        sw, sb = _grad_slot(ctx.w_ref), (None if b_ is None else _grad_slot(ctx.b_ref))
+        dw = sw if sw is not None else torch.zeros_like(w_)
+        db = None if b_ is None else (sb if sb is not None else torch.zeros_like(b_))
         call("gfe_dwconv1d_silu_bwd", ptr(x_), ptr(w_), ptr(b_), ptr(d), ptr(dx), ptr(dw), ptr(db), B, L, ED, w_.shape[-1], stream())
-        return dx, dw, db
+        return dx, (None if sw is not None else dw), (None if sb is not None or b_ is None else db)
 
 
 def dwconv1d_silu(x, conv_weight, conv_bias):

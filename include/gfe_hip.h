@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 11
+#define GFE_ABI_VERSION 12
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -257,8 +257,8 @@ int gfe_dwconv1d_silu_fwd(const float* x, const float* w, const float* bias, flo
 int gfe_dwconv1d_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw_zeroed, float* db_zeroed,
                           int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
 
-/* out[n] = sum_m x[m][n] for a row-major (M, N) f32 matrix with row stride ld: the bias gradient of every nn.Linear. */
-int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, void* stream);
+/* out[n] (+)= sum_m x[m][n] for a row-major (M, N) f32 matrix (accumulate != 0: added to what out holds) with row stride ld: the bias gradient of every nn.Linear. */
+int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream);
 
 /* Image condition (cross_atten/mamba_transformer.py:89-94): 'b c h w d -> (b c) (h w) d' then transpose(1, 2):
  * out[b][c][r] (bf16, row stride ldo, batch stride out_batch_stride) = in[b][r][c] (f32, contiguous (batch, R, Cc)). */
