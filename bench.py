@@ -145,8 +145,12 @@ class Vit3dWorkload:
         flops = 4.0 * B * H * n * n * dh                 # attention FLOPs per layer = 4 B h n^2 d
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)",
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": self._traffic(), "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)",
                 "launch_ms": round(ms, 4), "algorithmic_flops": flops}
+
+    def _traffic(self):
+        from gfe_hip.step_bench import measured_traffic
+        return measured_traffic("attn_fwd_b8_h8_n1729") if self.B == 8 else None
 
     def cpu_baseline(self):
         """oracle.ref_ops.vit3d (torch CPU restatement of vit_3d.py:113-128) on ONE volume."""

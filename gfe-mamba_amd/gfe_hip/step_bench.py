@@ -7,6 +7,18 @@ from . import det_init as det
 from .step import ClassifyStep, build_models
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def measured_traffic(key):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v3.json: FETCH_SIZE x2 as the
+    gfx950 correction prescribes + WRITE_SIZE, separate passes); None when the file does not travel with the tree."""
+    import json
+    import os
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01", "traffic_v3.json")
+    try:
+        return float(json.load(open(f))[key]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 # generator conv FLOPs per 96^3 volume (SURVEY.md 8-a): 3x3x3 convs + transposed convs, multiply-add = 2 flop
 CONV_K3_GFLOP_PER_VOL = 4 * 195.7 + 4 * 97.8 + 2 * 48.9
 GEN_GFLOP_PER_VOL = 1356.1
@@ -53,7 +65,8 @@ class StepWorkload:
         flops = 2.0 * 27 * 64 * 64 * self.batch * self.vol[0] * self.vol[1] * self.vol[2]
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": None, "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @96^3, ReLU)", "launch_ms": round(ms, 4),
+                "traffic": measured_traffic("conv_igemm_64to64_96cubed_b8") if self.batch == 8 else None,
+                "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @96^3, ReLU)", "launch_ms": round(ms, 4),
                 "algorithmic_flops": flops}
 
     def cpu_baseline(self):
