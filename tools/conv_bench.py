@@ -13,11 +13,12 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+CI = int(sys.argv[5]) if len(sys.argv) > 5 else C          # input channels (default: square)
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, D, D, D, C, generator=g).to(torch.bfloat16).cuda()
-w32 = K.pack_conv3((torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5).cuda(), torch.float32)
-ss = K.groupnorm_scale_shift(x, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 8)
-w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, C, C)
+x = torch.randn(B, D, D, D, CI, generator=g).to(torch.bfloat16).cuda()
+w32 = K.pack_conv3((torch.randn(C, CI, 3, 3, 3, generator=g) / (27 * CI) ** 0.5).cuda(), torch.float32)
+ss = K.groupnorm_scale_shift(x, torch.ones(CI, device="cuda"), torch.zeros(CI, device="cuda"), 8)
+w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, CI, C)
 y = K.conv_igemm(x, w, K.CONV3_TAPS, C, bias_tab=tab, relu=True)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,5 +28,5 @@ for _ in range(iters):
 e1.record()
 e1.synchronize()
 ms = e0.elapsed_time(e1) / iters
-fl = 2.0 * 27 * C * C * B * D ** 3
-print(f"conv C={C} D={D} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+fl = 2.0 * 27 * C * CI * B * D ** 3
+print(f"conv Cin={CI} C={C} D={D} B={B}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
