@@ -139,6 +139,15 @@ class MambaBlock(nn.Module):
         delta = _dt_linear(delta, self.dt_proj)
         return selective_scan_tm(x, delta, A, B, C, self.D.float(), z=z, delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
 
+    def selective_scan(self, x, delta, A, B, C, D):
+        """The reference's parallel-scan form (mamba.py:265-286): y = (pscan(exp(delta (x) A), delta B x) @ C) + D x with delta already
+        softplus-ed.  x, delta: (B, L, ED); A: (ED, N); B, C: (B, L, N); D: (ED) -> (B, L, ED).  One fused kernel here."""
+        return selective_scan_tm(x, delta, A, B, C, D)
+
+    def selective_scan_seq(self, x, delta, A, B, C, D):
+        """The reference's sequential definition (mamba.py:288-318) -- the same function of its inputs, same kernel."""
+        return selective_scan_tm(x, delta, A, B, C, D)
+
     # ---- single-token inference (mamba.py:342-405); not on the classify path, plain torch ops --------------------------
     def step(self, x, cache):
         h, inputs = cache

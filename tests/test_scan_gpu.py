@@ -151,3 +151,16 @@ def test_selective_scan_ragged_and_edge_shapes():
         gr = torch.autograd.grad((ref * w.double()).sum(), ins)
         for a, b in zip(gi, gr):
             assert rel_err(a.grad, b) < TOL32, (B, L, ED, N)
+
+
+def test_mambablock_selective_scan_methods_match_reference_fixture():
+    """MambaBlock.selective_scan / selective_scan_seq (mamba.py:265-318) keep their names and signatures and agree with the
+    reference's outputs for both."""
+    from cross_atten.mamba import MambaBlock, MambaConfig
+    fx = golden("t0_selective_scan.npz")
+    i = _ss_inputs(fx)
+    blk = MambaBlock(MambaConfig(d_model=32, n_layers=1)).to(DEV)
+    with torch.no_grad():
+        y = blk.selective_scan(i["x"], i["delta"], i["A"], i["B"], i["C"], i["D"])
+        ys = blk.selective_scan_seq(i["x"], i["delta"], i["A"], i["B"], i["C"], i["D"])
+    assert rel_err(y, tt(fx["ss_y"])) < TOL32 and rel_err(ys, tt(fx["ss_y_seq"])) < TOL32

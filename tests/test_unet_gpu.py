@@ -250,3 +250,38 @@ def test_vit3d_vs_reference_fixture(tag, kw):
         assert rel_err(m(x), tt(fx["out"])) < 2e-2
         m.pool = "mean"
         assert rel_err(m(x), tt(fx["out_mean"])) < 2e-2
+
+
+def test_generator_real_width_64_cubed_vs_oracle():
+    """Full-width generator (f_maps 64/128/256, ViT 512x4x6) on a 64^3 volume -- every channel count of the real model, 2 tiles
+    per axis incl. boundary classes -- against the oracle on the same deterministic weights."""
+    import gfe_hip.det_init as det
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    vol = (64, 64, 64)
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(64, 128, 256), vol_size=vol)
+    sd = det.det_state_dict(gen.state_dict(), seed=31, prefix="gen64.")
+    gen.load_state_dict(sd)
+    gen = gen.to(DEV).eval()
+    x = det.det_inputs(1, vol, seed=5)[0]
+    with torch.no_grad():
+        mi, mo, pet = gen(x.to(DEV), output_vit_mid=True)
+        omi, omo, opet = O.generator(x, {k: v.float() for k, v in sd.items()})
+    assert rel_err(mi, omi) < 2e-2 and rel_err(mo, omo) < 3e-2 and rel_err(pet, opet) < 5e-2, (rel_err(mi, omi), rel_err(mo, omo), rel_err(pet, opet))
+
+
+def test_generator_128_cubed_config4_runs():
+    """BASELINE config 4 geometry (128^3 -> ViT image (256,128), patch 32): shapes, finiteness and run-to-run agreement
+    (not bit equality: the split-K patch-embed GEMM and the GroupNorm fold accumulate with f32 atomics)."""
+    import gfe_hip.det_init as det
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    vol = (128, 128, 128)
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(64, 128, 256), vol_size=vol)
+    gen.load_state_dict(det.det_state_dict(gen.state_dict(), seed=32, prefix="gen128."))
+    gen = gen.to(DEV).eval()
+    x = det.det_inputs(1, vol, seed=6)[0].to(DEV)
+    with torch.no_grad():
+        mi, mo, pet = gen(x, output_vit_mid=True)
+        mi2, mo2, pet2 = gen(x, output_vit_mid=True)
+    assert tuple(mi.shape) == (1, 256, 256, 128) and tuple(mo.shape) == (1, 256, 256, 128) and tuple(pet.shape) == (1, 1, 128, 128, 128)
+    assert torch.isfinite(pet).all() and torch.isfinite(mo.float()).all()
+    assert rel_err(pet, pet2) < 5e-3 and rel_err(mo, mo2) < 5e-3
