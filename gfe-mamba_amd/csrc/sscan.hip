@@ -307,6 +307,58 @@ __device__ __forceinline__ float wave_reduce_vec(float (&v)[N]) {
     return r;
 }
 
+// dB / dC rows of one timestep together (N == 16): 32 per-lane partials -> one total per lane, VALU only (no LDS crossbar trips,
+// no waits): v_permlane32_swap pairs dB[i] with dC[i] (lanes < 32 end up owning dB, lanes >= 32 dC), v_permlane16_swap halves the
+// 16 values by lane bit 4, then three DPP reduce-scatter levels inside the 16-lane rows (row_ror:8, row_half_mirror, reversed
+// quads: each pairing flips the split bit) and a final quad xor-1 add.  Lane l returns the total of vector (l >> 5) for
+// n = (l >> 1) & 15 (lanes l and l ^ 1 hold the same value).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_reduce_bc16(const float (&dBv)[16], const float (&dCv)[16]) {
+    const int lane = threadIdx.x & 63;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(dBv[i]), __float_as_uint(dCv[i]), false, false);
+        v[i] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+    }
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[8 + i]), false, false);
+        w[i] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+    }
+    float a4[4], a2[2];
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = w[i], hi = w[4 + i];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            a4[i] = (up ? hi : lo) + dpp_mov<0x128>(up ? lo : hi);          // row_ror:8 == lane ^ 8
+        }
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float lo = a4[i], hi = a4[2 + i];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            a2[i] = (up ? hi : lo) + dpp_mov<0x141>(up ? lo : hi);          // row_half_mirror: i <-> 7 - i
+        }
+    }
+    float r;
+    {
+        const bool up = (lane & 2) != 0;
+        float lo = a2[0], hi = a2[1];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        r = (up ? hi : lo) + dpp_mov<0x1b>(up ? lo : hi);                   // quad_perm [3,2,1,0]: i <-> 3 - i
+    }
+    return r + dpp_mov<0xb1>(r);                                            // quad_perm [1,0,3,2]: i <-> i ^ 1
+}
+
 // K3': one wave per block (64 channels), chunk of T steps processed as sub-chunks of S steps:
 //   sweep 1 (forward): chunk-start state -> state at every sub-chunk start, parked in LDS (u/delta in 16-step register tiles)
 //   sweep 2 (sub-chunks in reverse): recompute the S states in registers, then run the adjoint; the u/delta/z/dy values of
@@ -497,10 +549,28 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
                 IO<T>::st(du + off, fmaf(dub, dts[s2], Dv * g));
                 dDacc = fmaf(g, us[s2], dDacc);
                 dbacc += ddraw;
-                dBrow[s2] = wave_reduce_vec<N>(dBv);
-                dCrow[s2] = wave_reduce_vec<N>(dCv);
+                if constexpr (N == 16) {
+                    dBrow[s2] = wave_reduce_bc16(dBv, dCv);       // both vectors in one VALU-only butterfly (dCrow unused)
+                } else {
+                    dBrow[s2] = wave_reduce_vec<N>(dBv);
+                    dCrow[s2] = wave_reduce_vec<N>(dCv);
+                }
             }
         }
+        if constexpr (N == 16) {
+            // lane l holds, for every step s, the total of vector (l >> 5) for n = (l >> 1) & 15: two steps per 64-lane atomic
+#pragma unroll
+            for (int s0 = 0; s0 < S; s0 += 2) {
+                const int sidx = s0 + (lane & 1);
+                float val = dBrow[s0];
+                if (s0 + 1 < S && (lane & 1)) val = dBrow[s0 + 1];
+                const int t = ts + sidx;
+                if (sidx < S && t < t1) {
+                    float* base = (lane >> 5) ? p.dCws : p.dBws;
+                    atomicAdd(base + ((size_t)b * p.L + t) * N + ((lane >> 1) & 15), val);
+                }
+            }
+        } else {
         // lane l holds the (t = ts + s, n = l % N) totals for every s; emit S*N contiguous floats per atomic
         constexpr int STEPS_PER_WAVE = 64 / N;     // timesteps covered by one 64-lane atomic
 #pragma unroll
@@ -516,6 +586,7 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
                 atomicAdd(p.dBws + o, vb);
                 atomicAdd(p.dCws + o, vc);
             }
+        }
         }
         if (k > 0 && j == k * SPT) { tB.park(tbuf ^ 1, fb2); tC.park(tbuf ^ 1, fc2); }   // leaving tile k
 #pragma unroll
