@@ -389,17 +389,22 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
     const RowTile<N, TT> tC{tiles + 2 * F4, p.Cm, last_f4, lane, vz};
     const int64_t row0 = (int64_t)b * p.L + t0;
 
-    float A2[N], h[N];
+    // states travel as float2 pairs (n = 2k, 2k+1): the mul / fma chains become v_pk_mul_f32 / v_pk_fma_f32 without the
+    // register-pairing moves the compiler needs when it packs scalar code on its own
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = N / 2;
+    f2 A2[NP], h[NP];
 #pragma unroll
-    for (int n = 0; n < N; ++n) A2[n] = p.A[(size_t)e * N + n] * GFE_LOG2E;
+    for (int k = 0; k < NP; ++k) A2[k] = f2{p.A[(size_t)e * N + 2 * k], p.A[(size_t)e * N + 2 * k + 1]} * GFE_LOG2E;
     const size_t sbase = ((size_t)b * p.nchunks + c) * N * p.ED + e;
     if (p.nchunks > 1) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) h[n] = p.hstate[sbase + (size_t)n * p.ED];
+        for (int k = 0; k < NP; ++k) h[k] = f2{p.hstate[sbase + (size_t)(2 * k) * p.ED], p.hstate[sbase + (size_t)(2 * k + 1) * p.ED]};
     } else {
 #pragma unroll
-        for (int n = 0; n < N; ++n) h[n] = 0.f;
+        for (int k = 0; k < NP; ++k) h[k] = f2{0.f, 0.f};
     }
+    auto exp2v = [](f2 x) { return f2{fast_exp2(x.x), fast_exp2(x.y)}; };
     const float bias = p.dbias ? p.dbias[e] : 0.f;
     const float Dv = p.D ? p.D[e] : 0.f;
 
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
                     if ((s2 % S) == 0) {
                         const int j = (t - t0) / S;
 #pragma unroll
-                        for (int n = 0; n < N; ++n) ck[(j * N + n) * 64 + lane] = h[n];
+                        for (int k = 0; k < NP; ++k) { ck[(j * N + 2 * k) * 64 + lane] = h[k].x; ck[(j * N + 2 * k + 1) * 64 + lane] = h[k].y; }
                     }
                     float dt = IO<T>::ld(&db[s2]) + bias;
                     if (p.softplus) dt = softplusf_(dt);
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
                     float Bv[N];
                     tB.row(cur, s2, Bv);
 #pragma unroll
-                    for (int n = 0; n < N; ++n) h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
+                    for (int k = 0; k < NP; ++k) h[k] = exp2v(A2[k] * dt) * h[k] + f2{Bv[2 * k], Bv[2 * k + 1]} * dtu;
                 }
             }
             if (more) tB.park(cur ^ 1, fb);
@@ -443,19 +448,19 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
             for (int s2 = 0; s2 < TT; ++s2) { ub[s2] = un[s2]; db[s2] = dn[s2]; }
         }
 #pragma unroll
-        for (int n = 0; n < N; ++n) ck[((nsub - 1) * N + n) * 64 + lane] = h[n];
+        for (int k = 0; k < NP; ++k) { ck[((nsub - 1) * N + 2 * k) * 64 + lane] = h[k].x; ck[((nsub - 1) * N + 2 * k + 1) * 64 + lane] = h[k].y; }
     }
 
-    float q[N], dAacc[N];
+    f2 q[NP], dAacc[NP];
     if (p.nchunks > 1) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) q[n] = p.qstate[sbase + (size_t)n * p.ED];
+        for (int k = 0; k < NP; ++k) q[k] = f2{p.qstate[sbase + (size_t)(2 * k) * p.ED], p.qstate[sbase + (size_t)(2 * k + 1) * p.ED]};
     } else {
 #pragma unroll
-        for (int n = 0; n < N; ++n) q[n] = 0.f;
+        for (int k = 0; k < NP; ++k) q[k] = f2{0.f, 0.f};
     }
 #pragma unroll
-    for (int n = 0; n < N; ++n) dAacc[n] = 0.f;
+    for (int k = 0; k < NP; ++k) dAacc[k] = f2{0.f, 0.f};
     float dDacc = 0.f, dbacc = 0.f;
 
     // ---- sweep 2
@@ -484,10 +489,11 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
             fc2 = tC.fetch(row0 + (int64_t)(k - 1) * TT);
         }
         const int ts = t0 + j * S;
-        float hs[S][N], dts[S], us[S], sg[S];
-        float h0[N];
+        f2 hs[S][NP];
+        float dts[S], us[S], sg[S];
+        f2 h0[NP];
 #pragma unroll
-        for (int n = 0; n < N; ++n) h0[n] = ck[(j * N + n) * 64 + lane];
+        for (int k = 0; k < NP; ++k) h0[k] = f2{ck[(j * N + 2 * k) * 64 + lane], ck[(j * N + 2 * k + 1) * 64 + lane]};
 #pragma unroll
         for (int s2 = 0; s2 < S; ++s2) {
             const float draw = IO<T>::ld(&dc[s2]) + bias;
@@ -499,9 +505,9 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
             float Bv[N];
             tB.row(tbuf, r0 + s2, Bv);
 #pragma unroll
-            for (int n = 0; n < N; ++n) {
-                const float hp = (s2 == 0) ? h0[n] : hs[s2 - 1][n];
-                hs[s2][n] = fmaf(fast_exp2(dt * A2[n]), hp, dtu * Bv[n]);
+            for (int k = 0; k < NP; ++k) {
+                const f2 hp = (s2 == 0) ? h0[k] : hs[s2 - 1][k];
+                hs[s2][k] = exp2v(A2[k] * dt) * hp + f2{Bv[2 * k], Bv[2 * k + 1]} * dtu;
             }
         }
         float dBrow[S], dCrow[S];
@@ -520,29 +526,33 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
                 if (has_z) {
                     const float zv = IO<T>::ld(&zc[s2]);
                     const float sz = sigmoidf_(zv);
-                    float yss = Dv * us[s2];
+                    f2 ys2 = f2{Dv * us[s2], 0.f};
 #pragma unroll
-                    for (int n = 0; n < N; ++n) yss = fmaf(hs[s2][n], Cv[n], yss);
+                    for (int k = 0; k < NP; ++k) ys2 += hs[s2][k] * f2{Cv[2 * k], Cv[2 * k + 1]};
+                    const float yss = ys2.x + ys2.y;
                     // d/dz [y*z*sigmoid(z)] = y*sigmoid(z)*(1 + z*(1-sigmoid(z)))
                     IO<T>::st(dz + off, dyv * yss * sz * (1.f + zv * (1.f - sz)));
                     g = dyv * zv * sz;
                 }
-                float ddt = 0.f, dub = 0.f;
                 float dBv[N], dCv[N];
                 const float dtu = dts[s2] * us[s2];
+                f2 ddt2 = f2{0.f, 0.f}, dub2 = f2{0.f, 0.f};
 #pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    const float a = fast_exp2(dts[s2] * A2[n]);
-                    const float dh = fmaf(Cv[n], g, q[n]);
-                    const float hp = (s2 == 0) ? h0[n] : hs[s2 - 1][n];
-                    const float da = dh * hp * a;                 // dL/d(dt*A) for this (t,n)
-                    dAacc[n] = fmaf(da, dts[s2], dAacc[n]);
-                    ddt = fmaf(da, A2[n], ddt);                   // A2 = A*log2e, rescaled below
-                    dub = fmaf(dh, Bv[n], dub);
-                    dBv[n] = dh * dtu;
-                    dCv[n] = hs[s2][n] * g;
-                    q[n] = a * dh;
+                for (int k = 0; k < NP; ++k) {
+                    const f2 a = exp2v(A2[k] * dts[s2]);
+                    const f2 dh = f2{Cv[2 * k], Cv[2 * k + 1]} * g + q[k];
+                    const f2 hp = (s2 == 0) ? h0[k] : hs[s2 - 1][k];
+                    const f2 da = dh * hp * a;                    // dL/d(dt*A) for this (t, n pair)
+                    dAacc[k] += da * dts[s2];
+                    ddt2 += da * A2[k];                           // A2 = A*log2e, rescaled below
+                    dub2 += dh * f2{Bv[2 * k], Bv[2 * k + 1]};
+                    const f2 db2 = dh * dtu, dc2 = hs[s2][k] * g;
+                    dBv[2 * k] = db2.x; dBv[2 * k + 1] = db2.y;
+                    dCv[2 * k] = dc2.x; dCv[2 * k + 1] = dc2.y;
+                    q[k] = a * dh;
                 }
+                const float dub = dub2.x + dub2.y;
+                float ddt = ddt2.x + ddt2.y;
                 ddt = ddt * GFE_LN2 + dub * us[s2];
                 const float ddraw = ddt * sg[s2];
                 IO<T>::st(dd + off, ddraw);
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(64) void sscan_bwd_kernel(const SScanBwdParams p) {
         for (int s2 = 0; s2 < S; ++s2) { uc[s2] = un2[s2]; dc[s2] = dn2[s2]; zc[s2] = zn2[s2]; gc[s2] = gn2[s2]; }
     }
 #pragma unroll
-    for (int n = 0; n < N; ++n) atomicAdd(p.dAws + (size_t)n * p.ED + e, dAacc[n]);
+    for (int k = 0; k < NP; ++k) { atomicAdd(p.dAws + (size_t)(2 * k) * p.ED + e, dAacc[k].x); atomicAdd(p.dAws + (size_t)(2 * k + 1) * p.ED + e, dAacc[k].y); }
     if (p.dDws) atomicAdd(p.dDws + e, dDacc);
     if (p.dbiasws) atomicAdd(p.dbiasws + e, dbacc);
 }
