@@ -89,17 +89,21 @@ __global__ __launch_bounds__(256, STATE_ONLY ? 4 : 3) void sscan_fwd_kernel(cons
     const RowTile<N, TT> tB{sm4 + wid * 4 * F4, p.Bm, last_f4, lane, vz};
     const RowTile<N, TT> tC{sm4 + wid * 4 * F4 + 2 * F4, p.Cm, last_f4, lane, vz};
 
-    float A2[N], h[N];
+    // states as float2 pairs (n = 2k, 2k+1): v_pk_mul_f32 / v_pk_fma_f32 chains without register-pairing moves
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = N / 2;
+    f2 A2[NP], h[NP];
 #pragma unroll
-    for (int n = 0; n < N; ++n) A2[n] = p.A[(size_t)e * N + n] * GFE_LOG2E;
+    for (int k = 0; k < NP; ++k) A2[k] = f2{p.A[(size_t)e * N + 2 * k], p.A[(size_t)e * N + 2 * k + 1]} * GFE_LOG2E;
     const size_t sbase = ((size_t)b * p.nchunks + c) * N * p.ED + e;
     if (!STATE_ONLY && p.nchunks > 1) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) h[n] = p.hstate[sbase + (size_t)n * p.ED];
+        for (int k = 0; k < NP; ++k) h[k] = f2{p.hstate[sbase + (size_t)(2 * k) * p.ED], p.hstate[sbase + (size_t)(2 * k + 1) * p.ED]};
     } else {
 #pragma unroll
-        for (int n = 0; n < N; ++n) h[n] = 0.f;
+        for (int k = 0; k < NP; ++k) h[k] = f2{0.f, 0.f};
     }
+    auto exp2v = [](f2 x) { return f2{fast_exp2(x.x), fast_exp2(x.y)}; };
     const float bias = p.dbias ? p.dbias[e] : 0.f;
     const float Dv = (!STATE_ONLY && p.D) ? p.D[e] : 0.f;
     float sd = 0.f;
@@ -141,19 +145,17 @@ __global__ __launch_bounds__(256, STATE_ONLY ? 4 : 3) void sscan_fwd_kernel(cons
                 if (STATE_ONLY) {
                     sd += dt;
 #pragma unroll
-                    for (int n = 0; n < N; ++n) h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
+                    for (int k = 0; k < NP; ++k) h[k] = exp2v(A2[k] * dt) * h[k] + f2{Bv[2 * k], Bv[2 * k + 1]} * dtu;
                 } else {
                     float Cv[N];
                     tC.row(cur, s2, Cv);
-                    float acc0 = 0.f, acc1 = 0.f;
+                    f2 acc = f2{0.f, 0.f};
 #pragma unroll
-                    for (int n = 0; n < N; n += 2) {
-                        h[n] = fmaf(fast_exp2(dt * A2[n]), h[n], dtu * Bv[n]);
-                        h[n + 1] = fmaf(fast_exp2(dt * A2[n + 1]), h[n + 1], dtu * Bv[n + 1]);
-                        acc0 = fmaf(h[n], Cv[n], acc0);
-                        acc1 = fmaf(h[n + 1], Cv[n + 1], acc1);
+                    for (int k = 0; k < NP; ++k) {
+                        h[k] = exp2v(A2[k] * dt) * h[k] + f2{Bv[2 * k], Bv[2 * k + 1]} * dtu;
+                        acc += h[k] * f2{Cv[2 * k], Cv[2 * k + 1]};
                     }
-                    float yv = fmaf(Dv, uu, acc0 + acc1);
+                    float yv = fmaf(Dv, uu, acc.x + acc.y);
                     if (has_z) yv *= siluf_(IO<T>::ld(&zb[s2]));
                     IO<T>::st(y + row * p.ED + e, yv);
                 }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, STATE_ONLY ? 4 : 3) void sscan_fwd_kernel(cons
     }
     if (STATE_ONLY) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) p.hstate[sbase + (size_t)n * p.ED] = h[n];
+        for (int k = 0; k < NP; ++k) { p.hstate[sbase + (size_t)(2 * k) * p.ED] = h[k].x; p.hstate[sbase + (size_t)(2 * k + 1) * p.ED] = h[k].y; }
         p.sdelta[((size_t)b * p.nchunks + c) * p.ED + e] = sd;
     }
 }
