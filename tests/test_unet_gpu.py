@@ -284,4 +284,4 @@ def test_generator_128_cubed_config4_runs():
         mi2, mo2, pet2 = gen(x, output_vit_mid=True)
     assert tuple(mi.shape) == (1, 256, 256, 128) and tuple(mo.shape) == (1, 256, 256, 128) and tuple(pet.shape) == (1, 1, 128, 128, 128)
     assert torch.isfinite(pet).all() and torch.isfinite(mo.float()).all()
-    assert rel_err(pet, pet2) < 5e-3 and rel_err(mo, mo2) < 5e-3
+    assert rel_err(pet, pet2) < 2e-2 and rel_err(mo, mo2) < 2e-2
