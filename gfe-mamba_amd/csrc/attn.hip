@@ -45,7 +45,8 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((
 // ds_read_b64_tr_b16 then cover 64 distinct banks
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) * 16); }
 
-__global__ __launch_bounds__(ANW * 64, 16 / ANW) void attn_fwd_kernel(const AttnParams p) {
+// (HIP: the second __launch_bounds__ argument is the minimum number of waves per SIMD: 4 keeps the kernel at <= 128 VGPRs)
+__global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer / LDS-DMA builtins)
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * TILE_BYTES];      // K[2], V[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
