@@ -301,14 +301,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                     const int set = PIPE ? (tl & 1) : 0;
                     if constexpr (PIPE) { if (tl + 1 < TPS) frag_load(tl + 1, (tl + 1) & 1); }
                     else frag_load(tl, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
+                    if constexpr (PIPE) {
+                        // the next tap's 8 fragment reads ride in the shadows of this tap's MFMAs: one ds_read_b128 per two MFMAs
 #pragma unroll
-                    for (int ct = 0; ct < NT; ++ct)
+                        for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                        for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[set][ct], xf[set][xt], acc[xt][ct]);
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
+                            for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[set][ct], xf[set][xt], acc[xt][ct]);
+                        if (tl + 1 < TPS) {
+#pragma unroll
+                            for (int i = 0; i < 2 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                            for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[set][ct], xf[set][xt], acc[xt][ct]);
+                        __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else {
 #pragma unroll
