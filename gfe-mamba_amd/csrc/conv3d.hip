@@ -143,15 +143,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     // lane -> voxel 16k + lane/4, LDS chunk slot lane%4, which must hold data chunk slot ^ ((row & 1) << 1).
     const int dw = wave & (DMA_WAVES - 1);
     const bool a_wave = wave >= DMA_WAVES;
-    int acoord[A_PER_WAVE];          // ld | lh << 4 | lw << 8 | (chunk*16) << 12 | valid << 20
+    // Per piece one thread constant: the byte offset of the lane's 16 B from the tile's first halo voxel (slab 0), or OOB for lanes
+    // outside the halo box.  Tiles whose halo box lies inside the volume (58 % at 96^3) need no per-lane arithmetic at all: the tile
+    // origin goes into the scalar offset of the buffer instruction.  Boundary tiles recompute the lane's coordinates.
+    constexpr bool FASTA = REG27;       // the tap-list variants have no registers to spare for the second per-piece constant
+    unsigned arel[FASTA ? A_PER_WAVE : 1];
+    int acoord[A_PER_WAVE];          // ld | lh << 4 | lw << 8 | (chunk*16) << 12 | valid << 20   (boundary tiles)
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
         const int k = dw + DMA_WAVES * j, v = 16 * k + (lane >> 2);
         const int ld = v / (PH * PW), rem = v - ld * (PH * PW), lh = rem / PW, lw = rem - lh * PW;
         const int c = (lane & 3) ^ ((lh & 1) << 1);
         const bool valid = k < A_PIECES && v < A_VOX && ld < p.LD && lh < p.LH && lw < p.LW;
+        if constexpr (FASTA) arel[j] = valid ? (unsigned)((((ld * p.H + lh) * p.W + lw) * p.Cin) * 2 + c * 16) : OOB;
         acoord[j] = ld | (lh << 4) | (lw << 8) | ((c * 16) << 12) | ((valid ? 1 : 0) << 20);
     }
+    const bool full_slabs = (p.Cin & 31) == 0;
     // weight piece k = dw + 4*j moves stage rows 16k..16k+15 (row = tap_local*WROWS_TAP + r): lane -> row 16k + lane/4
     unsigned wvoff[W_PER_WAVE];
 #pragma unroll
@@ -184,17 +191,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         const int d0 = rfl(q.td) * TD + p.lo_d, h0 = rfl(q.th) * TH + p.lo_h, w0 = rfl(q.tw) * TW + p.lo_w;
         const int lds_off = rfl(buf) * A_BYTES;
         slab = rfl(slab);
+        const bool interior = FASTA && full_slabs && d0 >= 0 && h0 >= 0 && w0 >= 0 && d0 + p.LD <= p.D && h0 + p.LH <= p.H && w0 + p.LW <= p.W;
+        if (interior) {                                                          // wave-uniform
+            const unsigned soff = (unsigned)((((d0 * p.H + h0) * p.W + w0) * p.Cin + slab * 32) * 2);
 #pragma unroll
-        for (int j = 0; j < A_PER_WAVE; ++j) {
-            const int k = dw + DMA_WAVES * j;
-            if (j >= j0 && j < j1) {                                         // wave-uniform
-                const int ac = acoord[j];
-                const int gd = d0 + (ac & 15), gh = h0 + ((ac >> 4) & 15), gw = w0 + ((ac >> 8) & 15);
-                const int cb = (ac >> 12) & 0xff;                            // chunk byte offset inside the slab
-                const bool ok = ((ac >> 20) & 1) && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
-                                (unsigned)gw < (unsigned)p.W && slab * 32 + (cb >> 1) < p.Cin;
-                const unsigned voff = ok ? (unsigned)((((gd * p.H + gh) * p.W + gw) * p.Cin + slab * 32) * 2 + cb) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + lds_off + k * 1024), 16, voff, 0, 0, 0);
+            for (int j = 0; j < A_PER_WAVE; ++j)
+                if (j >= j0 && j < j1)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + lds_off + (dw + DMA_WAVES * j) * 1024), 16, arel[FASTA ? j : 0], soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_PER_WAVE; ++j) {
+                const int k = dw + DMA_WAVES * j;
+                if (j >= j0 && j < j1) {                                         // wave-uniform
+                    const int ac = acoord[j];
+                    const int gd = d0 + (ac & 15), gh = h0 + ((ac >> 4) & 15), gw = w0 + ((ac >> 8) & 15);
+                    const int cb = (ac >> 12) & 0xff;                            // chunk byte offset inside the slab
+                    const bool ok = ((ac >> 20) & 1) && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H &&
+                                    (unsigned)gw < (unsigned)p.W && slab * 32 + (cb >> 1) < p.Cin;
+                    const unsigned voff = ok ? (unsigned)((((gd * p.H + gh) * p.W + gw) * p.Cin + slab * 32) * 2 + cb) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + lds_off + k * 1024), 16, voff, 0, 0, 0);
+                }
             }
         }
     };
