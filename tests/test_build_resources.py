@@ -1,0 +1,50 @@
+"""Compile-time guard for the hot kernels (CPU only: hipcc cross-compiles gfx950 without a GPU).
+
+A VGPR spill in the conv main loop cost 30 % in round 1 without failing any parity test, so the register budget of the kernels that
+DESIGN.md quotes is asserted here from hipcc's own resource remarks."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gfe-mamba_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _resources(src, tmp_path):
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-c", os.path.join(CSRC, src),
+                          "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return res
+
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("make") is None, reason="needs the ROCm toolchain")
+
+
+def test_conv_hot_variants_do_not_spill(tmp_path):
+    res = _resources("conv3d.hip", tmp_path)
+    hot = [k for k in res if "conv_igemm_kernelILi4ELi3ELb1" in k]          # 27-tap variants (with / without GroupNorm partials)
+    assert len(hot) == 2
+    for k in hot:
+        assert res[k]["VGPRs Spill"] == 0 and res[k]["VGPRs"] <= 256, (k, res[k])
+    for k in res:                                                          # 8 waves per CU need <= 256 VGPRs everywhere
+        if "conv_igemm_kernel" in k:
+            assert res[k]["VGPRs"] <= 256
+
+
+def test_attention_keeps_four_waves_per_simd(tmp_path):
+    res = _resources("attn.hip", tmp_path)
+    (k,) = [k for k in res if "attn_fwd_kernel" in k]
+    assert res[k]["VGPRs"] <= 128 and res[k]["VGPRs Spill"] == 0, res[k]
