@@ -20,25 +20,35 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     for (int c = lane; c < dim; c += 64) yr[c] = xr[c] * r * w[c];
 }
 
-// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd (f32 atomics over rows, dw zeroed)
+// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd.  Block = 4 waves x RB rows each; the weight
+// gradient is folded in LDS first (a per-row global atomic per column is 296-way contended on 512 addresses: measured 23 us).
+constexpr int RMS_RB = 4;          // rows per wave
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ rstd,
                                                           const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
                                                           int rows, int dim) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * dim;
-    const float* gr = dy + (size_t)row * dim;
-    const float r = rstd[row];
-    float s = 0.f;
-    for (int c = lane; c < dim; c += 64) s = fmaf(gr[c] * w[c], xr[c], s);
-    s = wave_sum(s);
-    const float k = s * r * r / (float)dim;
-    float* dxr = dx + (size_t)row * dim;
-    for (int c = lane; c < dim; c += 64) {
-        const float xv = xr[c], g = gr[c];
-        dxr[c] = r * (g * w[c] - xv * k);
-        atomicAdd(dw + c, g * xv * r);
+    extern __shared__ float sdw[];                      // [dim]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < dim; c += 256) sdw[c] = 0.f;
+    __syncthreads();
+    for (int k = 0; k < RMS_RB; ++k) {
+        const int row = (blockIdx.x * 4 + wave) * RMS_RB + k;
+        if (row >= rows) break;
+        const float* xr = x + (size_t)row * dim;
+        const float* gr = dy + (size_t)row * dim;
+        const float r = rstd[row];
+        float s = 0.f;
+        for (int c = lane; c < dim; c += 64) s = fmaf(gr[c] * w[c], xr[c], s);
+        s = wave_sum(s);
+        const float kk = s * r * r / (float)dim;
+        float* dxr = dx + (size_t)row * dim;
+        for (int c = lane; c < dim; c += 64) {
+            const float xv = xr[c], g = gr[c];
+            dxr[c] = r * (g * w[c] - xv * kk);
+            atomicAdd(&sdw[c], g * xv * r);             // LDS atomic, <= 4-way
+        }
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dw + c, sdw[c]);
 }
 
 // ---- depthwise causal conv1d (kernel KS, left padding KS-1) + bias + SiLU on (B, L, ED); lane = channel --------------------
@@ -65,27 +75,29 @@ __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const float* __res
     }
 }
 
-// backward: dpre = dy * silu'(pre); dx[t] = sum_k w[k] * dpre[t + (KS-1) - k]; dw[k] += dpre[t] * x[t + k - (KS-1)]; db += dpre
+// backward: dpre = dy * silu'(pre); dx[t] = sum_k w[k] * dpre[t + (KS-1) - k]; dw[k] += dpre[t] * x[t + k - (KS-1)]; db += dpre.
+// Block = 64 channels of one sample; its 4 waves split the time steps: phase 1 writes dpre[t][channel] to LDS and keeps dw / db
+// partials, phase 2 forms dx from the LDS copy, then the partials are folded across the waves and added to dw / db (B-way atomics).
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
                                                               float* __restrict__ db, int L, int ED) {
-    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (e >= ED) return;
+    extern __shared__ float sp[];                       // [L + KS - 1][64] dpre (zero tail), then [4][KS + 1][64] partials
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const bool live = e < ED;
     float wk[KS], dwacc[KS];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { wk[k] = w[e * KS + k]; dwacc[k] = 0.f; }
-    const float bv = bias ? bias[e] : 0.f;
+    for (int k = 0; k < KS; ++k) { wk[k] = live ? w[e * KS + k] : 0.f; dwacc[k] = 0.f; }
+    const float bv = (bias && live) ? bias[e] : 0.f;
     float dbacc = 0.f;
-    float win[KS], dp[KS];                            // dp[j] = dpre[t - (KS-1) + j]
-#pragma unroll
-    for (int k = 0; k < KS; ++k) { win[k] = 0.f; dp[k] = 0.f; }
-    for (int t = 0; t < L + KS - 1; ++t) {
-#pragma unroll
-        for (int k = 0; k < KS - 1; ++k) { win[k] = win[k + 1]; dp[k] = dp[k + 1]; }
+    const float* xb = x + (size_t)b * L * ED + e;
+    for (int t = wave; t < L + KS - 1; t += 4) {
         float d = 0.f;
-        if (t < L) {
-            win[KS - 1] = x[((size_t)b * L + t) * ED + e];
+        if (t < L && live) {
+            float win[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) { const int tt = t + k - (KS - 1); win[k] = tt >= 0 ? xb[(size_t)tt * ED] : 0.f; }
             float pre = bv;
 #pragma unroll
             for (int k = 0; k < KS; ++k) pre = fmaf(wk[k], win[k], pre);
@@ -94,22 +106,33 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < KS; ++k) dwacc[k] = fmaf(d, win[k], dwacc[k]);
             dbacc += d;
-        } else {
-            win[KS - 1] = 0.f;
         }
-        dp[KS - 1] = d;
-        // dpre is now known up to step t: dx[t - (KS-1)] = sum_k w[k] * dpre[t - k]
-        const int tx = t - (KS - 1);
-        if (tx >= 0) {
+        sp[t * 64 + lane] = d;                           // rows L .. L+KS-2 stay zero: dpre beyond the sequence
+    }
+    __syncthreads();
+    if (live) {
+        for (int t = wave; t < L; t += 4) {
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], dp[KS - 1 - k], acc);
-            dx[((size_t)b * L + tx) * ED + e] = acc;
+            for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], sp[(t + (KS - 1) - k) * 64 + lane], acc);
+            dx[((size_t)b * L + t) * ED + e] = acc;
         }
     }
+    __syncthreads();
+    float* part = sp;                                    // reuse: [4][KS + 1][64]
 #pragma unroll
-    for (int k = 0; k < KS; ++k) atomicAdd(dw + e * KS + k, dwacc[k]);
-    if (db) atomicAdd(db + e, dbacc);
+    for (int k = 0; k < KS; ++k) part[(wave * (KS + 1) + k) * 64 + lane] = dwacc[k];
+    part[(wave * (KS + 1) + KS) * 64 + lane] = dbacc;
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int k = 0; k <= KS; ++k) {
+            const float t = part[(0 * (KS + 1) + k) * 64 + lane] + part[(1 * (KS + 1) + k) * 64 + lane] +
+                            part[(2 * (KS + 1) + k) * 64 + lane] + part[(3 * (KS + 1) + k) * 64 + lane];
+            if (k < KS) atomicAdd(dw + e * KS + k, t);
+            else if (db) atomicAdd(db + e, t);
+        }
+    }
 }
 
 }  // namespace
@@ -127,7 +150,9 @@ int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const flo
                     int64_t rows, int64_t dim, void* stream) {
     GFE_REQUIRE(x && w && rstd && dy && dx && dw_zeroed, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, rstd, dy, dx, dw_zeroed, (int)rows, (int)dim);
+    GFE_REQUIRE(dim <= 16384, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)ceil_div(rows, 4 * RMS_RB)), dim3(256), (size_t)dim * sizeof(float), (hipStream_t)stream,
+                       x, w, rstd, dy, dx, dw_zeroed, (int)rows, (int)dim);
     return gfe_launch_status();
 }
 
@@ -142,8 +167,10 @@ int gfe_dwconv1d_silu_bwd(const float* x, const float* w, const float* bias, con
                           int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
     GFE_REQUIRE(x && w && dy && dx && dw_zeroed, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL((dwconv_silu_bwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, dy, dx,
-                       dw_zeroed, db_zeroed, (int)L, (int)ED);
+    const size_t rows = (size_t)L + 3 > 20 ? (size_t)L + 3 : 20;          // dpre rows, reused for the 4 x 5 partial rows
+    GFE_REQUIRE(rows * 64 * sizeof(float) <= 64 * 1024, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((dwconv_silu_bwd_kernel<4>), dim3((unsigned)ceil_div(ED, 64), (unsigned)B), dim3(256), rows * 64 * sizeof(float), (hipStream_t)stream,
+                       x, w, bias, dy, dx, dw_zeroed, db_zeroed, (int)L, (int)ED);
     return gfe_launch_status();
 }
 

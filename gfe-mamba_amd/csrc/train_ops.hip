@@ -10,105 +10,114 @@
 namespace {
 
 // ---- head Linear forward: out[b][src*C + c][s] += sum_{hw in chunk} mid_src[b][hw][c] * W[s][hw] --------------------
-// grid (chunks, 2*B): blockIdx.y = b*2 + src.  64 lanes x 8 channels = 512 channels per wave pass; 4 waves split the rows.
+// A skinny reduction over hw (13 824 rows of 512 B per (sample, tensor)): HBM-bound.  grid (chunks, 2*B), blockIdx.y = b*2 + src.
+// Thread = (row slot, 16-byte channel chunk): every lane streams; 4 rows in flight per thread; Wt is W transposed to (HW, S) so a
+// row's S weights are one float4.  The block's row slots are folded through LDS, one f32 atomic per (channel, s) and block.
 template <int S>
 __global__ __launch_bounds__(256) void mid_linear_fwd_kernel(const bf16_t* __restrict__ mid_in, const bf16_t* __restrict__ mid_out,
-                                                             const float* __restrict__ W, float* __restrict__ out,
+                                                             const float* __restrict__ Wt, float* __restrict__ out,
                                                              int HW, int C, int rows_per_block) {
-    extern __shared__ float red[];                       // [4 waves][S][C]
+    static_assert(S == 4, "a row's weights are read as one float4");
+    extern __shared__ float red[];                       // [row slots][S][C]
     const int b = blockIdx.y >> 1, src = blockIdx.y & 1;
     const bf16_t* mid = (src ? mid_out : mid_in) + (size_t)b * HW * C;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int CP = C >> 3, RPP = 256 / CP;               // chunks per row, rows per pass
+    const int chunk = threadIdx.x % CP, rs = threadIdx.x / CP;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
-    for (int c0 = 0; c0 < C; c0 += 512) {
-        const int c = c0 + lane * 8;
-        float acc[S][8];
+    float acc[S][8];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+    if (rs < RPP) {
+        for (int rb = r0 + rs; rb < r1; rb += 4 * RPP) {
+            uint4 v[4]; float4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rb + k * RPP;
+                const int rc = r < r1 ? r : r0;                                  // clamped: the tail contributes with weight 0
+                v[k] = *reinterpret_cast<const uint4*>(mid + (size_t)rc * C + chunk * 8);
+                w[k] = r < r1 ? *reinterpret_cast<const float4*>(Wt + (size_t)rc * S) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f[8] = {bf16lo_to_f32(v[k].x), bf16hi_to_f32(v[k].x), bf16lo_to_f32(v[k].y), bf16hi_to_f32(v[k].y),
+                                    bf16lo_to_f32(v[k].z), bf16hi_to_f32(v[k].z), bf16lo_to_f32(v[k].w), bf16hi_to_f32(v[k].w)};
+                const float ws[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[s][j] = fmaf(f[j], ws[s], acc[s][j]);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
-        if (c < C) {
-#pragma unroll 4
-            for (int r = r0 + wave; r < r1; r += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(mid + (size_t)r * C + c);
-                const float f[8] = {bf16lo_to_f32(v.x), bf16hi_to_f32(v.x), bf16lo_to_f32(v.y), bf16hi_to_f32(v.y),
-                                    bf16lo_to_f32(v.z), bf16hi_to_f32(v.z), bf16lo_to_f32(v.w), bf16hi_to_f32(v.w)};
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float w = W[(size_t)s * HW + r];          // wave-uniform
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[s][j] = fmaf(f[j], w, acc[s][j]);
-                }
-            }
-        }
-        __syncthreads();
-        if (c < C) {
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) red[(wave * S + s) * 512 + lane * 8 + j] = acc[s][j];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < S * 512; i += 256) {
-            const int s = i / 512, cc = i - s * 512;
-            if (c0 + cc < C) {
-                const float t = red[(0 * S + s) * 512 + cc] + red[(1 * S + s) * 512 + cc] + red[(2 * S + s) * 512 + cc] + red[(3 * S + s) * 512 + cc];
-                atomicAdd(out + ((size_t)b * 2 * C + src * C + c0 + cc) * S + s, t);
-            }
-        }
+            for (int j = 0; j < 8; ++j) red[(rs * S + s) * C + chunk * 8 + j] = acc[s][j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * C; i += 256) {
+        const int s = i / C, c = i - s * C;
+        float t = 0.f;
+        for (int k = 0; k < RPP; ++k) t += red[(k * S + s) * C + c];
+        atomicAdd(out + ((size_t)b * 2 * C + src * C + c) * S + s, t);
     }
 }
 
 // ---- head Linear weight gradient: dW[s][hw] = sum_{b,src,c} dout[b][src*C+c][s] * mid_src[b][hw][c] -------------------
-// one wave per hw row; dout of one (b, src) staged in LDS as [S][C].
+// All of dout (B x 2C x S f32, 64 KB at the model's size) sits in LDS; a row of hw is handled by C/8 lanes (16 B each), which stream
+// the row's 2*B pieces with all loads in flight, multiply against the LDS copy and fold their S partial sums with DPP adds.
 template <int S>
 __global__ __launch_bounds__(256) void mid_linear_wgrad_kernel(const bf16_t* __restrict__ mid_in, const bf16_t* __restrict__ mid_out,
                                                                const float* __restrict__ dout, float* __restrict__ dW,
                                                                int B, int HW, int C, int rows_per_block) {
-    extern __shared__ float sd[];                        // [S][C]
+    static_assert(S == 4, "dout rows are read as float4");
+    extern __shared__ __attribute__((aligned(16))) float sd[];          // [2B][C][S]
+    const int nbs = 2 * B;
+    for (int i = threadIdx.x; i < nbs * C; i += 256) {
+        const int bs = i / C, c = i - bs * C, b = bs >> 1, src = bs & 1;
+        reinterpret_cast<float4*>(sd)[i] = *reinterpret_cast<const float4*>(dout + ((size_t)b * 2 * C + src * C + c) * S);
+    }
+    __syncthreads();
+    const int CP = C >> 3;                               // lanes per row (a power of two <= 64: checked by the host)
+    const int RPW = 64 / CP;                             // rows per wave pass
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = lane % CP, rsub = lane / CP;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
-    constexpr int RPW = 4;                               // rows per wave held in registers
-    float acc[RPW][S];
-    // rows of this wave: r0 + wave + 4*k
-    for (int rb = r0; rb < r1; rb += 4 * RPW) {
+    for (int rb = r0 + wave * RPW; rb < r1; rb += 4 * RPW) {
+        const int r = rb + rsub;
+        const int rc = r < r1 ? r : r0;
+        float acc[S] = {0.f, 0.f, 0.f, 0.f};
+        for (int bs0 = 0; bs0 < nbs; bs0 += 8) {
+            uint4 v[8];
 #pragma unroll
-        for (int k = 0; k < RPW; ++k)
-#pragma unroll
-            for (int s = 0; s < S; ++s) acc[k][s] = 0.f;
-        for (int bs = 0; bs < 2 * B; ++bs) {
-            const int b = bs >> 1, src = bs & 1;
-            __syncthreads();
-            for (int i = threadIdx.x; i < S * C; i += 256) {
-                const int c = i / S, s = i - c * S;
-                sd[s * C + c] = dout[((size_t)b * 2 * C + src * C + c) * S + s];
+            for (int k = 0; k < 8; ++k) {
+                const int bs = bs0 + k < nbs ? bs0 + k : nbs - 1;
+                const bf16_t* mid = ((bs & 1) ? mid_out : mid_in) + ((size_t)(bs >> 1) * HW + rc) * C;
+                v[k] = *reinterpret_cast<const uint4*>(mid + chunk * 8);
             }
-            __syncthreads();
-            const bf16_t* mid = (src ? mid_out : mid_in) + (size_t)b * HW * C;
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-                const int r = rb + wave + 4 * k;
-                if (r < r1) {
-                    for (int c = lane * 8; c < C; c += 512) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(mid + (size_t)r * C + c);
-                        const float f[8] = {bf16lo_to_f32(v.x), bf16hi_to_f32(v.x), bf16lo_to_f32(v.y), bf16hi_to_f32(v.y),
-                                            bf16lo_to_f32(v.z), bf16hi_to_f32(v.z), bf16lo_to_f32(v.w), bf16hi_to_f32(v.w)};
+            for (int k = 0; k < 8; ++k) {
+                if (bs0 + k < nbs) {
+                    const float f[8] = {bf16lo_to_f32(v[k].x), bf16hi_to_f32(v[k].x), bf16lo_to_f32(v[k].y), bf16hi_to_f32(v[k].y),
+                                        bf16lo_to_f32(v[k].z), bf16hi_to_f32(v[k].z), bf16lo_to_f32(v[k].w), bf16hi_to_f32(v[k].w)};
+                    const float4* dv = reinterpret_cast<const float4*>(sd) + (size_t)(bs0 + k) * C + chunk * 8;
 #pragma unroll
-                        for (int s = 0; s < S; ++s)
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[k][s] = fmaf(f[j], sd[s * C + c + j], acc[k][s]);
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 d = dv[j];
+                        acc[0] = fmaf(f[j], d.x, acc[0]); acc[1] = fmaf(f[j], d.y, acc[1]);
+                        acc[2] = fmaf(f[j], d.z, acc[2]); acc[3] = fmaf(f[j], d.w, acc[3]);
                     }
                 }
             }
         }
+        // fold the CP lanes of the row (xor butterflies stay inside the row's aligned lane group)
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const int r = rb + wave + 4 * k;
+        for (int s = 0; s < S; ++s)
+            for (int o = CP >> 1; o > 0; o >>= 1) acc[s] += __shfl_xor(acc[s], o, 64);
+        if (chunk == 0 && r < r1) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float t = wave_sum(acc[k][s]);
-                if (lane == 0 && r < r1) dW[(size_t)s * HW + r] = t;
-            }
+            for (int s = 0; s < S; ++s) dW[(size_t)s * HW + r] = acc[s];
         }
     }
 }
@@ -176,17 +185,25 @@ __global__ __launch_bounds__(256) void interleave_rows_kernel(const float* __res
 }
 
 // column sums of a row-major (M, N) f32 matrix (bias gradients): block = 256 threads covers 64 columns x 4 row-strips
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int64_t ld, int accumulate) {
+// out[c] (+)= sum over rows [blockIdx.y*rows_per_block, ...) of x[r][c]: 4 row strips x 64 columns per block, strips folded in LDS.
+// One row block: plain store / read-modify-write; several: f32 atomics onto a zeroed (or accumulating) out.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int64_t ld, int accumulate,
+                                                     int rows_per_block) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (c < N)
-        for (int r = strip; r < M; r += 4) acc += x[(size_t)r * ld + c];
-    red[strip][threadIdx.x & 63] = acc;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < N) {
+        int r = r0 + strip;
+        for (; r + 4 < r1; r += 8) { a0 += x[(size_t)r * ld + c]; a1 += x[(size_t)(r + 4) * ld + c]; }
+        if (r < r1) a0 += x[(size_t)r * ld + c];
+    }
+    red[strip][threadIdx.x & 63] = a0 + a1;
     __syncthreads();
     if (strip == 0 && c < N) {
         const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[c] = accumulate ? out[c] + t : t;
+        if (gridDim.y > 1) atomicAdd(out + c, t);
+        else out[c] = accumulate ? out[c] + t : t;
     }
 }
 
@@ -197,28 +214,45 @@ extern "C" {
 int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream) {
     GFE_REQUIRE(x && out, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && M <= 0x7fffffff && N <= 0x7fffffff, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, x, out, (int)M, (int)N, ld, accumulate);
+    // the column blocks alone are ceil(N/64): split the rows too until the launch has a few hundred blocks
+    int64_t rblocks = ceil_div((int64_t)256, ceil_div(N, 64));
+    if (rblocks > ceil_div(M, 32)) rblocks = ceil_div(M, 32);
+    if (rblocks < 1) rblocks = 1;
+    const int rpb = (int)ceil_div(M, rblocks);
+    rblocks = ceil_div(M, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (rblocks > 1 && !accumulate) (void)hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)rblocks), dim3(256), 0, st, x, out, (int)M, (int)N, ld, accumulate, rpb);
     return gfe_launch_status();
 }
 
-int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* W, float* out_zeroed,
+int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt, float* out_zeroed,
                        int64_t B, int64_t HW, int64_t C, int64_t S, void* stream) {
-    GFE_REQUIRE(mid_in && mid_out && W && out_zeroed, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && S == 4, GFE_ERR_SHAPE);
-    int rpb = (int)ceil_div(HW, 128);
-    if (rpb < 16) rpb = 16;
+    GFE_REQUIRE(mid_in && mid_out && Wt && out_zeroed, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 32767 && HW > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && 256 % (C / 8) == 0 && S == 4, GFE_ERR_SHAPE);
+    // ~512 blocks: enough to stream at HBM rate, few enough that the atomics stay 32-way
+    int64_t chunks = ceil_div((int64_t)512, 2 * B);
+    int rpb = (int)ceil_div(HW, chunks);
+    if (rpb < 32) rpb = 32;
     const dim3 grid((unsigned)ceil_div(HW, rpb), (unsigned)(2 * B));
-    hipLaunchKernelGGL((mid_linear_fwd_kernel<4>), grid, dim3(256), 4 * 4 * 512 * sizeof(float), (hipStream_t)stream,
-                       (const bf16_t*)mid_in, (const bf16_t*)mid_out, W, out_zeroed, (int)HW, (int)C, rpb);
+    const size_t lds = (size_t)(256 / (C / 8)) * S * C * sizeof(float);
+    GFE_REQUIRE(lds <= 64 * 1024, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((mid_linear_fwd_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t*)mid_in, (const bf16_t*)mid_out, Wt, out_zeroed, (int)HW, (int)C, rpb);
     return gfe_launch_status();
 }
 
 int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* dout, float* dW,
                          int64_t B, int64_t HW, int64_t C, int64_t S, void* stream) {
     GFE_REQUIRE(mid_in && mid_out && dout && dW, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && S == 4 && S * C * sizeof(float) <= 64 * 1024, GFE_ERR_SHAPE);
-    const int rpb = 16;
-    hipLaunchKernelGGL((mid_linear_wgrad_kernel<4>), dim3((unsigned)ceil_div(HW, rpb)), dim3(256), (size_t)S * C * sizeof(float),
+    const int64_t CP = C / 8;
+    GFE_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && S == 4 && CP >= 1 && CP <= 64 && (CP & (CP - 1)) == 0, GFE_ERR_SHAPE);
+    const size_t lds = (size_t)2 * B * C * S * sizeof(float);
+    GFE_REQUIRE(lds <= 128 * 1024, GFE_ERR_SHAPE);
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) { (void)hipFuncSetAttribute((const void*)mid_linear_wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    const int rpb = 32;
+    hipLaunchKernelGGL((mid_linear_wgrad_kernel<4>), dim3((unsigned)ceil_div(HW, rpb)), dim3(256), lds,
                        (hipStream_t)stream, (const bf16_t*)mid_in, (const bf16_t*)mid_out, dout, dW, (int)B, (int)HW, (int)C, rpb);
     return gfe_launch_status();
 }

@@ -128,8 +128,8 @@ class _MidLinearFn(torch.autograd.Function):
         B, H, W, C = mid_in.shape
         S = weight.shape[0]
         out = torch.zeros((B, 2 * C, S), dtype=torch.float32, device=mid_in.device)
-        w = weight.detach().float().contiguous()
-        call("gfe_mid_linear_fwd", ptr(mid_in), ptr(mid_out), ptr(w), ptr(out), B, H * W, C, S, stream())
+        wt = weight.detach().float().t().contiguous()          # (HW, S): one 16-byte load per row in the kernel
+        call("gfe_mid_linear_fwd", ptr(mid_in), ptr(mid_out), ptr(wt), ptr(out), B, H * W, C, S, stream())
         ctx.save_for_backward(mid_in, mid_out)
         ctx.S = S
         return out + bias.detach().float()

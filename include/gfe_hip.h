@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 12
+#define GFE_ABI_VERSION 13
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -229,8 +229,9 @@ int gfe_vit_embed(const float* tok, const float* cls, const float* pos, float* x
 /* Combine_classfier_vit_mid (classify/classifier.py:329-333): Linear(H*W -> S) over cat([mid_input, mid_output], dim=1),
  * evaluated on the generator's channels-last mid features without materialising the concat:
  *   out[b][src*C + c][s] = sum_hw mid_src[b][hw][c] * W[s][hw]      (bias and the final transpose are host-side views)
- * mid_in, mid_out: (B, HW, C) bf16; W: (S, HW) f32; out_zeroed: (B, 2C, S) f32, zero on entry (atomic accumulation). S == 4. */
-int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* W, float* out_zeroed,
+ * mid_in, mid_out: (B, HW, C) bf16; Wt: the weight TRANSPOSED to (HW, S) f32 (a row's S weights are one 16-byte load);
+ * out_zeroed: (B, 2C, S) f32, zero on entry (atomic accumulation). S == 4, 256 % (C/8) == 0. */
+int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt, float* out_zeroed,
                        int64_t B, int64_t HW, int64_t C, int64_t S, void* stream);
 
 /* Weight gradient of the above: dW[s][hw] = sum_{b,c} dout[b][c][s] * mid[b][hw][c]; dout: (B, 2C, S) f32; dW: (S, HW) f32. */
