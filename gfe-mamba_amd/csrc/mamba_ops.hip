@@ -20,59 +20,63 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     for (int c = lane; c < dim; c += 64) yr[c] = xr[c] * r * w[c];
 }
 
-// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd.  Block = 4 waves x RB rows each; the weight
-// gradient is folded in LDS first (a per-row global atomic per column is 296-way contended on 512 addresses: measured 23 us).
-constexpr int RMS_RB = 4;          // rows per wave
+// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd.  One row per wave at a time, RB rows per wave; a
+// lane owns columns lane + 64 i and keeps their weight-gradient partials in registers over its rows (a global atomic per row and
+// column is 296-way contended on 512 addresses: 23 us; LDS float atomics are not much better), then waves fold through LDS.
+constexpr int RMS_RB = 2;          // rows per wave
+constexpr int RMS_CV = 16;         // columns per lane kept in registers (dim <= 1024)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ rstd,
                                                           const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
                                                           int rows, int dim) {
-    extern __shared__ float sdw[];                      // [dim]
+    extern __shared__ float sdw[];                      // [4][dim]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = threadIdx.x; c < dim; c += 256) sdw[c] = 0.f;
-    __syncthreads();
+    float wv[RMS_CV], dwacc[RMS_CV];
+#pragma unroll
+    for (int i = 0; i < RMS_CV; ++i) { const int c = lane + 64 * i; wv[i] = c < dim ? w[c] : 0.f; dwacc[i] = 0.f; }
     for (int k = 0; k < RMS_RB; ++k) {
         const int row = (blockIdx.x * 4 + wave) * RMS_RB + k;
         if (row >= rows) break;
         const float* xr = x + (size_t)row * dim;
         const float* gr = dy + (size_t)row * dim;
         const float r = rstd[row];
+        float xv[RMS_CV], gv[RMS_CV];
         float s = 0.f;
-        for (int c = lane; c < dim; c += 64) s = fmaf(gr[c] * w[c], xr[c], s);
+#pragma unroll
+        for (int i = 0; i < RMS_CV; ++i) {
+            const int c = lane + 64 * i;
+            xv[i] = c < dim ? xr[c] : 0.f; gv[i] = c < dim ? gr[c] : 0.f;
+            s = fmaf(gv[i] * wv[i], xv[i], s);
+        }
         s = wave_sum(s);
         const float kk = s * r * r / (float)dim;
         float* dxr = dx + (size_t)row * dim;
-        for (int c = lane; c < dim; c += 64) {
-            const float xv = xr[c], g = gr[c];
-            dxr[c] = r * (g * w[c] - xv * kk);
-            atomicAdd(&sdw[c], g * xv * r);             // LDS atomic, <= 4-way
+#pragma unroll
+        for (int i = 0; i < RMS_CV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < dim) dxr[c] = r * (gv[i] * wv[i] - xv[i] * kk);
+            dwacc[i] = fmaf(gv[i] * xv[i], r, dwacc[i]);
         }
     }
+#pragma unroll
+    for (int i = 0; i < RMS_CV; ++i) { const int c = lane + 64 * i; if (c < dim) sdw[wave * dim + c] = dwacc[i]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dw + c, sdw[c]);
+    for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dw + c, sdw[c] + sdw[dim + c] + sdw[2 * dim + c] + sdw[3 * dim + c]);
 }
 
 // ---- depthwise causal conv1d (kernel KS, left padding KS-1) + bias + SiLU on (B, L, ED); lane = channel --------------------
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                               float* __restrict__ y, int L, int ED) {
-    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    // one thread per (sample, step, channel): the KS-wide window is re-read (L1 hits) instead of carried through a sequential loop
+    const int e = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, b = blockIdx.z;
     if (e >= ED) return;
-    float wk[KS];
+    float pre = bias ? bias[e] : 0.f;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) wk[k] = w[e * KS + k];
-    const float bv = bias ? bias[e] : 0.f;
-    float win[KS];                                    // win[k] = x[t + k - (KS-1)]
-#pragma unroll
-    for (int k = 0; k < KS; ++k) win[k] = 0.f;
-    for (int t = 0; t < L; ++t) {
-#pragma unroll
-        for (int k = 0; k < KS - 1; ++k) win[k] = win[k + 1];
-        win[KS - 1] = x[((size_t)b * L + t) * ED + e];
-        float pre = bv;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) pre = fmaf(wk[k], win[k], pre);
-        y[((size_t)b * L + t) * ED + e] = pre * sigmoidf_(pre);
+    for (int k = 0; k < KS; ++k) {
+        const int tt = t + k - (KS - 1);
+        if (tt >= 0) pre = fmaf(w[e * KS + k], x[((size_t)b * L + tt) * ED + e], pre);
     }
+    y[((size_t)b * L + t) * ED + e] = pre * sigmoidf_(pre);
 }
 
 // backward: dpre = dy * silu'(pre); dx[t] = sum_k w[k] * dpre[t + (KS-1) - k]; dw[k] += dpre[t] * x[t + k - (KS-1)]; db += dpre.
@@ -150,16 +154,16 @@ int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const flo
                     int64_t rows, int64_t dim, void* stream) {
     GFE_REQUIRE(x && w && rstd && dy && dx && dw_zeroed, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
-    GFE_REQUIRE(dim <= 16384, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)ceil_div(rows, 4 * RMS_RB)), dim3(256), (size_t)dim * sizeof(float), (hipStream_t)stream,
+    GFE_REQUIRE(dim <= 64 * RMS_CV, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)ceil_div(rows, 4 * RMS_RB)), dim3(256), (size_t)4 * dim * sizeof(float), (hipStream_t)stream,
                        x, w, rstd, dy, dx, dw_zeroed, (int)rows, (int)dim);
     return gfe_launch_status();
 }
 
 int gfe_dwconv1d_silu_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
     GFE_REQUIRE(x && w && y, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL((dwconv_silu_fwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (int)L, (int)ED);
+    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && L <= 65535 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((dwconv_silu_fwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)L, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (int)L, (int)ED);
     return gfe_launch_status();
 }
 
