@@ -482,7 +482,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         for (int wv_ = 0; wv_ < NWAVES; ++wv_) t += sRed[wv_ * 2 * WROWS_TAP + tid];
                         const int st = tid / WROWS_TAP, c = group * WROWS_TAP + (tid - st * WROWS_TAP);
                         // the slot of the LAST tile that went into the sums: unique per flush; slots never written stay zero (caller-zeroed)
-                        const int slot = p.stats_slot0 + (cur.td * p.nth + cur.th) * p.ntw + cur.tw;
+                        // one channel group: a block leaves a sample at most once -> slot = block index (a 256-slot table);
+                        // several groups flush per (tile, group) -> slot = tile index inside the sample
+                        const int slot = p.stats_slot0 + (p.ngroups == 1 ? vb : (cur.td * p.nth + cur.th) * p.ntw + cur.tw);
                         if (c < p.Cout) p.stats[(((size_t)b * p.stats_nblk + slot) * 2 + st) * p.Cout + c] = t;
                     }
                 }
@@ -570,6 +572,13 @@ extern "C" {
 
 int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W) { return (int)(ceil_div(D, TD) * ceil_div(H, TH) * ceil_div(W, TW)); }
 
+int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout) {
+    const int64_t tps = gfe_conv3d_tiles(D, H, W), tiles = B * tps;
+    if (gfe_conv3d_cout_pad(Cout) > 64) return (int)tps;                    // several channel groups: one slot per tile
+    const int64_t tpb = ceil_div(tiles, 256);
+    return (int)ceil_div(tiles, tpb);                                        // one slot per persistent block
+}
+
 #if defined(GFE_EXP_STAMP)
 int gfe_debug_set_stamp_buffer(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -4; }
 #endif
@@ -641,7 +650,7 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
     }
     p.ntd = (int)ceil_div(D, TD); p.nth = (int)ceil_div(H, TH); p.ntw = (int)ceil_div(W, TW);
     p.stats = stats_ws; p.stats_nblk = (int)stats_nblk; p.stats_slot0 = (int)stats_slot0;
-    if (stats_ws) GFE_REQUIRE(stats_slot0 >= 0 && stats_slot0 + (int64_t)p.ntd * p.nth * p.ntw <= stats_nblk && stats_nblk <= 0x7fffffff, GFE_ERR_SHAPE);
+    if (stats_ws) GFE_REQUIRE(stats_slot0 >= 0 && stats_slot0 + gfe_conv3d_stat_slots(B, D, H, W, Cout) <= stats_nblk && stats_nblk <= 0x7fffffff, GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     // regular 3x3x3 tap list in canonical order -> immediate-offset fast path
     bool reg27 = ntaps == 27 && ostride == 1;

@@ -111,6 +111,11 @@ def conv_tiles(D, H, W):
     return lib().gfe_conv3d_tiles(D, H, W)
 
 
+def conv_stat_slots(B, D, H, W, cout):
+    """GroupNorm-partial slots per sample that one conv_igemm(stats=...) call writes (gfe_conv3d_stat_slots)."""
+    return lib().gfe_conv3d_stat_slots(B, D, H, W, cout)
+
+
 def new_gn_partials(B, nblk, C, device):
     """Zeroed workspace a producer fills with the GroupNorm partials of its output (gfe_hip.h: stats_ws): the conv kernel
     writes only the slots where one of its persistent blocks changes sample / ends, the rest must read as zero."""
@@ -139,7 +144,7 @@ def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu
     wstride = w_packed.stride(0) if w_packed.dim() == 5 else 0
     ws, slot0 = None, 0
     if stats is True:
-        ws = new_gn_partials(B, conv_tiles(D, H, W), cout, x.device)
+        ws = new_gn_partials(B, conv_stat_slots(B, D, H, W, cout), cout, x.device)
     elif stats is not None:
         ws, slot0 = stats
     call("gfe_conv3d_igemm", ptr(x), ptr(w_packed), wstride, ptr(bias), ptr(bias_tab), ptr(res), ptr(out),

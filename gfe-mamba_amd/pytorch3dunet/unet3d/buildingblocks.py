@@ -132,10 +132,10 @@ class TransposeConvUpsampling(nn.Module):
         classes = self._pack.get([ct.weight], lambda: K.pack_convT(ct.weight))
         out = torch.empty_like(encoder_features)
         B, D, H, W, _ = x.shape
-        tiles = K.conv_tiles(D, H, W)
-        ws = K.new_gn_partials(B, 8 * tiles, ct.out_channels, x.device)    # the 8 parity classes fill disjoint slot ranges
+        slots = K.conv_stat_slots(B, D, H, W, ct.out_channels)
+        ws = K.new_gn_partials(B, 8 * slots, ct.out_channels, x.device)    # the 8 parity classes fill disjoint slot ranges
         for i, (par, (w, taps)) in enumerate(classes.items()):
-            K.conv_igemm(x, w, taps, ct.out_channels, res=encoder_features, transposed=(par, out), stats=(ws, i * tiles))
+            K.conv_igemm(x, w, taps, ct.out_channels, res=encoder_features, transposed=(par, out), stats=(ws, i * slots))
         assert len(classes) == 8
         out.gn_partials = ws
         return out

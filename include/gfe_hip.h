@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 13
+#define GFE_ABI_VERSION 14
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -107,9 +107,10 @@ int gfe_conv3d_cout_pad(int64_t Cout);
  *   stats_ws (or NULL): GroupNorm partials of the tensor this call STORES, for the GroupNorm of the next SingleConv -- saves
  *   re-reading y.  Layout (B, stats_nblk, 2, Cout) f32, ZEROED by the caller: [.,slot,0,c] = sum, [.,slot,1,c] = sum of squares of
  *   the rounded bf16 outputs.  A persistent block keeps per-lane sums over its run of 8x8x8 tiles and stores them (plain stores,
- *   fixed order: deterministic) when its run leaves the sample / channel group or ends, into slot = stats_slot0 + index inside
- *   the sample of the run's last tile (< gfe_conv3d_tiles); all other slots stay zero.  Calls that build one tensor together
- *   (the 8 parity classes of a transposed conv) use disjoint slot ranges;
+ *   fixed order: deterministic) when its run leaves the sample / channel group or ends.  The call uses the slots
+ *   stats_slot0 .. stats_slot0 + gfe_conv3d_stat_slots(B, D, H, W, Cout) - 1 (one per persistent block when Cout <= 64, one per
+ *   tile otherwise); slots it does not write stay zero.  Calls that build one tensor together (the 8 parity classes of a
+ *   transposed conv) use disjoint slot ranges;
  *   consume with gfe_groupnorm_from_partials. */
 int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias, const float* bias_tab,
                      const void* res, void* y,
@@ -121,6 +122,8 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
 
 /* Number of 8x8x8 output tiles per sample of gfe_conv3d_igemm on a (D, H, W) class grid = partial slots one call writes. Host-only. */
 int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W);
+/* GroupNorm-partial slots per sample one gfe_conv3d_igemm call with stats_ws writes (see above). Host-only. */
+int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout);
 
 /* Folds GroupNorm(x) = scale[b,c]*x + shift[b,c] (from gfe_groupnorm_scale_shift) into the convolution that consumes it
  * (create_conv order 'g' before 'c', buildingblocks.py:55-67; zero padding is applied AFTER the norm):
