@@ -251,7 +251,7 @@ int gfe_groupnorm_from_partials(const float* ws, int64_t nblk, const float* gamm
     GFE_REQUIRE(ws && gamma && beta && scale && shift, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 65535 && S > 0 && nblk > 0 && nblk <= 0x7fffffff && C > 0 && G > 0 && C % G == 0 && G <= 256 && 2 * C <= 1024, GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
-    if (nblk > 128) {
+    if (nblk > 512) {
         GFE_REQUIRE(ws2, GFE_ERR_NULL);
         hipLaunchKernelGGL(gn_reduce_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, ws, ws2, (int)nblk, (int)(2 * C));
         ws = ws2; nblk = 32;

@@ -163,7 +163,7 @@ def groupnorm_scale_shift(x, gamma, beta, groups, eps=1e-5):
     if part is not None:                         # the producer of x already reduced it tile by tile
         nblk = part.shape[1]
         ss = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
-        ws2 = torch.empty((B, 32, 2, C), dtype=torch.float32, device=x.device) if nblk > 128 else None
+        ws2 = torch.empty((B, 32, 2, C), dtype=torch.float32, device=x.device) if nblk > 512 else None
         call("gfe_groupnorm_from_partials", ptr(part), nblk, ptr(gamma), ptr(beta), ptr(ss[0]), ptr(ss[1]), ptr(ws2), B, S, C, groups, eps, stream())
         return ss[0], ss[1]
     vpb, nblk = ctypes.c_int(), ctypes.c_int()

@@ -142,7 +142,7 @@ int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* be
 
 /* The same affine from partials a producer already wrote (gfe_conv3d_igemm / gfe_conv_in1 `stats_ws`): ws (B, nblk, 2, C) f32
  * per-slot channel sums / sums of squares over disjoint voxel sets covering all S voxels.  ws2: (B, 32, 2, C) f32 scratch
- * (used when nblk > 128: a first kernel folds the slots 32-ways in parallel). */
+ * (used when nblk > 512: a first kernel folds the slots 32-ways in parallel). */
 int gfe_groupnorm_from_partials(const float* ws, int64_t nblk, const float* gamma, const float* beta, float* scale, float* shift,
                                 float* ws2, int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream);
 
