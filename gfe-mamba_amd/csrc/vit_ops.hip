@@ -76,49 +76,45 @@ __global__ __launch_bounds__(1024) void layernorm_kernel(const TI* __restrict__ 
     }
 }
 
-// softmax(q k^T * scale) v for short sequences: one block per (batch, head); q, k, v rows are read with arbitrary
-// row strides so packed qkv buffers work.  nq, nk <= 256, dh <= 64 and a multiple of 8.  f32 math, bf16 I/O.
+// softmax(q k^T * scale) v for short sequences: block = (batch, head) x 4 query rows (one per wave); q, k, v rows are read with
+// arbitrary row strides so packed qkv buffers work.  nq, nk <= 256, dh <= 64.  f32 math, bf16 I/O.  K and V (a few KB) are staged
+// per block: re-staging them for every 4 queries is cheaper than walking all queries of a head sequentially in one block.
 __global__ __launch_bounds__(256) void attn_small_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                          bf16_t* __restrict__ o, int H, int nq, int nk, int dh,
                                                          int64_t qb, int64_t qr, int64_t kb, int64_t kr, int64_t vb, int64_t vr,
                                                          int64_t ob, int64_t orow, float scale) {
-    extern __shared__ float sm[];                 // K [nk][dh+1], V [nk][dh+1], P [4][nk]
+    extern __shared__ float sm[];                 // K [nk][dh+1], V [nk][dh+1], P [4][nk], Q [4][dh]
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int ld = dh + 1;
-    float* sK = sm; float* sV = sm + nk * ld; float* sP = sV + nk * ld;
+    float* sK = sm; float* sV = sm + nk * ld; float* sP = sV + nk * ld; float* sQ = sP + 4 * nk;
     for (int i = threadIdx.x; i < nk * dh; i += 256) {
         const int r = i / dh, c = i - r * dh;
         sK[r * ld + c] = bf16_to_f32(k[b * kb + (int64_t)r * kr + h * dh + c]);
         sV[r * ld + c] = bf16_to_f32(v[b * vb + (int64_t)r * vr + h * dh + c]);
     }
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int iq = blockIdx.y * 4 + wave;
+    if (iq < nq && lane < dh) sQ[wave * dh + lane] = bf16_to_f32(q[b * qb + (int64_t)iq * qr + h * dh + lane]) * scale;
+    __syncthreads();
+    if (iq >= nq) return;
     float* P = sP + wave * nk;
-    for (int iq = wave; iq < nq; iq += 4) {        // one wave per query row
-        const float qv = lane < dh ? bf16_to_f32(q[b * qb + (int64_t)iq * qr + h * dh + lane]) : 0.f;
-        float mx = -3.0e38f;
-        for (int j0 = 0; j0 < nk; j0 += 64) {
-            const int j = j0 + lane;
-            float sc = 0.f;
-            for (int c = 0; c < dh; ++c) {
-                const float qc = __shfl(qv, c, 64);
-                if (j < nk) sc = fmaf(qc, sK[j * ld + c], sc);
-            }
-            sc *= scale;
-            if (j < nk) { P[j] = sc; mx = fmaxf(mx, sc); }
-        }
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lane; j < nk; j += 64) { const float e = __expf(P[j] - mx); P[j] = e; sum += e; }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < dh) {
-            float acc = 0.f;
-            for (int j = 0; j < nk; ++j) acc = fmaf(P[j], sV[j * ld + lane], acc);
-            o[b * ob + (int64_t)iq * orow + h * dh + lane] = f32_to_bf16(acc * inv);
-        }
-        __builtin_amdgcn_wave_barrier();
+    const float* Q = sQ + wave * dh;
+    float mx = -3.0e38f;
+    for (int j = lane; j < nk; j += 64) {
+        float sc = 0.f;
+        for (int c = 0; c < dh; ++c) sc = fmaf(Q[c], sK[j * ld + c], sc);          // Q[c]: LDS broadcast
+        P[j] = sc; mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) { const float e = __expf(P[j] - mx); P[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < dh) {
+        float acc = 0.f;
+        for (int j = 0; j < nk; ++j) acc = fmaf(P[j], sV[j * ld + lane], acc);
+        o[b * ob + (int64_t)iq * orow + h * dh + lane] = f32_to_bf16(acc * inv);
     }
 }
 
@@ -182,9 +178,9 @@ int gfe_attention_small(const void* q, const void* k, const void* v, void* o, in
                         int64_t o_batch, int64_t o_row, float scale, void* stream) {
     GFE_REQUIRE(q && k && v && o, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && H > 0 && nq > 0 && nk > 0 && nk <= 256 && dh > 0 && dh <= 64, GFE_ERR_SHAPE);
-    const size_t lds = (2 * (size_t)nk * (dh + 1) + 4 * (size_t)nk) * sizeof(float);
-    GFE_REQUIRE(lds <= 64 * 1024, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * H)), dim3(256), lds, (hipStream_t)stream,
+    const size_t lds = (2 * (size_t)nk * (dh + 1) + 4 * (size_t)nk + 4 * (size_t)dh) * sizeof(float);
+    GFE_REQUIRE(lds <= 64 * 1024 && B * H <= 0x7fffffff && nq <= 65535 * 4, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)(B * H), (unsigned)ceil_div(nq, 4)), dim3(256), lds, (hipStream_t)stream,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, (int)H, (int)nq, (int)nk, (int)dh,
                        q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale);
     return gfe_launch_status();
