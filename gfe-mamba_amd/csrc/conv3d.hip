@@ -88,9 +88,12 @@ struct ConvParams {
     int ntd, nth, ntw, tiles_per_block;
     int toff[27];                              // LDS byte offset of each tap inside the halo tile
     int txor[27];                              // 32 when the tap shifts the row parity (swizzle term), else 0
+    // multi-class launches (the 8 parity classes of a transposed conv in ONE launch, work item = (tile, class)): class c uses taps
+    // c_tap0[c] .. c_tap0[c] + c_ntaps[c] - 1 of toff / txor, the weight set at element offset c_woff[c], output parity c_op[c]
+    int ncls; int c_ntaps[8]; int c_tap0[8]; int c_op[8]; long long c_woff[8]; unsigned w_bytes;
 };
 
-struct TilePos { int b, td, th, tw; };
+struct TilePos { int b, td, th, tw, cls; };
 
 #if defined(GFE_EXP_STAMP)     // diagnostic build only: in-kernel cycle stamps of one block (tools/conv_stamps.py); never in the product library
 __device__ unsigned long long* g_stamp_buf = nullptr;
@@ -99,7 +102,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define GFE_STAMP(slot) do {} while (0)
 #endif
 
-template <int NT, int TPS, bool REG27, bool STATS>
+template <int NT, int TPS, bool REG27, bool STATS, bool MC>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer/LDS-DMA builtins)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    const int ntiles = p.B * p.ntd * p.nth * p.ntw;
+    const int ntiles = p.B * p.ntd * p.nth * p.ntw * (MC ? p.ncls : 1);       // work items: (tile, class) with the class innermost
     // XCD-aware placement: blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so the blocks of one XCD
     // get ADJACENT tile ranges -- halo planes shared by neighbouring ranges are then served by that XCD's own L2 instead of being
     // fetched once per XCD (measured: 2.0 GB FETCH_SIZE for a 0.9 GB input before the remap).  Speed only, never correctness.
@@ -124,7 +127,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     const int upt = p.ngroups * p.nslab;                     // units per tile: (group, slab)
     const int nunits = (tile_end - tile_begin) * upt;
     if (nunits <= 0) return;
-    const int nstage = (p.ntaps + TPS - 1) / TPS;
 #if defined(GFE_EXP_STAMP)
     const bool stamp_on = g_stamp_buf != nullptr && blockIdx.x == 101;
     int stamp_i = 0;
@@ -172,12 +174,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     TilePos cur;
     {
         int t = tile_begin;
+        cur.cls = 0;
+        if constexpr (MC) { cur.cls = t % p.ncls; t /= p.ncls; }
         cur.tw = t % p.ntw; t /= p.ntw;
         cur.th = t % p.nth; t /= p.nth;
         cur.td = t % p.ntd; cur.b = t / p.ntd;
     }
     TilePos nxt = cur;
     auto advance = [&](TilePos& q) {
+        if constexpr (MC) { if (++q.cls < p.ncls) return; q.cls = 0; }
         if (++q.tw == p.ntw) { q.tw = 0; if (++q.th == p.nth) { q.th = 0; if (++q.td == p.ntd) { q.td = 0; ++q.b; } } }
     };
 
@@ -214,10 +219,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             }
         }
     };
-    auto w_dma = [&](int b, int group, int slab, int stage, int buf) {
-        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(p.w + (size_t)rfl(b) * p.w_batch_stride, wset_bytes);
+    auto w_dma = [&](const TilePos& q, int group, int slab, int stage, int buf) {
         // taps beyond ntaps in the last stage read past the slab (still inside the set, or OOB -> zeros): never multiplied
-        const unsigned soff = (unsigned)rfl((int)((((size_t)slab * p.ntaps + stage * TPS) * p.CoutPad + group * WROWS_TAP) * 64));
+        const int ntaps_q = MC ? p.c_ntaps[rfl(q.cls)] : p.ntaps;
+        const __amdgpu_buffer_rsrc_t rs = MC ? uniform_rsrc(p.w + p.c_woff[rfl(q.cls)], p.w_bytes - (unsigned)(p.c_woff[rfl(q.cls)] * 2))
+                                             : uniform_rsrc(p.w + (size_t)rfl(q.b) * p.w_batch_stride, wset_bytes);
+        const unsigned soff = (unsigned)rfl((int)((((size_t)slab * ntaps_q + stage * TPS) * p.CoutPad + group * WROWS_TAP) * 64));
         const int lds_off = rfl(buf) * (W_PIECES * 1024);
 #pragma unroll
         for (int j = 0; j < W_PER_WAVE; ++j) {
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         for (int i = 0; i < 4 * NT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
     }
 
-    if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur.b, 0, 0, 0, 0);
+    if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur, 0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
 
@@ -249,6 +256,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         const int group1 = ut1 / p.nslab, slab1 = ut1 - group1 * p.nslab;
         if (next_unit && ut1 == 0) advance(nxt);
         const uint8_t* aT = sA + (u & 1) * A_BYTES;
+        const int ntaps_u = MC ? p.c_ntaps[cur.cls] : p.ntaps, tap0_u = MC ? p.c_tap0[cur.cls] : 0;
+        const int nstage = (ntaps_u + TPS - 1) / TPS;
 
         if (slab == 0) {
 #pragma unroll
@@ -280,8 +289,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // refill the buffers nobody reads any more: next stage's weights, and (once per unit) the next unit's tile
 #if !defined(GFE_EXP_NOW)      // timing experiment only: weights are never restaged
             if (!a_wave) {
-                if (s + 1 < nstage) w_dma(cur.b, group, slab, s + 1, (gstage + 1) & 1);
-                else if (next_unit) w_dma(nxt.b, group1, slab1, 0, (gstage + 1) & 1);
+                if (s + 1 < nstage) w_dma(cur, group, slab, s + 1, (gstage + 1) & 1);
+                else if (next_unit) w_dma(nxt, group1, slab1, 0, (gstage + 1) & 1);
             }
 #endif
 #if !defined(GFE_EXP_NOA)      // timing experiment only: the activation tile is never restaged
@@ -343,8 +352,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     const int tap = s * TPS + tl;
-                    if (tap < p.ntaps) {                          // wave-uniform
-                        const int toff = p.toff[tap], txor = p.txor[tap];
+                    if (tap < ntaps_u) {                          // wave-uniform
+                        const int toff = p.toff[tap0_u + tap], txor = p.txor[tap0_u + tap];
                         bf16x8 xf[4];
 #pragma unroll
                         for (int xt = 0; xt < 4; ++xt) xf[xt] = *reinterpret_cast<const bf16x8*>(aT + ((abase[xt] + toff) ^ txor));
@@ -380,7 +389,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 for (int xt = 0; xt < 4; ++xt) {
                     const int ch_ = h0 + 2 * xt + (lr >> 3), cw_ = w0 + (lr & 7);
                     if (ch_ >= p.H || cw_ >= p.W) continue;
-                    const int od = p.ostride * cd + p.op_d, oh = p.ostride * ch_ + p.op_h, ow = p.ostride * cw_ + p.op_w;
+                    const int opar = MC ? p.c_op[cur.cls] : (p.op_d | (p.op_h << 1) | (p.op_w << 2));
+                    const int od = p.ostride * cd + (opar & 1), oh = p.ostride * ch_ + ((opar >> 1) & 1), ow = p.ostride * cw_ + ((opar >> 2) & 1);
                     // transposed conv: raw output has 2n-1 planes per axis; class-1 positions past it do not exist
                     if (p.ostride == 2 && (od > 2 * p.D - 2 || oh > 2 * p.H - 2 || ow > 2 * p.W - 2)) continue;
                     // finish the tile in place (the accumulators are dead afterwards): 4 channels at a time keeps the epilogue's
@@ -484,7 +494,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         // the slot of the LAST tile that went into the sums: unique per flush; slots never written stay zero (caller-zeroed)
                         // one channel group: a block leaves a sample at most once -> slot = block index (a 256-slot table);
                         // several groups flush per (tile, group) -> slot = tile index inside the sample
-                        const int slot = p.stats_slot0 + (p.ngroups == 1 ? vb : (cur.td * p.nth + cur.th) * p.ntw + cur.tw);
+                        const int tix = (cur.td * p.nth + cur.th) * p.ntw + cur.tw;
+                        const int slot = p.stats_slot0 + (p.ngroups == 1 ? vb : (MC ? tix * p.ncls + cur.cls : tix));
                         if (c < p.Cout) p.stats[(((size_t)b * p.stats_nblk + slot) * 2 + st) * p.Cout + c] = t;
                     }
                 }
@@ -550,19 +561,19 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     tab[((size_t)b * 64 + cls) * CoutPad + ch] = acc;
 }
 
-template <int NT, int TPS, bool REG27, bool STATS>
+template <int NT, int TPS, bool REG27, bool STATS, bool MC = false>
 int conv_launch(const ConvParams& p, hipStream_t st) {
     constexpr int W_PIECES = (TPS * NT * 16 + 15) / 16;
     const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * NT * 16 * sizeof(float);
-    const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw;
+    const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw * (MC ? p.ncls : 1);
     if (tiles > 0x7fffffff) return GFE_ERR_SHAPE;
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
     q.tiles_per_block = (int)ceil_div(tiles, 256);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27, STATS>), grid, dim3(NTHREADS), lds, st, q);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27, STATS, MC>), grid, dim3(NTHREADS), lds, st, q);
     return gfe_launch_status();
 }
 
@@ -577,6 +588,13 @@ int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Co
     if (gfe_conv3d_cout_pad(Cout) > 64) return (int)tps;                    // several channel groups: one slot per tile
     const int64_t tpb = ceil_div(tiles, 256);
     return (int)ceil_div(tiles, tpb);                                        // one slot per persistent block
+}
+
+int gfe_convt3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout) {
+    const int64_t tps = gfe_conv3d_tiles(D, H, W), items = B * tps * 8;
+    if (gfe_conv3d_cout_pad(Cout) > 64) return (int)(tps * 8);                // (tile, class) slots
+    const int64_t ipb = ceil_div(items, 256);
+    return (int)ceil_div(items, ipb);                                        // one slot per persistent block
 }
 
 #if defined(GFE_EXP_STAMP)
@@ -650,6 +668,8 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
     }
     p.ntd = (int)ceil_div(D, TD); p.nth = (int)ceil_div(H, TH); p.ntw = (int)ceil_div(W, TW);
     p.stats = stats_ws; p.stats_nblk = (int)stats_nblk; p.stats_slot0 = (int)stats_slot0;
+    p.ncls = 1; p.w_bytes = 0;
+    for (int c = 0; c < 8; ++c) { p.c_ntaps[c] = 0; p.c_tap0[c] = 0; p.c_op[c] = 0; p.c_woff[c] = 0; }
     if (stats_ws) GFE_REQUIRE(stats_slot0 >= 0 && stats_slot0 + gfe_conv3d_stat_slots(B, D, H, W, Cout) <= stats_nblk && stats_nblk <= 0x7fffffff, GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
     // regular 3x3x3 tap list in canonical order -> immediate-offset fast path
@@ -664,6 +684,49 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
     if (NT == 1) return conv_launch<1, 3, false, false>(p, st);
     if (NT == 2) return conv_launch<2, 3, false, false>(p, st);
     return reg27 ? conv_launch<4, 3, true, false>(p, st) : conv_launch<4, 3, false, false>(p, st);
+}
+
+int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* cls_woff, const int* cls_ntaps, const int8_t* cls_parity,
+                           const int8_t* tap_offsets, int64_t w_elems, const void* res, void* y,
+                           int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t OD, int64_t OH, int64_t OW,
+                           int oshift, float* stats_ws, int64_t stats_nblk, void* stream) {
+    GFE_REQUIRE(x && w_packed && cls_woff && cls_ntaps && cls_parity && tap_offsets && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, GFE_ERR_SHAPE);
+    GFE_REQUIRE(gfe_conv3d_cout_pad(Cout) >= 64, GFE_ERR_SHAPE);              // the multi-class variant is built for 64-channel groups
+    GFE_REQUIRE(oshift == 0 || oshift == 1, GFE_ERR_SHAPE);
+    GFE_REQUIRE(OD == 2 * D - 1 + oshift && OH == 2 * H - 1 + oshift && OW == 2 * W - 1 + oshift, GFE_ERR_SHAPE);
+    GFE_REQUIRE(D * H * W * Cin * 2 < 0x7fffffffLL && w_elems * 2 < 0xffffffffLL, GFE_ERR_SHAPE);
+    ConvParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = nullptr; p.bias_tab = nullptr;
+    p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = 0;
+    p.B = (int)B; p.D = (int)D; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
+    p.CoutPad = gfe_conv3d_cout_pad(Cout);
+    p.OD = (int)OD; p.OH = (int)OH; p.OW = (int)OW;
+    p.nslab = (int)ceil_div(Cin, 32); p.ngroups = p.CoutPad / 64;
+    p.ncls = 8; p.w_bytes = (unsigned)(w_elems * 2);
+    int total = 0;
+    for (int c = 0; c < 8; ++c) {
+        GFE_REQUIRE(cls_ntaps[c] >= 1 && cls_ntaps[c] <= 8 && cls_woff[c] >= 0 && cls_woff[c] % 8 == 0, GFE_ERR_SHAPE);
+        p.c_ntaps[c] = cls_ntaps[c]; p.c_tap0[c] = total; p.c_woff[c] = cls_woff[c];
+        p.c_op[c] = (cls_parity[3 * c] & 1) | ((cls_parity[3 * c + 1] & 1) << 1) | ((cls_parity[3 * c + 2] & 1) << 2);
+        total += cls_ntaps[c];
+    }
+    GFE_REQUIRE(total <= 27, GFE_ERR_SHAPE);
+    p.ntaps = total;
+    // one halo box for all classes: offsets are 0 / +1 per axis
+    for (int t = 0; t < total; ++t) {
+        const int8_t* o = tap_offsets + 3 * t;
+        GFE_REQUIRE(o[0] >= 0 && o[0] <= 1 && o[1] >= 0 && o[1] <= 1 && o[2] >= 0 && o[2] <= 1, GFE_ERR_SHAPE);
+        p.toff[t] = ((o[0] * PH + o[1]) * PW + o[2]) * VSTRIDE;
+        p.txor[t] = (o[1] & 1) ? 32 : 0;
+    }
+    p.lo_d = p.lo_h = p.lo_w = 0; p.LD = TD + 1; p.LH = TH + 1; p.LW = TW + 1;
+    p.ostride = 2; p.op_d = p.op_h = p.op_w = 0; p.oshift = oshift; p.relu = 0;
+    p.ntd = (int)ceil_div(D, TD); p.nth = (int)ceil_div(H, TH); p.ntw = (int)ceil_div(W, TW);
+    p.stats = stats_ws; p.stats_nblk = (int)stats_nblk; p.stats_slot0 = 0;
+    if (stats_ws) GFE_REQUIRE(gfe_convt3d_stat_slots(B, D, H, W, Cout) <= stats_nblk && stats_nblk <= 0x7fffffff, GFE_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    return stats_ws ? conv_launch<4, 3, false, true, true>(p, st) : conv_launch<4, 3, false, false, true>(p, st);
 }
 
 }  // extern "C"

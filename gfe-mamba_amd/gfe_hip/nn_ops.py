@@ -106,6 +106,39 @@ def pack_convT(weight):
     return out
 
 
+def fuse_convT(classes):
+    """The 8 per-class packs of pack_convT as one buffer + the host tables gfe_convt3d_k3s2_fused takes: heavy classes first so
+    that the tail of a persistent block's work list is made of light items."""
+    order = sorted(classes.keys(), key=lambda par: -len(classes[par][1]))
+    parts, woff, ntaps, parity, taps, off = [], [], [], [], [], 0
+    for par in order:
+        w, tl = classes[par]
+        parts.append(w.reshape(-1))
+        woff.append(off)
+        off += w.numel()
+        ntaps.append(len(tl))
+        parity.extend(par)
+        taps.extend(tl)
+    return dict(w=torch.cat(parts).contiguous(), woff=_i64(woff), ntaps=(np.ascontiguousarray(np.asarray(ntaps, dtype=np.int32)),),
+                parity=_i8(parity), taps=_i8(taps), elems=off)
+
+
+def convT_fused(x, fused, cout, res, out, stats=True):
+    """ConvTranspose3d(k3, s2, p1) + nearest resize to out's size + `res + .` in one launch (gfe_convt3d_k3s2_fused); out is
+    tagged with the GroupNorm partials of the result."""
+    B, D, H, W, cin = x.shape
+    OD, OH, OW = out.shape[1:4]
+    oshift = OD - (2 * D - 1)
+    assert oshift in (0, 1) and OH == 2 * H - 1 + oshift and OW == 2 * W - 1 + oshift, "unsupported upsampling size"
+    ws = new_gn_partials(B, lib().gfe_convt3d_stat_slots(B, D, H, W, cout), cout, x.device) if stats else None
+    nt = fused["ntaps"][0]
+    call("gfe_convt3d_k3s2_fused", ptr(x), ptr(fused["w"]), fused["woff"][1], nt.ctypes.data, fused["parity"][1], fused["taps"][1],
+         fused["elems"], ptr(res), ptr(out), B, D, H, W, cin, cout, OD, OH, OW, oshift, ptr(ws), 0 if ws is None else ws.shape[1], stream())
+    if stats:
+        out.gn_partials = ws
+    return out
+
+
 # ---- generator ops --------------------------------------------------------------------------------------------------
 def conv_tiles(D, H, W):
     return lib().gfe_conv3d_tiles(D, H, W)

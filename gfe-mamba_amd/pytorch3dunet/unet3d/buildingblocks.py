@@ -129,8 +129,10 @@ class TransposeConvUpsampling(nn.Module):
     def forward(self, encoder_features, x):
         """Returns encoder_features + resize(convT(x)) -- the upsampling AND the summation join (buildingblocks.py:396-400)."""
         ct = self.upsample.conv_transposed
-        classes = self._pack.get([ct.weight], lambda: K.pack_convT(ct.weight))
+        classes, fused = self._pack.get([ct.weight], lambda: self._build(ct))
         out = torch.empty_like(encoder_features)
+        if fused is not None:                              # one launch for the 8 parity classes (64-channel groups)
+            return K.convT_fused(x, fused, ct.out_channels, encoder_features, out)
         B, D, H, W, _ = x.shape
         slots = K.conv_stat_slots(B, D, H, W, ct.out_channels)
         ws = K.new_gn_partials(B, 8 * slots, ct.out_channels, x.device)    # the 8 parity classes fill disjoint slot ranges
@@ -139,6 +141,12 @@ class TransposeConvUpsampling(nn.Module):
         assert len(classes) == 8
         out.gn_partials = ws
         return out
+
+    @staticmethod
+    def _build(ct):
+        classes = K.pack_convT(ct.weight)
+        fused = K.fuse_convT(classes) if K.cout_pad(ct.out_channels) >= 64 else None
+        return classes, fused
 
 
 class Decoder(nn.Module):

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 14
+#define GFE_ABI_VERSION 15
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -124,6 +124,19 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
 int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W);
 /* GroupNorm-partial slots per sample one gfe_conv3d_igemm call with stats_ws writes (see above). Host-only. */
 int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout);
+
+/* The whole TransposeConvUpsampling + summation join (buildingblocks.py:396-400, 523-537) in ONE launch: the 8 output-parity
+ * classes that gfe_conv3d_igemm takes as 8 calls become the innermost dimension of the persistent blocks' work list, so a block
+ * re-reads an activation tile for the next class out of L2 and the classes pipeline into each other.
+ *   w_packed: the classes' packed weight sets back to back (w_elems bf16 in total), class c at element offset cls_woff[c]
+ *   (HOST int64[8], multiples of 8) with cls_ntaps[c] taps (HOST int[8], 1/2/2/2/4/4/4/8 in any order) and output parity
+ *   cls_parity[3c..3c+2] (HOST int8, 0/1 per axis); tap_offsets: HOST int8, the classes' tap lists concatenated, offsets 0/+1.
+ *   res (skip) may be NULL.  stats_ws: (B, stats_nblk, 2, Cout) f32 ZEROED, stats_nblk >= gfe_convt3d_stat_slots(...). */
+int gfe_convt3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout);
+int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* cls_woff, const int* cls_ntaps, const int8_t* cls_parity,
+                           const int8_t* tap_offsets, int64_t w_elems, const void* res, void* y,
+                           int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t OD, int64_t OH, int64_t OW,
+                           int oshift, float* stats_ws, int64_t stats_nblk, void* stream);
 
 /* Folds GroupNorm(x) = scale[b,c]*x + shift[b,c] (from gfe_groupnorm_scale_shift) into the convolution that consumes it
  * (create_conv order 'g' before 'c', buildingblocks.py:55-67; zero padding is applied AFTER the norm):
