@@ -26,8 +26,12 @@
 // Operands are swapped (weights = A) and weight rows are permuted at pack time so a lane ends up with 16 consecutive
 // channels of one voxel -> contiguous 32-B stores.  Persistent blocks walk contiguous tile ranges (1 block per CU).
 //
+// The epilogue also produces the GroupNorm partials of what it stores (for the next layer's fold), and the 8 parity classes of a
+// transposed conv can run as one launch with the class as the innermost dimension of the blocks' work list (template flag MC).
+//
 // (Round-1 history, measured on the 64->64 @96^3 conv: VGPR-staged v1 671 TFLOP/s; v2 with prefetch registers, swizzled LDS
-// and division-free index math 730-780; ablation showed the non-MFMA instruction stream cost 2x the MFMA time -> this DMA form.)
+// and division-free index math 730-780; ablation showed the non-MFMA instruction stream cost 2x the MFMA time -> this DMA form,
+// 970-1030 TFLOP/s.  DESIGN.md 4.1 has the ablation table and the list of DMA-issue variants that were measured and dropped.)
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -8,9 +8,10 @@
 //
 // Layout (token-major, the layout MambaBlock already has before its transposes at mamba.py:245-252):
 //   u, delta, z, y : (B, L, ED)   ED contiguous  -> one wave = 64 consecutive channels, 128-B rows (bf16)
-//   Bm, Cm         : (B, L, N)    N contiguous   -> wave-uniform, fetched on the scalar path
+//   Bm, Cm         : (B, L, N)    N contiguous f32 -> wave-uniform rows, staged through wave-private LDS tiles (RowTile)
 //   A              : (ED, N) f32, D / delta_bias : (ED) f32
-// State is always f32 (mamba.py:232: A is .float()).  No MFMA: ~6 flop per state-step, HBM/VALU bound.
+// State is always f32 (mamba.py:232: A is .float()), kept as float2 pairs so that the mul/fma chains are v_pk_* instructions.
+// No MFMA: ~6 flop and one exp per state-step -- VALU-issue bound, not HBM bound.
 //
 // Parallel decomposition: one lane owns one channel and keeps its N states in registers.  L is cut
 // into chunks of T steps so that B*ED/64*nchunks waves fill the chip:
