@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d"])
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (volumes for `step`, sequences for `scan`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,11 +198,11 @@ def main():
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
     else:
         from gfe_hip.step_bench import StepWorkload
-        wl = StepWorkload(a.batch, world=world, rank=rank)
+        wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph)
         steps, warmup = a.steps or 10, a.warmup if a.warmup is not None else 3
         metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
-               "parallelism": f"dp{n_gpus}"}
+               "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph)}
 
     def barrier():
         if world > 1:

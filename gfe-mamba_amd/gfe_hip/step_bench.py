@@ -28,8 +28,8 @@ HEAD_GFLOP_PER_SAMPLE = 11.64
 class StepWorkload:
     name = "classify_mamba train step (frozen generator fwd + head fwd/bwd + per-param clip + Adam), 96^3, synthetic"
 
-    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96)):
-        self.batch, self.world, self.vol = batch, world, vol
+    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False):
+        self.batch, self.world, self.vol, self.graph = batch, world, vol, graph
         gen, head, ft = build_models(vol=vol, seed=0)
         self.step_obj = ClassifyStep(gen, head, ft, world_size=world)
         x, x_cat, x_num, y = det.det_inputs(batch, vol, seed=1000 + rank)
@@ -37,6 +37,8 @@ class StepWorkload:
         self.units = batch
 
     def step(self):
+        if self.graph:                                   # HIP-graph replay of zero_grad + forward + backward (small batches are host-bound)
+            return self.step_obj.train_step_graphed(*self.inputs)
         return self.step_obj.train_step(*self.inputs)
 
     def roofline(self, iters=3):

@@ -201,3 +201,27 @@ def test_gemm_ex_modes(M, N, K):
                     out = K_.gemm_ex(aa, a_t, bb, b_t)
                     err = (out - ref).abs().max().item()
                     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (a_f32, b_f32, a_t, b_t, err)
+
+
+@pytest.mark.gpu
+def test_graphed_step_matches_eager_step():
+    """ClassifyStep.train_step_graphed (HIP-graph replay of zero_grad + forward + backward) updates the parameters exactly like
+    train_step on the same inputs (dropout off so that both are deterministic up to the kernels' f32 atomics)."""
+    import copy
+    from gfe_hip.step import ClassifyStep, build_models
+    import gfe_hip.det_init as det
+    kw = dict(vol=(32, 32, 32), f_maps=(8, 16, 32), dim=64, depth=2, heads=8, vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), seed=3)
+    x, x_cat, x_num, y = [t.cuda() for t in det.det_inputs(2, (32, 32, 32), seed=4)]
+    outs = []
+    for graphed in (False, True):
+        gen, head, ft = build_models(**kw)
+        for m in ft.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        st = ClassifyStep(gen, head, ft)
+        fn = st.train_step_graphed if graphed else st.train_step
+        losses = [float(fn(x, x_cat, x_num, y)) for _ in range(3)]
+        outs.append((losses, st.opt.flat_p.clone()))
+    (l0, p0), (l1, p1) = outs
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
+    assert (p0 - p1).abs().max().item() < 2e-4           # 3 Adam steps of 1e-4 each: identical up to atomics-order noise
