@@ -89,8 +89,10 @@ class ScanWorkload:
         t_s = time_region(self.step, iters)
         t_b = max(t_s - t_f, 1e-6)
         gbs = (self.bytes_fwd + self.bytes_bwd) / (t_s * 1e-3) / 1e9
+        from gfe_hip.step_bench import measured_traffic
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": "sscan_fwd+sscan_bwd (fused selective scan)",
+                "traffic": measured_traffic("sscan_fwd_bwd_step_b8") if self.B == 8 else None,
+                "kernel": "sscan_fwd+sscan_bwd (fused selective scan; 6 launches per step)",
                 "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                 "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),
                 "algorithmic_bytes": self.bytes_fwd + self.bytes_bwd}
