@@ -31,7 +31,9 @@ class StepWorkload:
     def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False):
         self.batch, self.world, self.vol, self.graph = batch, world, vol, graph
         gen, head, ft = build_models(vol=vol, seed=0)
-        self.step_obj = ClassifyStep(gen, head, ft, world_size=world)
+        import os
+        ov = os.environ.get("GFE_OVERLAP_UPDATE")          # default off (see ClassifyStep); 1 turns it on for A/B runs
+        self.step_obj = ClassifyStep(gen, head, ft, world_size=world, overlap_update=None if ov is None else ov == "1")
         x, x_cat, x_num, y = det.det_inputs(batch, vol, seed=1000 + rank)
         self.inputs = [t.cuda() for t in (x, x_cat, x_num, y)]
         self.units = batch

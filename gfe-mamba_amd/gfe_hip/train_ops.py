@@ -269,12 +269,35 @@ class FlatAdam:
             _SHADOW[id(p)] = (self.flat_p16[o:o + s].view(p.shape), p._version)
 
     def zero_grad(self):
+        self.wait_updated()
         self.flat_g.zero_()
         for p, o, s in zip(self.params, self.offs[:-1], self.sizes):      # autograd keeps accumulating in place
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + int(o) * 4:
                 p.grad = self.flat_g[int(o):int(o) + s].view(p.shape)
 
-    def step(self, world_size=1, group=None):
+    def step(self, world_size=1, group=None, overlap=False):
+        """overlap=True runs the all-reduce and the update on a side stream and returns at once: whatever does not read the
+        parameters or the gradient buffer (the NEXT step's frozen-generator forward, 85 % of a step) then overlaps the collective.
+        Every reader of parameters / gradients must call wait_updated() first (ClassifyStep does)."""
+        if overlap:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())          # the backward that filled flat_g
+            with torch.cuda.stream(self._side):
+                self._step(world_size, group)
+                self._done = self._side.record_event()
+        else:
+            self.wait_updated()
+            self._step(world_size, group)
+
+    def wait_updated(self):
+        """Make the current stream wait for an update that step(overlap=True) left running on the side stream."""
+        ev = getattr(self, "_done", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._done = None
+
+    def _step(self, world_size, group):
         from .step import allreduce_grads_
         scale = allreduce_grads_(self.flat_g, world_size, group)         # SUM over ranks; the mean is folded into grad_scale
         self.t += 1

@@ -225,3 +225,27 @@ def test_graphed_step_matches_eager_step():
     (l0, p0), (l1, p1) = outs
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
     assert (p0 - p1).abs().max().item() < 2e-4           # 3 Adam steps of 1e-4 each: identical up to atomics-order noise
+
+
+@pytest.mark.gpu
+def test_overlapped_update_matches_inline_update():
+    """ClassifyStep(overlap_update=True) (optional: all-reduce + clip + Adam on a side stream underneath the next
+    step's frozen-generator forward) produces the same losses and parameters as the inline update."""
+    from gfe_hip.step import ClassifyStep, build_models
+    import gfe_hip.det_init as det
+    kw = dict(vol=(32, 32, 32), f_maps=(8, 16, 32), dim=64, depth=2, heads=8, vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), seed=3)
+    x, x_cat, x_num, y = [t.cuda() for t in det.det_inputs(2, (32, 32, 32), seed=4)]
+    outs = []
+    for overlap in (False, True):
+        gen, head, ft = build_models(**kw)
+        for m in ft.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        st = ClassifyStep(gen, head, ft, overlap_update=overlap)
+        losses = [fn for fn in (st.train_step(x, x_cat, x_num, y) for _ in range(5))]     # no host sync between steps
+        st.opt.wait_updated()
+        outs.append(([float(l) for l in losses], st.opt.flat_p.clone(), float(st.eval_step(x, x_cat, x_num).sum())))
+    (l0, p0, e0), (l1, p1, e1) = outs
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
+    assert (p0 - p1).abs().max().item() < 3e-4
+    assert abs(e0 - e1) < 1e-3
