@@ -1,7 +1,7 @@
 """Cross_mamba_both -- MI355X build of the classifier used by classify_mamba.py (reference:
-cross_atten/mamba_transformer.py:11-133).  Same keyword-only constructor, forward(x_categ, x_numer, feature_img,
-image_condition) contract and state-dict keys.  Additive: `d_cross` (default 160*160, the reference's hard-coded value at
-:84) so that 96^3 / 128^3 volumes are constructible.  Cross_jamba_both / Cross_mamba_ablation are next-round scope."""
+cross_atten/mamba_transformer.py:11-133) -- and its ablation twin Cross_mamba_ablation (:254-385).  Same keyword-only
+constructors, forward contracts and state-dict keys.  Additive: `d_cross` (default 160*160, the reference's hard-coded value at
+:84 / :325) so that 96^3 / 128^3 volumes are constructible.  Cross_jamba_both is next-round scope."""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -53,3 +53,32 @@ class Cross_mamba_both(nn.Module):
         x = self.final_cross(x, whole_condition) + x                                              # :124
         x = self.final_feed(x) + x                                                                # :125
         return self.to_logits(x.squeeze(1))                                                       # :127-131
+
+
+class Cross_mamba_ablation(Cross_mamba_both):
+    """Reference: cross_atten/mamba_transformer.py:254-385 -- the same modules and state-dict keys as Cross_mamba_both; forward
+    takes three switches: feature_img=None (table tokens only, :364), no_table=True (cls + image features only, :359) and
+    image_condition=None (skips final_cross / final_feed, :373-375)."""
+
+    def forward(self, x_categ, x_numer, feature_img=None, image_condition=None, no_table=False):
+        assert x_categ.shape[-1] == self.num_categories, f'you must pass in {self.num_categories} values for your categories input'
+        xs = []
+        if self.num_unique_categories > 0:
+            xs.append(self.categorical_embeds(x_categ + self.categories_offset))                  # :339-343
+        if self.num_continuous > 0:
+            xs.append(self.numerical_embedder(x_numer))
+        x = torch.cat(xs, dim=1)
+        cls_tokens = self.cls_token.expand(x.shape[0], -1, -1)
+        if no_table:
+            x = torch.cat((cls_tokens, feature_img), dim=1)                                       # :359
+        elif feature_img is not None:
+            x = torch.cat((cls_tokens, x, feature_img), dim=1)                                    # :362
+        else:
+            x = torch.cat((cls_tokens, x), dim=1)                                                 # :364
+        x = self.transformer(x)
+        x = torch.mean(x, dim=1, keepdims=True)                                                   # :371
+        if image_condition is not None:
+            cond = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))
+            x = self.final_cross(x, cond) + x                                                     # :374
+            x = self.final_feed(x) + x                                                            # :375
+        return self.to_logits(x.squeeze(1))                                                       # :377-381

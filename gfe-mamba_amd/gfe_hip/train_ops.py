@@ -3,6 +3,8 @@ features, the image condition buffers, and the flat-buffer per-parameter-clip + 
 
 Numerics: master weights, residual stream and reductions are f32; GEMM operands are rounded to bf16 (f32 accumulate).
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -16,7 +18,7 @@ _SHADOW = {}        # id(parameter) -> bf16 view kept fresh by FlatAdam (avoids 
 
 def _w16(weight):
     s = _SHADOW.get(id(weight))
-    if s is not None and s[1] == weight._version:
+    if s is not None and s[2]() is weight and s[1] == weight._version:     # (ids are reused once a parameter is freed)
         return s[0]
     return K.cast(weight.detach().float(), BF16)
 
@@ -86,7 +88,7 @@ class _LinearFn(torch.autograd.Function):
                 dx = K.gemm_ex(d32, False, _w16(weight), True).reshape(xs).to(xdt)        # dy (M, N) . W (N, K) read reduction-major
             if ctx.needs_input_grad[1]:
                 slot = _grad_slot(ctx.w_ref)                                              # accumulate straight into weight.grad
-                if xT16 is not None:
+                if xT16 is not None and K._ex_ok(xT16):
                     dw = K.gemm_ex(d32, True, xT16, False, accum_into=slot)               # dy^T . (K, M)^T
                 else:
                     dw = K.gemm_ex(d32, True, xin, True, accum_into=slot)                 # dy^T . x, both read reduction-major
@@ -266,7 +268,7 @@ class FlatAdam:
     def _register_shadows(self):
         for p, o, s in zip(self.params, self.offs[:-1], self.sizes):
             o = int(o)
-            _SHADOW[id(p)] = (self.flat_p16[o:o + s].view(p.shape), p._version)
+            _SHADOW[id(p)] = (self.flat_p16[o:o + s].view(p.shape), p._version, weakref.ref(p, lambda _, k=id(p): _SHADOW.pop(k, None)))
 
     def zero_grad(self):
         self.wait_updated()

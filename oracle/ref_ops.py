@@ -184,6 +184,33 @@ def cross_mamba_both(x_categ, x_numer, feature_img, image_condition, sd, depth, 
     return x @ sd[pre + "to_logits.1.weight"].t() + sd[pre + "to_logits.1.bias"]   # :131
 
 
+def cross_mamba_ablation(x_categ, x_numer, feature_img, image_condition, sd, depth, heads, pre="", no_table=False, drop_mask=None):
+    """Cross_mamba_ablation.forward (cross_atten/mamba_transformer.py:327-385): Cross_mamba_both with three switches --
+    feature_img=None (table only), no_table=True (cls + image features only), image_condition=None (no cross attention)."""
+    xs = []
+    if (pre + "categorical_embeds.weight") in sd:
+        xs.append(sd[pre + "categorical_embeds.weight"][x_categ + sd[pre + "categories_offset"]])      # :339-343
+    if (pre + "numerical_embedder.weights") in sd:
+        xs.append(x_numer.unsqueeze(-1) * sd[pre + "numerical_embedder.weights"] + sd[pre + "numerical_embedder.biases"])
+    x = torch.cat(xs, dim=1)                                         # :353
+    cls = sd[pre + "cls_token"].expand(x.shape[0], -1, -1)
+    if no_table:
+        x = torch.cat((cls, feature_img), dim=1)                     # :359
+    elif feature_img is not None:
+        x = torch.cat((cls, x, feature_img), dim=1)                  # :362
+    else:
+        x = torch.cat((cls, x), dim=1)                               # :364
+    x = mamba(x, sd, pre + "transformer.", depth)                    # :370
+    x = x.mean(dim=1, keepdim=True)                                  # :371
+    if image_condition is not None:                                  # :373-375
+        cond = build_condition(image_condition)
+        x = cross_attention(x, cond, sd, pre + "final_cross.", heads) + x
+        x = geglu_ff(x, sd, pre + "final_feed.", drop_mask) + x
+    x = x.squeeze(1)
+    x = F.layer_norm(x, x.shape[-1:], sd[pre + "to_logits.0.weight"], sd[pre + "to_logits.0.bias"])
+    return x @ sd[pre + "to_logits.1.weight"].t() + sd[pre + "to_logits.1.bias"]   # :381
+
+
 def combine_classifier_vit_mid(mid_input, mid_output, sd, pre=""):
     """Combine_classfier_vit_mid.forward (classify/classifier.py:329-333)."""
     t = torch.cat([mid_input, mid_output], dim=1).flatten(2)        # b c (h w)

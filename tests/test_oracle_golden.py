@@ -135,3 +135,33 @@ def test_c_scan_oracle():
     y = c_oracle.selective_scan(fx["ss_x"], fx["ss_draw"], fx["ss_A"], fx["ss_B"], fx["ss_C"], fx["ss_D"], z=fx["ss_z"],
                                 bias=fx["ss_dbias"], softplus=True)
     assert rel_err(tt(y), tt(fx["ss_yfn"])) < TOL
+
+
+ABL_CASES = dict(full=dict(feat=True, cond=True, no_table=False), table_only=dict(feat=False, cond=True, no_table=False),
+                 no_table=dict(feat=True, cond=True, no_table=True), no_cross=dict(feat=True, cond=False, no_table=False))
+
+
+def ablation_setup(fx, device="cpu"):
+    """Inputs + deterministic weights of tests/golden/t3_ablation.npz (tools/make_golden.py t3)."""
+    import gfe_hip.det_init as det
+    from cross_atten.mamba_transformer import Cross_mamba_ablation
+    m = [int(v) for v in fx["meta"]]
+    cards, (n_cont, dim, depth, heads), vol, Bn = tuple(m[:3]), m[3:7], tuple(m[7:10]), m[10]
+    ft = Cross_mamba_ablation(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads,
+                              d_cross=vol[0] * vol[1])
+    ft.load_state_dict(det.det_state_dict(ft.state_dict(), seed=31, prefix="abl."))
+    x, x_cat, x_num, y = [t.to(device) for t in det.det_inputs(Bn, vol, cards, n_cont, seed=31)]
+    return ft, depth, heads, x, x_cat, x_num, y, tt(fx["pet"], device=device), tt(fx["feat"], device=device)
+
+
+def test_cross_mamba_ablation_variants():
+    fx = golden("t3_ablation.npz")
+    ft, depth, heads, x, x_cat, x_num, y, pet, feat = ablation_setup(fx)
+    sd = {k: v.detach() for k, v in ft.state_dict().items()}
+    for name, c in ABL_CASES.items():
+        pred = O.cross_mamba_ablation(x_cat, x_num, feat if c["feat"] else None, [x, pet] if c["cond"] else None, sd, depth, heads,
+                                      no_table=c["no_table"])
+        assert rel_err(pred, tt(fx[name + ".pred"])) < TOL, name
+    # the variants really differ (a fixture that ignored the switches would pass the loop above with one set of numbers)
+    preds = [fx[n + ".pred"] for n in ABL_CASES]
+    assert all(np.abs(preds[i] - preds[j]).max() > 1e-4 for i in range(4) for j in range(i))

@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -311,6 +311,31 @@ def t2(R, out):
     np.savez_compressed(os.path.join(out, "t2_full96_step.npz"), **fx)
 
 
+def t3(R, out):
+    """Cross_mamba_ablation (cross_atten/mamba_transformer.py:254-385): the four forward variants + parameter gradients of each."""
+    cards, n_cont, dim, depth, heads, vol, Bn = (5, 3, 2), 6, 64, 2, 8, (8, 12, 6), 3
+    ft = R.mt.Cross_mamba_ablation(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads)
+    ft.final_cross = R.xattn.CrossAttention(n_heads=heads, d_embed=dim, d_cross=vol[0] * vol[1])      # :325 hard-codes 160*160
+    load_det(ft, 31, "abl.")
+    ft.eval()
+    x, x_cat, x_num, y = det.det_inputs(Bn, vol, cards, n_cont, seed=31)
+    pet = rnd_det("abl.pet", (Bn, 1) + vol)
+    feat = rnd_det("abl.feat", (Bn, 4, dim))
+    fx = dict(meta=np.array(list(cards) + [n_cont, dim, depth, heads] + list(vol) + [Bn]), pet=npy(pet), feat=npy(feat))
+    cases = dict(full=dict(feature_img=feat, image_condition=[x, pet]), table_only=dict(feature_img=None, image_condition=[x, pet]),
+                 no_table=dict(feature_img=feat, image_condition=[x, pet], no_table=True), no_cross=dict(feature_img=feat, image_condition=None))
+    for name, kw in cases.items():
+        ft.zero_grad()
+        pred = ft(x_cat, x_num, **kw)
+        loss = torch.nn.BCELoss()(torch.sigmoid(pred.squeeze(1)), y.float())
+        loss.backward()
+        fx[name + ".pred"] = npy(pred.double())
+        fx[name + ".loss"] = npy(loss.double())
+        for k, p in ft.named_parameters():
+            fx[name + ".gnorm." + k] = npy(p.grad.double().norm()) if p.grad is not None else np.array(-1.0)
+    np.savez_compressed(os.path.join(out, "t3_ablation.npz"), **fx)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -319,7 +344,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
