@@ -43,6 +43,11 @@ typedef __attribute__((address_space(3))) void* lds_void_t;
 #else
 #define GFE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
+#if defined(GFE_EXP_HALFLDS)
+#define GFE_XSET(set) 0
+#else
+#define GFE_XSET(set) (set)
+#endif
 
 namespace {
 
@@ -318,13 +323,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 // issue (two register sets), so only the first tap of a stage exposes the LDS latency
                 bf16x8 xf[STATS ? 1 : 2][4], wf[STATS ? 1 : 2][NT];
                 auto frag_load = [&](int tl, int set) {
+#if defined(GFE_EXP_HALFLDS)   // timing experiment only: the activation fragments of tap 0 are reused for taps 1, 2 (a third of the reads)
+                    if (tl == 0)
+#endif
 #pragma unroll
                     for (int xt = 0; xt < 4; ++xt) xf[set][xt] = *reinterpret_cast<const bf16x8*>(aT + ax[xt] + tl * VSTRIDE);
 #pragma unroll
                     for (int ct = 0; ct < NT; ++ct) wf[set][ct] = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
                 };
                 constexpr bool PIPE = !STATS;         // the second register set does not fit beside the GroupNorm partials (spills)
+#if defined(GFE_EXP_NOSTART)   // timing experiment only: no exposed first-tap fragment reads at the start of a stage
+                if constexpr (PIPE) { if (gstage == 0) frag_load(0, 0); __builtin_amdgcn_sched_barrier(0); }
+#else
                 if constexpr (PIPE) { frag_load(0, 0); __builtin_amdgcn_sched_barrier(0); }
+#endif
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     const int set = PIPE ? (tl & 1) : 0;
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #pragma unroll
                         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                            for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[set][ct], xf[set][xt], acc[xt][ct]);
+                            for (int xt = 0; xt < 4; ++xt) acc[xt][ct] = GFE_MFMA(wf[set][ct], xf[GFE_XSET(set)][xt], acc[xt][ct]);
                         if (tl + 1 < TPS) {
 #pragma unroll
                             for (int i = 0; i < 2 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
