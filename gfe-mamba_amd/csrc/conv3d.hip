@@ -35,6 +35,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void* lds_void_t;
 
@@ -244,14 +245,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     };
 
     f32x4 acc[4][NT];
-    // GroupNorm shift term of interior voxels (boundary class 0): kept in registers per (sample, group) so the epilogue of
-    // interior tiles has no load on its critical path; boundary voxels read their class row from the table
-    float bias0[4 * NT];
-    int bias0_key = -1;
-    float gs[STATS ? 4 * NT : 1], gq[STATS ? 4 * NT : 1];     // GroupNorm partials of the stored output, see the epilogue
+    // GroupNorm partials of the stored output, see the epilogue.  64-channel tiles (NT == 4) keep ONE sum per 8 consecutive channels
+    // (v_dot2c_f32_bf16 adds a packed pair straight into it): GroupNorm groups of >= 8 channels never need finer ones (the host
+    // refuses the combination otherwise), it is 4 registers instead of 32 and a quarter of the epilogue's VALU work.
+    constexpr bool OCT = STATS && NT == 4;
+    constexpr int NSTAT = !STATS ? 1 : (OCT ? 2 : 4 * NT);
+    float gs[NSTAT], gq[NSTAT];
     if constexpr (STATS) {
 #pragma unroll
-        for (int i = 0; i < 4 * NT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+        for (int i = 0; i < NSTAT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
     }
 
     if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur, 0, 0, 0, 0);
@@ -273,13 +275,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             for (int xt = 0; xt < 4; ++xt)
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct) acc[xt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!STATS && p.bias_tab && bias0_key != cur.b * p.ngroups + group) {       // wave-uniform; lands during the unit's stages
-                bias0_key = cur.b * p.ngroups + group;
-                const int c0b = group * WROWS_TAP + lq * 4 * NT;
-                const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + (size_t)cur.b * 64 * p.CoutPad + (c0b < p.CoutPad ? c0b : 0));
-#pragma unroll
-                for (int i = 0; i < NT; ++i) { const float4 t = bt[i]; bias0[4 * i] = t.x; bias0[4 * i + 1] = t.y; bias0[4 * i + 2] = t.z; bias0[4 * i + 3] = t.w; }
-            }
         }
 
         for (int s = 0; s < nstage; ++s, ++gstage) {
@@ -321,7 +316,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 for (int xt = 0; xt < 4; ++xt) ax[xt] = (abase[xt] + sbase) ^ sx;
                 // software pipeline over the stage's taps: the 8 fragment reads of tap t+1 are in flight while the 16 MFMAs of tap t
                 // issue (two register sets), so only the first tap of a stage exposes the LDS latency
-                bf16x8 xf[STATS ? 1 : 2][4], wf[STATS ? 1 : 2][NT];
+#if defined(GFE_EXP_NOPIPE_OCT)   // timing experiment only: the statistics variant without the second fragment set
+                constexpr bool PIPE = !STATS;
+#else
+                constexpr bool PIPE = !STATS || OCT;  // per-channel GroupNorm partials (NT < 4) leave no room for the second register set
+#endif
+                bf16x8 xf[PIPE ? 2 : 1][4], wf[PIPE ? 2 : 1][NT];
                 auto frag_load = [&](int tl, int set) {
 #if defined(GFE_EXP_HALFLDS)   // timing experiment only: the activation fragments of tap 0 are reused for taps 1, 2 (a third of the reads)
                     if (tl == 0)
@@ -331,7 +331,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #pragma unroll
                     for (int ct = 0; ct < NT; ++ct) wf[set][ct] = *reinterpret_cast<const bf16x8*>(wb + (tl * WROWS_TAP + ct * 16) * VSTRIDE);
                 };
-                constexpr bool PIPE = !STATS;         // the second register set does not fit beside the GroupNorm partials (spills)
 #if defined(GFE_EXP_NOSTART)   // timing experiment only: no exposed first-tap fragment reads at the start of a stage
                 if constexpr (PIPE) { if (gstage == 0) frag_load(0, 0); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -415,18 +414,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         // boundary class: which neighbours of this voxel fall outside the volume
                         const int cls = (cd == 0) | ((cd == p.D - 1) << 1) | ((ch_ == 0) << 2) | ((ch_ == p.H - 1) << 3) |
                                         ((cw_ == 0) << 4) | ((cw_ == p.W - 1) << 5);
-                        if (!STATS && cls == 0) {           // (with the GroupNorm partials live, bias0 would not fit in registers)
+                        const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + ((size_t)b * 64 + cls) * p.CoutPad + c0);
 #pragma unroll
-                            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) acc[xt][i][r] += bias0[4 * i + r];
-                        } else {
-                            const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + ((size_t)b * 64 + cls) * p.CoutPad + c0);
-#pragma unroll
-                            for (int i = 0; i < NT; ++i) {
-                                const float4 t = bt[i];
-                                acc[xt][i][0] += t.x; acc[xt][i][1] += t.y; acc[xt][i][2] += t.z; acc[xt][i][3] += t.w;
-                            }
+                        for (int i = 0; i < NT; ++i) {
+                            const float4 t = bt[i];
+                            acc[xt][i][0] += t.x; acc[xt][i][1] += t.y; acc[xt][i][2] += t.z; acc[xt][i][3] += t.w;
                         }
                     }
                     if (p.bias) {
@@ -469,12 +461,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                                         }
                                         if (p.relu) { w0_ = fmaxf(w0_, 0.f); w1_ = fmaxf(w1_, 0.f); w2_ = fmaxf(w2_, 0.f); w3_ = fmaxf(w3_, 0.f); }
                                         pk[2 * j] = pack_bf16x2(w0_, w1_); pk[2 * j + 1] = pack_bf16x2(w2_, w3_);
-                                        if constexpr (STATS) {
+                                        if constexpr (STATS && !OCT) {
                                             const float r0 = bf16lo_to_f32(pk[2 * j]), r1 = bf16hi_to_f32(pk[2 * j]);
                                             const float r2 = bf16lo_to_f32(pk[2 * j + 1]), r3 = bf16hi_to_f32(pk[2 * j + 1]);
                                             gs[4 * i] += r0; gs[4 * i + 1] += r1; gs[4 * i + 2] += r2; gs[4 * i + 3] += r3;
                                             gq[4 * i] = fmaf(r0, r0, gq[4 * i]); gq[4 * i + 1] = fmaf(r1, r1, gq[4 * i + 1]);
                                             gq[4 * i + 2] = fmaf(r2, r2, gq[4 * i + 2]); gq[4 * i + 3] = fmaf(r3, r3, gq[4 * i + 3]);
+                                        }
+                                    }
+                                    if constexpr (OCT) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) {
+                                            const bf16x2 v = __builtin_bit_cast(bf16x2, pk[j]);
+                                            gs[h] = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(bf16x2, 0x3f803f80u), gs[h], false);
+                                            gq[h] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[h], false);
                                         }
                                     }
                                     if constexpr (NT >= 2) reinterpret_cast<uint4*>(p.y + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -489,18 +489,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 if (flush) {
                     // 16 voxel lanes of a DPP row -> one value; 8 d-plane waves -> LDS; one plain store per (slot, channel, stat)
 #pragma unroll
-                    for (int i = 0; i < 4 * NT; ++i) { gs[i] = row16_sum(gs[i]); gq[i] = row16_sum(gq[i]); }
+                    for (int i = 0; i < NSTAT; ++i) { gs[i] = row16_sum(gs[i]); gq[i] = row16_sum(gq[i]); }
                     if (lr == 0) {
                         float4* r0 = reinterpret_cast<float4*>(sRed + (wave * 2) * WROWS_TAP + lq * 4 * NT);
                         float4* r1 = reinterpret_cast<float4*>(sRed + (wave * 2 + 1) * WROWS_TAP + lq * 4 * NT);
 #pragma unroll
                         for (int i = 0; i < NT; ++i) {
-                            r0[i] = make_float4(gs[4 * i], gs[4 * i + 1], gs[4 * i + 2], gs[4 * i + 3]);
-                            r1[i] = make_float4(gq[4 * i], gq[4 * i + 1], gq[4 * i + 2], gq[4 * i + 3]);
+                            if constexpr (OCT) {        // the 8-channel sum goes to the first channel of the octet, zeros to the other seven
+                                r0[i] = make_float4((i & 1) ? 0.f : gs[i >> 1], 0.f, 0.f, 0.f);
+                                r1[i] = make_float4((i & 1) ? 0.f : gq[i >> 1], 0.f, 0.f, 0.f);
+                            } else {
+                                r0[i] = make_float4(gs[4 * i], gs[4 * i + 1], gs[4 * i + 2], gs[4 * i + 3]);
+                                r1[i] = make_float4(gq[4 * i], gq[4 * i + 1], gq[4 * i + 2], gq[4 * i + 3]);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < 4 * NT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+                    for (int i = 0; i < NSTAT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
                     __syncthreads();
                     if (tid < 2 * WROWS_TAP) {
                         float t = 0.f;
@@ -693,6 +698,7 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
     for (int t = 0; t < ntaps && reg27; ++t)
         reg27 = tap_offsets[3 * t] == t / 9 - 1 && tap_offsets[3 * t + 1] == (t / 3) % 3 - 1 && tap_offsets[3 * t + 2] == t % 3 - 1;
     if (stats_ws) {
+        GFE_REQUIRE(NT < 4 || Cout % 64 == 0, GFE_ERR_SHAPE);         // 64-channel tiles write 8-channel sums (see OCT in the kernel)
         if (NT == 1) return conv_launch<1, 3, false, true>(p, st);
         if (NT == 2) return conv_launch<2, 3, false, true>(p, st);
         return reg27 ? conv_launch<4, 3, true, true>(p, st) : conv_launch<4, 3, false, true>(p, st);
@@ -709,6 +715,7 @@ int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* c
     GFE_REQUIRE(x && w_packed && cls_woff && cls_ntaps && cls_parity && tap_offsets && y, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(gfe_conv3d_cout_pad(Cout) >= 64, GFE_ERR_SHAPE);              // the multi-class variant is built for 64-channel groups
+    GFE_REQUIRE(!stats_ws || Cout % 64 == 0, GFE_ERR_SHAPE);                  // ... whose partials are 8-channel sums
     GFE_REQUIRE(oshift == 0 || oshift == 1, GFE_ERR_SHAPE);
     GFE_REQUIRE(OD == 2 * D - 1 + oshift && OH == 2 * H - 1 + oshift && OW == 2 * W - 1 + oshift, GFE_ERR_SHAPE);
     GFE_REQUIRE(D * H * W * Cin * 2 < 0x7fffffffLL && w_elems * 2 < 0xffffffffLL, GFE_ERR_SHAPE);

@@ -130,6 +130,7 @@ def convT_fused(x, fused, cout, res, out, stats=True):
     OD, OH, OW = out.shape[1:4]
     oshift = OD - (2 * D - 1)
     assert oshift in (0, 1) and OH == 2 * H - 1 + oshift and OW == 2 * W - 1 + oshift, "unsupported upsampling size"
+    stats = stats and cout % 64 == 0          # 64-channel tiles write 8-channel sums (gfe_hip.h)
     ws = new_gn_partials(B, lib().gfe_convt3d_stat_slots(B, D, H, W, cout), cout, x.device) if stats else None
     nt = fused["ntaps"][0]
     call("gfe_convt3d_k3s2_fused", ptr(x), ptr(fused["w"]), fused["woff"][1], nt.ctypes.data, fused["parity"][1], fused["taps"][1],
@@ -176,6 +177,8 @@ def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu
         assert oshift in (0, 1) and OH == 2 * H - 1 + oshift and OW == 2 * W - 1 + oshift, "unsupported upsampling size"
     wstride = w_packed.stride(0) if w_packed.dim() == 5 else 0
     ws, slot0 = None, 0
+    if stats is True and cout >= 64 and cout % 64:
+        stats = None                 # 64-channel tiles write 8-channel sums: other widths take the separate statistics pass
     if stats is True:
         ws = new_gn_partials(B, conv_stat_slots(B, D, H, W, cout), cout, x.device)
     elif stats is not None:

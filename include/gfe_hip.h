@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 15
+#define GFE_ABI_VERSION 16
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -111,7 +111,9 @@ int gfe_conv3d_cout_pad(int64_t Cout);
  *   stats_slot0 .. stats_slot0 + gfe_conv3d_stat_slots(B, D, H, W, Cout) - 1 (one per persistent block when Cout <= 64, one per
  *   tile otherwise); slots it does not write stay zero.  Calls that build one tensor together (the 8 parity classes of a
  *   transposed conv) use disjoint slot ranges;
- *   consume with gfe_groupnorm_from_partials. */
+ *   consume with gfe_groupnorm_from_partials.  Granularity: for Cout >= 64 (64-channel tiles) channel 8k holds the sums of channels
+ *   8k .. 8k+7 and the other seven read zero -- exact for GroupNorm groups that are multiples of 8 channels, which is why Cout must
+ *   then be a multiple of 64 (GFE_ERR_SHAPE otherwise; narrower outputs keep per-channel sums). */
 int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias, const float* bias_tab,
                      const void* res, void* y,
                      int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
