@@ -132,10 +132,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     // fetched once per XCD (measured: 2.0 GB FETCH_SIZE for a 0.9 GB input before the remap).  Speed only, never correctness.
     const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const int vb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;       // bijective for any grid size
-    const int tile_begin = vb * p.tiles_per_block;
-    const int tile_end = min(ntiles, tile_begin + p.tiles_per_block);
+    // ... and INTERLEAVED inside the XCD's range (block xi of an XCD with nbx blocks takes items xi, xi + nbx, ...): at any time the
+    // XCD works on ~nbx consecutive tiles, so the halo faces shared with the w- and h-neighbours are in its L2 while they are wanted
+    // (a block walking its own contiguous range met its h-neighbour 12 tiles = 40 us later, long after the L2 had turned over).
+    // Multi-class launches keep contiguous ranges: there the same block re-reads a tile for the next parity class.
+    const int nbx = xq + (xcd < xr ? 1 : 0);                 // blocks on this XCD
+    const int xcd_begin = min(ntiles, (vb - xi) * p.tiles_per_block), xcd_end = min(ntiles, (vb - xi + nbx) * p.tiles_per_block);
+    const int tile_stride = MC ? 1 : nbx;
+    const int tile_begin = MC ? vb * p.tiles_per_block : xcd_begin + xi;
+    const int tile_end = MC ? min(ntiles, tile_begin + p.tiles_per_block) : xcd_end;
     const int upt = p.ngroups * p.nslab;                     // units per tile: (group, slab)
-    const int nunits = (tile_end - tile_begin) * upt;
+    const int my_tiles = tile_end > tile_begin ? (tile_end - tile_begin + tile_stride - 1) / tile_stride : 0;
+    const int nunits = my_tiles * upt;
     if (nunits <= 0) return;
 #if defined(GFE_EXP_STAMP)
     const bool stamp_on = g_stamp_buf != nullptr && blockIdx.x == 101;
@@ -181,20 +189,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         wvoff[j] = (k < W_PIECES && R < WSTAGE_ROWS) ? (unsigned)((tl * p.CoutPad + r) * 64 + c * 16) : OOB;
     }
 
-    TilePos cur;
-    {
-        int t = tile_begin;
-        cur.cls = 0;
-        if constexpr (MC) { cur.cls = t % p.ncls; t /= p.ncls; }
-        cur.tw = t % p.ntw; t /= p.ntw;
-        cur.th = t % p.nth; t /= p.nth;
-        cur.td = t % p.ntd; cur.b = t / p.ntd;
-    }
-    TilePos nxt = cur;
-    auto advance = [&](TilePos& q) {
-        if constexpr (MC) { if (++q.cls < p.ncls) return; q.cls = 0; }
-        if (++q.tw == p.ntw) { q.tw = 0; if (++q.th == p.nth) { q.th = 0; if (++q.td == p.ntd) { q.td = 0; ++q.b; } } }
+    auto decode = [&](int t) {
+        TilePos q;
+        q.cls = 0;
+        if constexpr (MC) { q.cls = t % p.ncls; t /= p.ncls; }
+        q.tw = t % p.ntw; t /= p.ntw;
+        q.th = t % p.nth; t /= p.nth;
+        q.td = t % p.ntd; q.b = t / p.ntd;
+        return q;
     };
+    int cur_t = tile_begin, nxt_t = tile_begin;             // work-item indices (block-uniform)
+    TilePos cur = decode(cur_t);
+    TilePos nxt = cur;
 
     const size_t sample_elems = (size_t)p.D * p.H * p.W * p.Cin;
     const unsigned sample_bytes = (unsigned)(sample_elems * 2);
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         const bool next_unit = u + 1 < nunits;
         const int ut1 = (ut + 1 == upt) ? 0 : ut + 1;
         const int group1 = ut1 / p.nslab, slab1 = ut1 - group1 * p.nslab;
-        if (next_unit && ut1 == 0) advance(nxt);
+        if (next_unit && ut1 == 0) { nxt_t += tile_stride; nxt = decode(nxt_t); }
         const uint8_t* aT = sA + (u & 1) * A_BYTES;
         const int ntaps_u = MC ? p.c_ntaps[cur.cls] : p.ntaps, tap0_u = MC ? p.c_tap0[cur.cls] : 0;
         const int nstage = (ntaps_u + TPS - 1) / TPS;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             }
         }
         GFE_STAMP(5);
-        if (ut + 1 == upt) advance(cur);
+        if (ut + 1 == upt) { cur_t += tile_stride; cur = decode(min(cur_t, ntiles - 1)); }
     }
 #endif
 }
