@@ -33,6 +33,7 @@
 // and division-free index math 730-780; ablation showed the non-MFMA instruction stream cost 2x the MFMA time -> this DMA form,
 // 970-1030 TFLOP/s.  DESIGN.md 4.1 has the ablation table and the list of DMA-issue variants that were measured and dropped.)
 #include "common.h"
+#include "convt3d.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -621,7 +622,9 @@ int gfe_convt3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t C
     const int64_t tps = gfe_conv3d_tiles(D, H, W), items = B * tps * 8;
     if (gfe_conv3d_cout_pad(Cout) > 64) return (int)(tps * 8);                // (tile, class) slots
     const int64_t ipb = ceil_div(items, 256);
-    return (int)ceil_div(items, ipb);                                        // one slot per persistent block
+    const int slots = (int)ceil_div(items, ipb);                             // one slot per persistent block
+    const int slots_res = convt_resident_grid(B, D, H, W, nullptr);          // ... of either kernel (the dispatch depends on Cin)
+    return slots > slots_res ? slots : slots_res;
 }
 
 #if defined(GFE_EXP_STAMP)
@@ -725,6 +728,31 @@ int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* c
     GFE_REQUIRE(oshift == 0 || oshift == 1, GFE_ERR_SHAPE);
     GFE_REQUIRE(OD == 2 * D - 1 + oshift && OH == 2 * H - 1 + oshift && OW == 2 * W - 1 + oshift, GFE_ERR_SHAPE);
     GFE_REQUIRE(D * H * W * Cin * 2 < 0x7fffffffLL && w_elems * 2 < 0xffffffffLL, GFE_ERR_SHAPE);
+    if (convt_resident_fits(Cin, Cout) && !getenv("GFE_CONVT_STREAMED")) {
+        // all input channels of a 4x8x8 tile fit in LDS: stage them once for the 8 classes (convt3d.hip)
+        ConvTParams q;
+        q.x = (const uint16_t*)x; q.w = (const uint16_t*)w_packed; q.res = (const uint16_t*)res; q.y = (uint16_t*)y; q.stats = stats_ws;
+        q.B = (int)B; q.D = (int)D; q.H = (int)H; q.W = (int)W; q.Cin = (int)Cin; q.Cout = (int)Cout; q.CoutPad = 64;
+        q.OD = (int)OD; q.OH = (int)OH; q.OW = (int)OW; q.nslab = (int)(Cin / 32); q.oshift = oshift; q.stats_nblk = (int)stats_nblk;
+        q.w_bytes = (unsigned)(w_elems * 2);
+        int total = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int nt = cls_ntaps[c];
+            GFE_REQUIRE((nt == 1 || nt == 2 || nt == 4 || nt == 8) && cls_woff[c] >= 0 && cls_woff[c] % 8 == 0, GFE_ERR_SHAPE);
+            q.c_ntaps[c] = nt; q.c_lg[c] = nt == 1 ? 0 : nt == 2 ? 1 : nt == 4 ? 2 : 3; q.c_tap0[c] = total; q.c_woff[c] = cls_woff[c];
+            q.c_op[c] = (cls_parity[3 * c] & 1) | ((cls_parity[3 * c + 1] & 1) << 1) | ((cls_parity[3 * c + 2] & 1) << 2);
+            total += nt;
+        }
+        GFE_REQUIRE(total == 27, GFE_ERR_SHAPE);
+        for (int t = 0; t < total; ++t) {
+            const int8_t* o = tap_offsets + 3 * t;
+            GFE_REQUIRE(o[0] >= 0 && o[0] <= 1 && o[1] >= 0 && o[1] <= 1 && o[2] >= 0 && o[2] <= 1, GFE_ERR_SHAPE);
+            q.toff[t] = ((o[0] * PH + o[1]) * PW + o[2]) * VSTRIDE;
+            q.txor[t] = (o[1] & 1) ? 32 : 0;
+        }
+        if (stats_ws) GFE_REQUIRE(gfe_convt3d_stat_slots(B, D, H, W, Cout) <= stats_nblk && stats_nblk <= 0x7fffffff, GFE_ERR_SHAPE);
+        return convt_resident_launch(q, (hipStream_t)stream);
+    }
     ConvParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = nullptr; p.bias_tab = nullptr;
     p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = 0;
