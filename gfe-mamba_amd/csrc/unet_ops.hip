@@ -41,18 +41,30 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ scale,
                                                            float* __restrict__ shift, int64_t S, int C, int G, int nblk, float eps) {
-    extern __shared__ double dl[];               // [2][C] channel sums, then [2][G] mean / rstd
+    extern __shared__ double dl[];               // [2][C] channel sums, then [2][G] mean / rstd, then [tpc][2C] per-thread sums
     const int b = blockIdx.x, tid = threadIdx.x;
-    // column c = tid % (2C) is summed by 1024/(2C) threads striding over the nblk partials, merged through LDS atomics
+    // column c = tid % (2C) is summed by 1024/(2C) threads striding over the nblk partials (4 independent chains each), merged
+    // through a plain LDS table (double-precision LDS atomics are CAS loops)
     const int ncol = 2 * C;
-    for (int c = tid; c < ncol + 2 * G; c += 1024) dl[c] = 0.0;
-    __syncthreads();
     const int tpc = 1024 / ncol;                 // threads per column (2C <= 1024)
+    double* part_sums = dl + ncol + 2 * G;
     if (tid < tpc * ncol) {
         const int c = tid % ncol, part = tid / ncol;
+        const float* col = ws + (size_t)b * nblk * ncol + c;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = part;
+        for (; k + 3 * tpc < nblk; k += 4 * tpc) {
+            a0 += (double)col[(size_t)k * ncol]; a1 += (double)col[(size_t)(k + tpc) * ncol];
+            a2 += (double)col[(size_t)(k + 2 * tpc) * ncol]; a3 += (double)col[(size_t)(k + 3 * tpc) * ncol];
+        }
+        for (; k < nblk; k += tpc) a0 += (double)col[(size_t)k * ncol];
+        part_sums[part * ncol + c] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int c = tid; c < ncol; c += 1024) {
         double a = 0.0;
-        for (int k = part; k < nblk; k += tpc) a += (double)ws[((size_t)b * nblk + k) * ncol + c];
-        atomicAdd(&dl[c], a);
+        for (int q = 0; q < tpc; ++q) a += part_sums[q * ncol + c];
+        dl[c] = a;
     }
     __syncthreads();
     double* gm = dl + 2 * C;
@@ -241,7 +253,7 @@ int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* be
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, (unsigned)B), dim3(256), 2 * C * sizeof(float), st,
                        (const bf16_t*)x, ws, S, (int)C, vpb, nblk);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G) * sizeof(double), st,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G + 1024) * sizeof(double), st,
                        ws, gamma, beta, scale, shift, S, (int)C, (int)G, nblk, eps);
     return gfe_launch_status();
 }
@@ -256,7 +268,7 @@ int gfe_groupnorm_from_partials(const float* ws, int64_t nblk, const float* gamm
         hipLaunchKernelGGL(gn_reduce_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, ws, ws2, (int)nblk, (int)(2 * C));
         ws = ws2; nblk = 32;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G) * sizeof(double), st,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G + 1024) * sizeof(double), st,
                        ws, gamma, beta, scale, shift, S, (int)C, (int)G, (int)nblk, eps);
     return gfe_launch_status();
 }
