@@ -12,6 +12,9 @@ for b in 1 8 64; do python3 $R/bench.py --workload scan --batch $b > $O/scan_b${
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan -o scan -- python3 $R/bench.py --workload scan --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vit3d -o vit3d -- python3 $R/bench.py --workload vit3d --no-cpu-baseline > /dev/null 2>&1
+# the roofline kernel alone (one shape: 64->64 @96^3, B=8), so that its average duration can be read off directly
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv64 -o conv64 -- python3 $R/tools/conv_bench.py 64 96 8 20 > /dev/null 2>&1
+cp $O/prof_conv64/conv64_kernel_stats.csv $O/conv64_b8_${TAG}_kernel_stats.csv
 cp $O/prof_step/step_kernel_stats.csv $O/step_b8_${TAG}_kernel_stats.csv
 cp $O/prof_scan/scan_kernel_stats.csv $O/scan_b8_${TAG}_kernel_stats.csv
 cp $O/prof_vit3d/vit3d_kernel_stats.csv $O/vit3d_b8_${TAG}_kernel_stats.csv
