@@ -285,3 +285,36 @@ def test_generator_128_cubed_config4_runs():
     assert tuple(mi.shape) == (1, 256, 256, 128) and tuple(mo.shape) == (1, 256, 256, 128) and tuple(pet.shape) == (1, 1, 128, 128, 128)
     assert torch.isfinite(pet).all() and torch.isfinite(mo.float()).all()
     assert rel_err(pet, pet2) < 2e-2 and rel_err(mo, mo2) < 2e-2
+
+
+@pytest.mark.parametrize("shape,full", [((1, 5, 9, 7), True), ((2, 6, 8, 8), True), ((1, 4, 11, 16), False), ((1, 1, 1, 1), True), ((1, 9, 5, 3), False)])
+def test_resident_transposed_conv_ragged_shapes(shape, full, monkeypatch):
+    """The LDS-resident transposed-conv kernel (convt3d.hip, Cin = 128 -> Cout = 64) on sizes that are not multiples of its 4x8x8 tile,
+    with (2n) and without (2n-1) the nearest-resize duplicate plane: against ConvTranspose3d + F.interpolate + skip in torch fp32
+    (buildingblocks.py:523-537), and against the streamed kernel on the same inputs; GroupNorm partials against the statistics pass."""
+    from gfe_hip import nn_ops as K
+    from pytorch3dunet.unet3d.buildingblocks import TransposeConvUpsampling
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + H * 10 + W)
+    up = TransposeConvUpsampling(128, 64).to(DEV)
+    with torch.no_grad():
+        up.upsample.conv_transposed.weight.copy_(torch.randn(128, 64, 3, 3, 3, generator=g) / (27 * 128 / 8) ** 0.5)
+    x = torch.randn(B, D, H, W, 128, generator=g).to(BF).to(DEV)
+    osz = [2 * n if full else 2 * n - 1 for n in (D, H, W)]
+    skip = torch.randn(B, *osz, 64, generator=g).to(BF).to(DEV)
+    with torch.no_grad():
+        y = up(skip, x)
+        monkeypatch.setenv("GFE_CONVT_STREAMED", "1")
+        y_streamed = up(skip, x)
+        monkeypatch.delenv("GFE_CONVT_STREAMED")
+        wq = up.upsample.conv_transposed.weight.to(BF).float()
+        ref = F.conv_transpose3d(x.float().permute(0, 4, 1, 2, 3), wq, stride=2, padding=1)
+        if list(ref.shape[2:]) != osz:
+            ref = F.interpolate(ref, size=osz)                                    # default mode 'nearest' (buildingblocks.py:533)
+        ref = ref.permute(0, 2, 3, 4, 1) + skip.float()
+    assert rel_err(y, ref) < 1e-2 and rel_err(y_streamed, ref) < 1e-2
+    assert (y.float() - y_streamed.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()     # both round an f32 sum to bf16
+    gamma, beta = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    s1, t1 = K.groupnorm_scale_shift(y, gamma, beta, 8)
+    s0, t0 = K.groupnorm_scale_shift(y.clone(), gamma, beta, 8)
+    assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
