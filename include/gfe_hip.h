@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 16
+#define GFE_ABI_VERSION 17
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -286,6 +286,15 @@ int gfe_transpose_f32_to_bf16(const float* in, void* out, int64_t batch, int64_t
 /* The same data laid out for the K/V weight gradient: out[r][b*per_batch_cols + col_off + c] (bf16, row stride ldo) = in[b][r][c]. */
 int gfe_interleave_rows_bf16(const float* in, void* out, int64_t B, int64_t R, int64_t Cc, int64_t ldo, int64_t per_batch_cols,
                              int64_t col_off, void* stream);
+
+/* ---- input pipeline ------------------------------------------------------------------------------------
+ * adaptive_normal (utils/data_normalization.py:20-48, applied per volume at dataloader/pic_table_loader.py:107): lo / hi = the order
+ * statistics of the voxels >= 0 at ranks int((m-1)*0.001+0.5) / int((m-1)*0.999+0.5), y = clamp((x - (hi+lo)/2) / ((hi-lo)/2), -1, 1).
+ * x, y: (B, n) f32 contiguous (y may alias x); ws: B * gfe_adaptive_normal_ws_words() uint32 of scratch, on return per volume
+ * ws[0] = m, ws[5] / ws[6] = bit patterns of lo / hi.  Radix select instead of the reference's full sort; bit-exact.  A volume
+ * without a voxel >= 0 (the reference raises IndexError) leaves m = 0 and an unspecified y: callers check ws[0]. */
+int gfe_adaptive_normal_ws_words(void);
+int gfe_adaptive_normal(const float* x, float* y, uint32_t* ws, int64_t B, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

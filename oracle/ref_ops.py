@@ -420,3 +420,24 @@ def geometry(D1, D2, D3, md1=8):
     H, W, p = (D2 // 4) * md1, (D1 // 32) * (D3 // 4), D2 // 4
     assert W % p == 0
     return dict(H=H, W=W, patch=p, num_patches=(H // p) * (W // p), d_cross=D1 * D2, keys=2 * D3)
+
+
+# ------------------------------------------------------------------------------------------------
+# Input pipeline
+# ------------------------------------------------------------------------------------------------
+
+
+def adaptive_normal(img, min_p=0.001, max_p=0.999):
+    """utils/data_normalization.py:20-48: quantiles of the voxels >= 0 by a full sort, affine map to [-1, 1], clip."""
+    pix = torch.sort(img[img >= 0])[0]                                # :26-27
+    n = pix.numel()
+
+    def at(p):                                                         # :28-33 / :35-40
+        idx = int(round(n - 1) * p + 0.5)
+        return pix[min(max(idx, 0), n - 1)]
+    lo, hi = at(min_p), at(max_p)
+    mean, sd = (hi + lo) / 2.0, (hi - lo) / 2.0                       # :42-43
+    out = (img - mean) / sd                                           # :44
+    out[out < -1] = -1.0                                              # :45
+    out[out > 1] = 1.0                                                # :46
+    return out

@@ -165,3 +165,15 @@ def test_cross_mamba_ablation_variants():
     # the variants really differ (a fixture that ignored the switches would pass the loop above with one set of numbers)
     preds = [fx[n + ".pred"] for n in ABL_CASES]
     assert all(np.abs(preds[i] - preds[j]).max() > 1e-4 for i in range(4) for j in range(i))
+
+
+AN_CASES = ("normal", "ties", "positive", "constant", "nonfinite", "single", "tiny_mixed")
+
+
+def test_adaptive_normal_bit_exact():
+    """oracle/ref_ops.adaptive_normal against the reference's own output (tests/golden/t4_adaptive_normal.npz): same f32 operations
+    in the same order -> identical bits, NaNs in the same places."""
+    fx = golden("t4_adaptive_normal.npz")
+    for name in AN_CASES:
+        got = O.adaptive_normal(torch.from_numpy(fx[name + ".x"].copy())).numpy()
+        assert np.array_equal(got, fx[name + ".y"], equal_nan=True), name

@@ -8,6 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/step_b8_${TAG}_bench.json 2> /dev/null
 python3 $R/bench.py --workload vit3d > $O/vit3d_b8_${TAG}_bench.json 2> /dev/null
+python3 $R/bench.py --workload normalise > $O/normalise_b8_${TAG}_bench.json 2> /dev/null
 for b in 1 8 64; do python3 $R/bench.py --workload scan --batch $b > $O/scan_b${b}_${TAG}_bench.json 2> /dev/null; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan -o scan -- python3 $R/bench.py --workload scan --no-cpu-baseline > /dev/null 2>&1

@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -38,6 +38,14 @@ def import_reference():
             m.__path__ = []
             sys.modules[name] = m
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    # utils/data_normalization.py:2-12 imports monai / nibabel (absent here) for its __main__ demo only; adaptive_normal uses torch alone
+    for name in ("monai", "monai.transforms", "monai.utils", "nibabel"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    for n in ("Compose", "LoadImaged", "ToTensord", "EnsureChannelFirstd", "Spacingd", "ScaleIntensityRanged", "CropForegroundd", "Resized"):
+        setattr(sys.modules["monai.transforms"], n, object)
     sys.path.insert(0, REF)
     import cross_atten.pscan as r_pscan
     import cross_atten.mamba as r_mamba
@@ -49,7 +57,8 @@ def import_reference():
     import pytorch3dunet.unet3d.buildingblocks as r_bb
     import vit_pytorch_diy.vit as r_vit
     import vit_pytorch_diy.vit_3d as r_vit3d
-    return types.SimpleNamespace(pscan=r_pscan, mamba=r_mamba, xattn=r_xattn, ft=r_ft, mt=r_mt, cls=r_cls,
+    import utils.data_normalization as r_norm
+    return types.SimpleNamespace(norm=r_norm, pscan=r_pscan, mamba=r_mamba, xattn=r_xattn, ft=r_ft, mt=r_mt, cls=r_cls,
                                  model=r_model, bb=r_bb, vit=r_vit, vit3d=r_vit3d)
 
 
@@ -336,6 +345,29 @@ def t3(R, out):
     np.savez_compressed(os.path.join(out, "t3_ablation.npz"), **fx)
 
 
+def t4(R, out):
+    """adaptive_normal (utils/data_normalization.py:20-48) on volumes with negatives, ties, signed zeros, a constant volume and infinities."""
+    g = np.random.Generator(np.random.Philox(key=[404, 1]))
+    cases = {}
+    cases["normal"] = g.standard_normal((20, 24, 16)).astype(np.float32) * 300 + 100
+    q = np.round(g.standard_normal((16, 16, 12)) * 4).astype(np.float32)          # heavy ties, exact zeros
+    q[0, 0, :4] = -0.0
+    cases["ties"] = q
+    cases["positive"] = g.exponential(500.0, (32, 32, 32)).astype(np.float32)
+    cases["constant"] = np.full((4, 5, 6), 7.5, dtype=np.float32)
+    e = g.standard_normal((8, 8, 8)).astype(np.float32)
+    e[1, 2, 3] = np.inf; e[2, 2, 2] = -np.inf; e[3, 3, 3] = np.nan
+    cases["nonfinite"] = e
+    cases["single"] = np.array([[[3.0]]], dtype=np.float32)
+    cases["tiny_mixed"] = np.array([-5.0, 0.0, 2.0, -1.0, 9.0, 4.0, 4.0], dtype=np.float32).reshape(7, 1, 1)
+    fx = {}
+    for name, x in cases.items():
+        y = R.norm.adaptive_normal(torch.from_numpy(x.copy()))
+        fx[name + ".x"] = x
+        fx[name + ".y"] = npy(y)
+    np.savez_compressed(os.path.join(out, "t4_adaptive_normal.npz"), **fx)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -344,7 +376,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
