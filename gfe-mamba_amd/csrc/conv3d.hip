@@ -37,6 +37,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void* lds_void_t;
 
@@ -406,7 +407,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // GroupNorm partials of what this tile stores (the next layer normalises it): per-channel sum / sum of squares
             // of the ROUNDED values, so the statistics describe exactly the tensor the consumer reads.  The per-lane sums persist
             // across the block's tiles and are reduced / stored only when the (sample, channel group) changes or the block ends.
-            if (cd < p.D && c0 < p.Cout) {
+            // 64-channel single-class launches are always stride-1 convs (the host sends anything else to the multi-class variant)
+            constexpr bool FAST_OK = !MC && (!STATS || OCT) && NT == 4;
+            if constexpr (FAST_OK) {
+              if (cd < p.D && c0 < p.Cout) {
+                // ---- the common case (stride-1 conv, one destination per voxel): a 64-bit scalar tile base + 32-bit lane offsets, no
+                // duplicate-plane loops, ReLU on the packed bf16 words (v_pk_max_i16: a negative float is a negative int16, and
+                // relu(round(x)) == round(relu(x))).  ~40 % fewer VALU instructions than the general path below -- the epilogue is
+                // VALU-issue-bound.
+                const size_t tile_base = ((((size_t)b * p.D + d0) * p.H + h0) * p.W + w0) * p.Cout;      // scalar
+                const bf16_t* res_t = p.res ? p.res + tile_base : nullptr;
+                bf16_t* y_t = p.y + tile_base;
+#pragma unroll
+                for (int xt = 0; xt < 4; ++xt) {
+                    const int ch_ = h0 + 2 * xt + (lr >> 3), cw_ = w0 + (lr & 7);
+                    if (ch_ >= p.H || cw_ >= p.W) continue;
+                    const unsigned o = (unsigned)(((wave * p.H + 2 * xt + (lr >> 3)) * p.W + (lr & 7)) * p.Cout + c0);   // inside the tile's box
+                    if (p.bias_tab) {
+                        const int cls = (cd == 0) | ((cd == p.D - 1) << 1) | ((ch_ == 0) << 2) | ((ch_ == p.H - 1) << 3) |
+                                        ((cw_ == 0) << 4) | ((cw_ == p.W - 1) << 5);
+                        const float4* bt = reinterpret_cast<const float4*>(p.bias_tab + (unsigned)((b * 64 + cls) * p.CoutPad + c0));
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) {
+                            const float4 t = bt[i];
+                            acc[xt][i][0] += t.x; acc[xt][i][1] += t.y; acc[xt][i][2] += t.z; acc[xt][i][3] += t.w;
+                        }
+                    }
+                    if (p.bias) {
+                        const float4* bv = reinterpret_cast<const float4*>(p.bias + c0);
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) {
+                            const float4 t = bv[i];
+                            acc[xt][i][0] += t.x; acc[xt][i][1] += t.y; acc[xt][i][2] += t.z; acc[xt][i][3] += t.w;
+                        }
+                    }
+                    uint4 rv[2];
+                    if (res_t) { const uint4* rp = reinterpret_cast<const uint4*>(res_t + o); rv[0] = rp[0]; rv[1] = rp[1]; }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t rw[4] = {rv[h].x, rv[h].y, rv[h].z, rv[h].w};
+                        uint32_t pk[4];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4 a = acc[xt][2 * h + j];
+                            if (res_t) {
+                                a[0] += bf16lo_to_f32(rw[2 * j]); a[1] += bf16hi_to_f32(rw[2 * j]);
+                                a[2] += bf16lo_to_f32(rw[2 * j + 1]); a[3] += bf16hi_to_f32(rw[2 * j + 1]);
+                            }
+                            pk[2 * j] = pack_bf16x2(a[0], a[1]); pk[2 * j + 1] = pack_bf16x2(a[2], a[3]);
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[j]), s16x2{0, 0}));
+                        }
+                        if constexpr (OCT) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bf16x2 v = __builtin_bit_cast(bf16x2, pk[j]);
+                                gs[h] = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(bf16x2, 0x3f803f80u), gs[h], false);
+                                gq[h] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[h], false);
+                            }
+                        }
+                        reinterpret_cast<uint4*>(y_t + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    }
+                }
+              }
+            } else if (cd < p.D && c0 < p.Cout) {
 #pragma unroll
                 for (int xt = 0; xt < 4; ++xt) {
                     const int ch_ = h0 + 2 * xt + (lr >> 3), cw_ = w0 + (lr & 7);
@@ -706,6 +773,14 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
     bool reg27 = ntaps == 27 && ostride == 1;
     for (int t = 0; t < ntaps && reg27; ++t)
         reg27 = tap_offsets[3 * t] == t / 9 - 1 && tap_offsets[3 * t + 1] == (t / 3) % 3 - 1 && tap_offsets[3 * t + 2] == t % 3 - 1;
+    if (NT == 4 && ostride != 1) {
+        // one parity class of a transposed conv with >= 64 output channels, launched on its own: the single-class 64-channel kernels
+        // carry only the stride-1 epilogue, so this goes through the multi-class variant with one class
+        GFE_REQUIRE(!stats_ws || Cout % 64 == 0, GFE_ERR_SHAPE);
+        p.ncls = 1; p.c_ntaps[0] = ntaps; p.c_tap0[0] = 0; p.c_woff[0] = 0; p.c_op[0] = op_d | (op_h << 1) | (op_w << 2);
+        p.w_bytes = (unsigned)((size_t)p.nslab * ntaps * p.CoutPad * 64);
+        return stats_ws ? conv_launch<4, 3, false, true, true>(p, st) : conv_launch<4, 3, false, false, true>(p, st);
+    }
     if (stats_ws) {
         GFE_REQUIRE(NT < 4 || Cout % 64 == 0, GFE_ERR_SHAPE);         // 64-channel tiles write 8-channel sums (see OCT in the kernel)
         if (NT == 1) return conv_launch<1, 3, false, true>(p, st);
