@@ -214,7 +214,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise"])
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (volumes for `step`, sequences for `scan`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph")
+    ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph (experimental: for host-bound batches of 1-4 volumes; "
+                         "whole-step replay hits an intermittent HSA exception on this ROCm, see DESIGN.md 6)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
