@@ -5,6 +5,9 @@
 
 workload `step` (default): one classify_mamba training step (frozen generator fwd + head fwd/bwd + per-parameter
 clip + Adam) on a synthetic batch of 8 volumes of 96^3 per GPU (BASELINE config 5's per-GPU share == config 3 + bwd).
+By default the step is software-pipelined across batches (ClassifyStep.train_step_pipelined): every timed step runs the head
+(fwd, bwd, all-reduce, clip + Adam) of batch k on one stream and the frozen generator's forward for batch k+1 on another -- one
+generator forward and one head step per step, nothing skipped or cached, identical updates; `--no-pipeline` runs them back to back.
 workload `scan`: BASELINE config 2, the fused selective scan alone (L=4096, ED=1024, N=16, bf16), fwd+bwd.
 workload `vit3d`: the synthetic 3-D ViT of SURVEY 8-d (96^3, 8^3 patches -> 1729 tokens, dim 512, depth 4, 8 heads x 64), forward;
 its roofline object is the flash-attention kernel against the bf16 MFMA peak.
@@ -216,6 +219,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph (experimental: for host-bound batches of 1-4 volumes; "
                          "whole-step replay hits an intermittent HSA exception on this ROCm, see DESIGN.md 6)")
+    ap.add_argument("--no-pipeline", action="store_true", help="step workload: strictly serial step (generator, then head) on one stream")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,11 +249,12 @@ def main():
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
     else:
         from gfe_hip.step_bench import StepWorkload
-        wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph)
-        steps, warmup = a.steps or 10, a.warmup if a.warmup is not None else 3
+        wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph, pipeline=not a.no_pipeline)
+        steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 5
         metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
-               "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph)}
+               "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph),
+               "pipeline": "generator(batch k+1) || head(batch k), 2 streams" if wl.pipeline else "none"}
 
     def barrier():
         if world > 1:

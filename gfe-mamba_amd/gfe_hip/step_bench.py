@@ -28,8 +28,8 @@ HEAD_GFLOP_PER_SAMPLE = 11.64
 class StepWorkload:
     name = "classify_mamba train step (frozen generator fwd + head fwd/bwd + per-param clip + Adam), 96^3, synthetic"
 
-    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False):
-        self.batch, self.world, self.vol, self.graph = batch, world, vol, graph
+    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True):
+        self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline and not graph
         gen, head, ft = build_models(vol=vol, seed=0)
         import os
         ov = os.environ.get("GFE_OVERLAP_UPDATE")          # default off (see ClassifyStep); 1 turns it on for A/B runs
@@ -41,6 +41,10 @@ class StepWorkload:
     def step(self):
         if self.graph:                                   # HIP-graph replay of zero_grad + forward + backward (small batches are host-bound)
             return self.step_obj.train_step_graphed(*self.inputs)
+        if self.pipeline:
+            # one head step (this batch) + one generator forward (the next batch; synthetic: the same volumes) per call, on two
+            # streams: the frozen generator does not depend on the update (ClassifyStep.train_step_pipelined)
+            return self.step_obj.train_step_pipelined(*self.inputs, x_next=self.inputs[0])
         return self.step_obj.train_step(*self.inputs)
 
     def roofline(self, iters=3):

@@ -83,6 +83,7 @@ def save_checkpoint(step, run_dir, kind="current"):
     """Writes the head's and the classifier's state dicts under the reference's file names and key layout, so that the reference's
     own `load_state_dict` (plain `torch.load` + `load_state_dict`) accepts them.  `step.opt.wait_updated()` first: an overlapped
     update may still be running."""
+    step.join()
     step.opt.wait_updated()
     torch.cuda.current_stream().synchronize() if torch.cuda.is_available() else None
     paths = [os.path.join(run_dir, f) for f in _FILES[kind]]

@@ -293,3 +293,37 @@ def test_cross_mamba_ablation_vs_reference_fixture():
             else:
                 got = float(p.grad.double().norm())
                 assert abs(got - ref) <= 1e-1 * ref + atol, (name, k, got, ref)     # norms of bf16-operand gradients, as in T1 / T2
+
+
+@pytest.mark.gpu
+def test_pipelined_step_matches_serial_step():
+    """ClassifyStep.train_step_pipelined (head of batch k on a second stream under the frozen generator's forward for batch k+1)
+    over four DIFFERENT batches: same losses and parameters as the serial train_step -- in particular every head consumes the
+    generator outputs of its own batch -- with and without announcing the next batch."""
+    from gfe_hip.step import ClassifyStep, build_models
+    import gfe_hip.det_init as det
+    kw = dict(vol=(32, 32, 32), f_maps=(8, 16, 32), dim=64, depth=2, heads=8, vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), seed=3)
+    batches = [[t.cuda() for t in det.det_inputs(2, (32, 32, 32), seed=50 + i)] for i in range(4)]
+    outs = []
+    for mode in ("serial", "pipelined", "pipelined_unannounced"):
+        gen, head, ft = build_models(**kw)
+        for m in ft.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        st = ClassifyStep(gen, head, ft)
+        losses = []
+        for i, b in enumerate(batches):
+            if mode == "serial":
+                losses.append(st.train_step(*b))
+            else:
+                nxt = batches[i + 1][0] if (mode == "pipelined" and i + 1 < len(batches)) else None
+                losses.append(st.train_step_pipelined(*b, x_next=nxt))
+        st.join()
+        torch.cuda.synchronize()
+        outs.append(([float(l) for l in losses], st.opt.flat_p.clone(), float(st.eval_step(*batches[0][:3]).sum())))
+    (l0, p0, e0) = outs[0]
+    assert len(set(round(v, 4) for v in l0)) > 1                     # the batches really differ
+    for l1, p1, e1 in outs[1:]:
+        assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
+        assert (p0 - p1).abs().max().item() < 4e-4
+        assert abs(e0 - e1) < 1e-3
