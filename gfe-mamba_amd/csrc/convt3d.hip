@@ -10,8 +10,13 @@
 //
 // Same conventions as conv3d.hip: weights are the MFMA A operand (v_mfma_f32_16x16x32_bf16, rows permuted at pack time so a lane owns 16
 // consecutive channels of one voxel), activations the B operand, 64-B voxel rows with XOR-swizzled 16-B chunks applied on the DMA's source
-// side, weight stages of 3 k-steps (a k-step = one (slab, tap) pair of the class, slab-major) double-buffered by waves 0-3, activation
-// DMA by waves 4-7.  8 waves: wave = (d-plane of the tile, half of the plane's 4 voxel tiles) -> 2 x 4 accumulator tiles.
+// side, weight stages of 3 k-steps (a k-step = one (slab, tap) pair of the class, slab-major), double-buffered.
+// Nine waves.  Waves 0-7 compute: wave = (d-plane of the tile, half of the plane's 4 voxel tiles) -> 2 x 4 accumulator tiles, k-steps
+// software-pipelined over two fragment sets; waves 4-7 also issue the activation DMA.  Wave 8 only moves weight stages: the CU returns
+// vector-memory data in order and vmcnt retires in order, so a wave that waits for a weight stage every stage cannot also have the
+// class's skip-tensor rows in flight -- with the weights on their own wave, the compute waves request those rows at the START of a class
+// and find them in registers in its epilogue (0.95 -> 0.92 ms; timing builds: the skip read costs 0.22 ms and the stores 0.07 of that,
+// as memory throughput rather than latency -- each 16-B-per-lane access touches half a 128-B voxel row).
 // Inputs are exactly those of gfe_convt3d_k3s2_fused (gfe_hip.h), which dispatches here when the tile fits.
 #include "common.h"
 #include "convt3d.h"
@@ -38,27 +43,26 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 constexpr int TD = CONVT_TD, TH = 8, TW = 8;
-constexpr int NWAVES = 8, NTHREADS = 512, DMA_WAVES = 4;
+constexpr int NWAVES = 8, W_PROD = 8, NTHREADS = 576, DMA_WAVES = 4;   // 8 compute waves + one weight-producer wave
 constexpr int PH = 10, PW = 10, VSTRIDE = 64;           // LDS pitches (voxels) / bytes per voxel row of one slab: as in conv3d.hip
 constexpr int SLAB_VOX = (TD + 1) * PH * PW;            // 500
 constexpr int SLAB_PIECES = (SLAB_VOX + 15) / 16;       // 32 one-KiB DMA pieces
 constexpr int SLAB_BYTES = SLAB_PIECES * 1024;
 constexpr int A_PER_WAVE = SLAB_PIECES / DMA_WAVES;     // 8 pieces per activation wave and slab
 constexpr int TPS = 3, W_PIECES = TPS * 64 / 16;        // weight stage: 3 k-steps x 64 rows = 12 pieces
-constexpr int W_PER_WAVE = W_PIECES / DMA_WAVES;        // 3
 constexpr unsigned OOB = 0x80000000u;
-static_assert(SLAB_PIECES % DMA_WAVES == 0 && W_PIECES % DMA_WAVES == 0, "piece split");
+static_assert(SLAB_PIECES % DMA_WAVES == 0, "piece split");
 
 struct TilePos { int b, td, th, tw; };
 
-__global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvTParams p) {
+__global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* sA = smem;                                           // nslab x SLAB_BYTES
     uint8_t* sW = smem + CONVT_MAX_SLABS * SLAB_BYTES;            // 2 x 12 KiB
     float* sRed = reinterpret_cast<float*>(sW + 2 * W_PIECES * 1024);   // [NWAVES][2][64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     const int ntiles = p.B * p.ntd * p.nth * p.ntw;
     // XCD-aware, interleaved tile walk (see conv3d.hip)
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
     };
 
     // ---- compute mapping: plane pl of the tile, voxel tiles xt = 2*hx + j (rows 2xt, 2xt+1 of the plane)
-    const int pl = wave >> 1, hx = wave & 1;
+    const bool w_prod = wave == W_PROD;                            // wave 8: weight DMA only (its vmcnt queue holds nothing else)
+    const int pl = (wave >> 1) & 3, hx = wave & 1;
     int abase[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
 
     // ---- DMA constants
     const int dw = wave & (DMA_WAVES - 1);
-    const bool a_wave = wave >= DMA_WAVES;
+    const bool a_wave = wave >= DMA_WAVES && !w_prod;              // waves 4-7: activation DMA besides their compute share
     int acoord[A_PER_WAVE];          // ld | lh << 4 | lw << 8 | (chunk*16) << 12 | valid << 20
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
@@ -99,12 +104,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
         const bool valid = ld <= TD && lh <= TH && lw <= TW;
         acoord[j] = ld | (lh << 4) | (lw << 8) | ((c * 16) << 12) | ((valid ? 1 : 0) << 20);
     }
-    unsigned wvoff[W_PER_WAVE];
-#pragma unroll
-    for (int j = 0; j < W_PER_WAVE; ++j) {
-        const int R = 16 * (dw + DMA_WAVES * j) + (lane >> 2), tl = R >> 6, r = R & 63;
-        wvoff[j] = (unsigned)((tl * p.CoutPad + r) * 64 + (((lane & 3) ^ ((r >> 1) & 3)) * 16));
-    }
+    // weight stage = 3 k-steps x 64 rows = 12 KiB contiguous in the packed buffer (CoutPad = 64): piece k = rows 16k + lane/4
+    const unsigned wvoff = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) * 16));     // (row >> 1) & 3 == (lane >> 3) & 3
     const size_t sample_elems = (size_t)p.D * p.H * p.W * p.Cin;
     const unsigned sample_bytes = (unsigned)(sample_elems * 2);
 
@@ -121,21 +122,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sA + slab * SLAB_BYTES + (dw + DMA_WAVES * j) * 1024), 16, voff, 0, 0, 0);
         }
     };
-    auto w_dma = [&](int cls, int stage, int buf) {               // k-steps 3*stage .. 3*stage+2 of a class, by the four weight waves
+    auto w_dma = [&](int cls, int stage, int buf) {               // k-steps 3*stage .. 3*stage+2 of a class, by the producer wave
         cls = rfl(cls);
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(p.w + p.c_woff[cls], p.w_bytes - (unsigned)(p.c_woff[cls] * 2));
-        const unsigned soff = (unsigned)rfl(stage * TPS * p.CoutPad * 64);       // past the class: next class's rows or zeros, never multiplied
+        const int soff = rfl(stage) * (W_PIECES * 1024);          // past the class: next class's rows or zeros, never multiplied
         const int lds_off = rfl(buf) * (W_PIECES * 1024);
 #pragma unroll
-        for (int j = 0; j < W_PER_WAVE; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sW + lds_off + (dw + DMA_WAVES * j) * 1024), 16, wvoff[j], soff, 0, 0);
+        for (int k = 0; k < W_PIECES; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t)(sW + lds_off + k * 1024), 16, wvoff, soff + k * 1024, 0, 0);
     };
 
     f32x4 acc[2][4];
+    uint4 rpf[2][2];                                   // skip tensor of the class being computed (primary destination of the lane's 2 voxels)
     float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};     // GroupNorm partials (8-channel sums, see conv3d.hip OCT) of what this block stores
 
     TilePos cur = decode(tile_begin);
-    if (a_wave) { for (int sl = 0; sl < p.nslab; ++sl) a_dma(cur, sl); } else w_dma(CONVT_NCLS - 1, 0, 0);
+    if (a_wave) { for (int sl = 0; sl < p.nslab; ++sl) a_dma(cur, sl); }
+    if (w_prod) w_dma(CONVT_NCLS - 1, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;
 
@@ -155,36 +158,65 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
             for (int st = 0; st < nst; ++st, ++gstage) {
                 // st == 0: everything this wave had issued was drained at the end of the previous class (or before the loop); the
                 // first class of a tile additionally needs the tail of the tile prefetch the activation waves issued at the tile end
-                if (!a_wave && st > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (w_prod && st > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the producer's queue holds weight stages only
                 if (a_wave && st == 0 && ci == CONVT_NCLS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (!a_wave) {
+                if (!w_prod && st == 0 && p.res) {
+                    // skip-tensor prefetch: the compute waves wait on vmcnt only at the end of a class, so the rows this class's epilogue
+                    // adds are requested now (primary destination of the lane's two voxels, exactly as the epilogue computes it) and
+                    // arrive under the class's stages instead of as an exposed HBM round trip in the epilogue
+                    const int opar_ = p.c_op[ci], cd_ = cur.td * TD + pl;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ch_ = cur.th * TH + 2 * (2 * hx + j) + (lr >> 3), cw_ = cur.tw * TW + (lr & 7);
+                        const int dd_ = 2 * cd_ + (opar_ & 1) + p.oshift, dh_ = 2 * ch_ + ((opar_ >> 1) & 1) + p.oshift, dw_ = 2 * cw_ + ((opar_ >> 2) & 1) + p.oshift;
+                        if (cd_ < p.D && ch_ < p.H && cw_ < p.W && dd_ < p.OD && dh_ < p.OH && dw_ < p.OW) {
+                            const uint4* rp = reinterpret_cast<const uint4*>(p.res + ((((size_t)cur.b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_) * p.Cout + lq * 16);
+                            rpf[j][0] = rp[0]; rpf[j][1] = rp[1];
+                        }
+                    }
+                }
+#if defined(CONVT_EXP_NOW)     // timing experiment only: weights are never restaged
+                if (false) {
+#else
+                if (w_prod) {
+#endif
                     if (st + 1 < nst) w_dma(ci, st + 1, (gstage + 1) & 1);
                     else if (ci > 0) w_dma(ci - 1, 0, (gstage + 1) & 1);
                     else if (next_tile) w_dma(CONVT_NCLS - 1, 0, (gstage + 1) & 1);
-                } else if (ci == 0 && next_tile) {
+                } else if (a_wave && ci == 0 && next_tile) {
                     // last class: k-steps below 3*st are done by every wave (barrier above) -> the slabs they covered are free
+#if !defined(CONVT_EXP_NOA)    // timing experiment only: the next tile is never fetched
                     while (pf_slab < p.nslab && ntaps * (pf_slab + 1) <= TPS * st) { a_dma(nxt, pf_slab); ++pf_slab; }
+#endif
                 }
+                if (w_prod) continue;
                 const uint8_t* wb = sW + (gstage & 1) * (W_PIECES * 1024) + wbase;
+                // software pipeline over the stage's k-steps: the 6 fragment reads of k-step jk+1 are issued before the 8 MFMAs of
+                // k-step jk (two register sets), so only the first k-step of a stage exposes the LDS latency
+                bf16x8 xf[2][2], wf[2][4];
+                auto frag_load = [&](int jk, int set) {
+                    const int ks = st * TPS + jk;
+                    const int sl = ks >> lg, tap = tap0 + (ks & (ntaps - 1));
+                    const int toff = p.toff[tap], txor = p.txor[tap];
+                    const uint8_t* aS = sA + sl * SLAB_BYTES;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) xf[set][j] = *reinterpret_cast<const bf16x8*>(aS + ((abase[j] + toff) ^ txor));
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) wf[set][ct] = *reinterpret_cast<const bf16x8*>(wb + (jk * 64 + ct * 16) * VSTRIDE);
+                };
+                frag_load(0, 0);                                             // (stage st exists, so its first k-step does)
 #pragma unroll
                 for (int jk = 0; jk < TPS; ++jk) {
-                    const int ks = st * TPS + jk;
-                    if (ks < nk) {                                               // block-uniform
-                        const int sl = ks >> lg, tap = tap0 + (ks & (ntaps - 1));
-                        const int toff = p.toff[tap], txor = p.txor[tap];
-                        const uint8_t* aS = sA + sl * SLAB_BYTES;
-                        bf16x8 xf[2], wf[4];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(aS + ((abase[j] + toff) ^ txor));
-#pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) wf[ct] = *reinterpret_cast<const bf16x8*>(wb + (jk * 64 + ct * 16) * VSTRIDE);
+                    const int set = jk & 1;
+                    if (st * TPS + jk < nk) {                                    // block-uniform
+                        if (jk + 1 < TPS && st * TPS + jk + 1 < nk) frag_load(jk + 1, set ^ 1);
 #pragma unroll
                         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], xf[j], acc[j][ct], 0, 0, 0);
+                            for (int j = 0; j < 2; ++j) acc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[set][ct], xf[set][j], acc[j][ct], 0, 0, 0);
                     }
                 }
             }
@@ -194,13 +226,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#if !defined(CONVT_EXP_NOA)
                 if (a_wave) { while (pf_slab < p.nslab) { a_dma(nxt, pf_slab); ++pf_slab; } }
+#endif
             }
 
             // ---- epilogue of class ci: resize placement (dst = raw + oshift, dst 0 duplicates raw 0), skip-sum, bf16 store, partials
             const int opar = p.c_op[ci];
             const int cd = cur.td * TD + pl, c0 = lq * 16;
-            if (cd < p.D && c0 < p.Cout) {
+#if defined(CONVT_EXP_NOEPI)   // timing experiment only: only the block's very last class is stored
+            if (!w_prod && cd < p.D && c0 < p.Cout && !next_tile && ci == 0) {
+#else
+            if (!w_prod && cd < p.D && c0 < p.Cout) {
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int xt = 2 * hx + j;
@@ -216,7 +254,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
                                 if (dd_ >= p.OD || dh_ >= p.OH || dw_ >= p.OW) continue;
                                 const size_t o = ((((size_t)cur.b * p.OD + dd_) * p.OH + dh_) * p.OW + dw_) * p.Cout + c0;
                                 uint4 rv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-                                if (p.res) { const uint4* rp = reinterpret_cast<const uint4*>(p.res + o); rv[0] = rp[0]; rv[1] = rp[1]; }
+#if !defined(CONVT_EXP_NORES)  // timing experiment only: the skip tensor is not read
+                                if (p.res) {
+                                    if (zd == 0 && zh == 0 && zw == 0) { rv[0] = rpf[j][0]; rv[1] = rpf[j][1]; }          // prefetched at the class start
+                                    else { const uint4* rp = reinterpret_cast<const uint4*>(p.res + o); rv[0] = rp[0]; rv[1] = rp[1]; }
+                                }
+#endif
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
                                     const uint32_t rw[4] = {rv[h].x, rv[h].y, rv[h].z, rv[h].w};
@@ -235,6 +278,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
                                             gq[h] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[h], false);
                                         }
                                     }
+#if defined(CONVT_EXP_NOSTORE)  // timing experiment only: results are computed but only the block's last class is stored
+                                    if (!next_tile && ci == 0)
+#endif
                                     reinterpret_cast<uint4*>(p.y + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                                 }
                             }
@@ -245,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void convt_resident_kernel(const ConvT
         if (p.stats && (!next_tile || nxt.b != cur.b)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) { gs[i] = row16_sum(gs[i]); gq[i] = row16_sum(gq[i]); }
-            if (lr == 0) {
+            if (lr == 0 && !w_prod) {
                 float4* r0 = reinterpret_cast<float4*>(sRed + (wave * 2) * 64 + lq * 16);
                 float4* r1 = reinterpret_cast<float4*>(sRed + (wave * 2 + 1) * 64 + lq * 16);
 #pragma unroll
