@@ -279,9 +279,9 @@ int gemm_launch(const GemmParams& p, int nsplit, hipStream_t st) {
 
 template <int AM, int BMODE>
 int gemm_launch_bm(const GemmParams& p, int nsplit, hipStream_t st) {
-    // weight-streaming shapes (the ViT's patch embedding: K = 147,456 with ~200 rows) re-read B once per row block: 128-row tiles
-    // even if the last one is half empty
-    const bool small = p.M <= 64 || (p.M % 128 != 0 && p.M % 128 <= 64 && p.M < 1024 && p.K < 32768);
+    // weight-streaming shapes (the ViT's patch embedding and its inverse: a 151 MB weight against ~200 rows) re-read B once per row
+    // block: 128-row tiles even if the last one is half empty
+    const bool small = p.M <= 64 || (p.M % 128 != 0 && p.M % 128 <= 64 && p.M < 1024 && (int64_t)p.N * p.K < (1LL << 25));   // B below 64 MB
     return small ? gemm_launch<64, AM, BMODE>(p, nsplit, st) : gemm_launch<128, AM, BMODE>(p, nsplit, st);
 }
 
