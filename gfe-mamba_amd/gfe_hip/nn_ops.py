@@ -210,6 +210,39 @@ def groupnorm_scale_shift(x, gamma, beta, groups, eps=1e-5):
     return ss[0], ss[1]
 
 
+_C1_MASK = {}
+
+
+def conv_c1_k3_tables(w32_oct, scale, shift, w1, b1):
+    """Effective weights / bias table of conv(GroupNorm(w1 x + b1)) as a one-channel 27-tap conv of x (gfe_conv3d_c1_k3):
+    w32_oct: (Cout, Cin, 27) f32 conv weight, taps in CONV3_TAPS order; scale, shift: (B, Cin) GroupNorm affine of r = w1 x + b1;
+    w1, b1: (Cin,) the 1x1x1 lift.  Returns weff (B, 27, Cout), tab (B, 64, Cout)."""
+    dev = w32_oct.device
+    m = _C1_MASK.get(str(dev))
+    if m is None:                                   # mask[cls][tap] = 1 when the tap stays inside the volume for boundary class cls
+        rows = []
+        for cls in range(64):
+            rows.append([0.0 if ((dd < 0 and cls & 1) or (dd > 0 and cls & 2) or (dh < 0 and cls & 4) or (dh > 0 and cls & 8) or
+                                 (dw < 0 and cls & 16) or (dw > 0 and cls & 32)) else 1.0 for dd, dh, dw in CONV3_TAPS])
+        m = _C1_MASK[str(dev)] = torch.tensor(rows, dtype=torch.float32, device=dev)
+    sw = scale * w1                                                   # (B, Cin)
+    sh = scale * b1 + shift
+    both = torch.einsum('oct,nbc->nbto', w32_oct, torch.stack([sw, sh]))      # (2, B, 27, Cout)
+    return both[0].contiguous(), torch.matmul(m, both[1]).contiguous()
+
+
+def conv_c1_k3(x, weff, tab, relu=True):
+    """x: (B, 1, D, H, W) f32|bf16 -> (B, D, H, W, 64) bf16 with its GroupNorm partials attached (`y.gn_partials`)."""
+    B, _, D, H, W = x.shape
+    C = weff.shape[-1]
+    y = torch.empty((B, D, H, W, C), dtype=BF16, device=x.device)
+    nblk = lib().gfe_conv3d_c1_k3_nblk(B, D, H, W)
+    ws = torch.empty((B, nblk, 2, C), dtype=torch.float32, device=x.device)
+    call("gfe_conv3d_c1_k3", ptr(x), ptr(weff), ptr(tab), ptr(y), ptr(ws), nblk, B, D, H, W, C, dtype_code(x.dtype), int(relu), stream())
+    y.gn_partials = ws
+    return y
+
+
 def maxpool2(x):
     B, D, H, W, C = x.shape
     y = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=BF16, device=x.device)

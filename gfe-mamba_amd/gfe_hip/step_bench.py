@@ -56,7 +56,8 @@ class StepWorkload:
         with torch.no_grad():
             r = blk.lift(x)
             conv = blk.conv2
-            w32, g, b = conv._pack.get([conv.conv.weight, conv.groupnorm.weight, conv.groupnorm.bias], lambda: None)
+            w32 = K.pack_conv3(conv.conv.weight, torch.float32)
+            g, b = conv.groupnorm.weight.detach().float().contiguous(), conv.groupnorm.bias.detach().float().contiguous()
             ss = K.groupnorm_scale_shift(r, g, b, 8)
             w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, 64, 64)
             out = K.conv_igemm(r, w, K.CONV3_TAPS, 64, bias_tab=tab, relu=True)

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 17
+#define GFE_ABI_VERSION 18
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -286,6 +286,16 @@ int gfe_transpose_f32_to_bf16(const float* in, void* out, int64_t batch, int64_t
 /* The same data laid out for the K/V weight gradient: out[r][b*per_batch_cols + col_off + c] (bf16, row stride ldo) = in[b][r][c]. */
 int gfe_interleave_rows_bf16(const float* in, void* out, int64_t B, int64_t R, int64_t Cc, int64_t ldo, int64_t per_batch_cols,
                              int64_t col_off, void* stream);
+
+/* 3x3x3 convolution (zero padding 1) of a ONE-channel volume with per-sample weights, + boundary-class bias table + optional ReLU, and
+ * the GroupNorm partials of the result: what ResNetBlock.conv2(GroupNorm(conv1(x))) collapses to when conv1 is a 1x1x1 lift of a
+ * single-channel input (pytorch3dunet/unet3d/buildingblocks.py:191-229, first encoder; the algebra is in csrc/unet_ops.hip).
+ *   x: (B, D, H, W) f32|bf16; weff: (B, 27, C) f32, tap order (kd, kh, kw) with offsets k - 1; bias_tab: (B, 64, C) f32 indexed by the
+ *   voxel's boundary class as in gfe_conv3d_igemm; y: (B, D, H, W, C) bf16; stats_ws: (B, nblk, 2, C) f32 with
+ *   nblk = gfe_conv3d_c1_k3_nblk(B, D, H, W), every slot written (8-channel sums like gfe_conv3d_igemm).  C must be 64. */
+int gfe_conv3d_c1_k3_nblk(int64_t B, int64_t D, int64_t H, int64_t W);
+int gfe_conv3d_c1_k3(const void* x, const float* weff, const float* bias_tab, void* y, float* stats_ws, int64_t stats_nblk,
+                     int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int in_dtype, int relu, void* stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------------
  * adaptive_normal (utils/data_normalization.py:20-48, applied per volume at dataloader/pic_table_loader.py:107): lo / hi = the order

@@ -318,3 +318,38 @@ def test_resident_transposed_conv_ragged_shapes(shape, full, monkeypatch):
     s1, t1 = K.groupnorm_scale_shift(y, gamma, beta, 8)
     s0, t0 = K.groupnorm_scale_shift(y.clone(), gamma, beta, 8)
     assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 24), (1, 13, 9, 20), (1, 8, 8, 8), (1, 3, 5, 2)])
+def test_first_block_collapsed_conv2_matches_the_mfma_path(shape):
+    """The first ResNetBlock (one-channel input, 64 features): conv2(GroupNorm(conv1(x))) computed as a one-channel 27-tap convolution
+    of x with per-sample effective weights (gfe_conv3d_c1_k3) against (a) the same block through the generic GroupNorm-folded MFMA
+    conv and (b) torch fp32 (buildingblocks.py:191-229), on ragged sizes; and the GroupNorm partials it hands to conv3."""
+    from gfe_hip import nn_ops as K
+    from pytorch3dunet.unet3d.buildingblocks import ResNetBlock
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 31 + W)
+    blk = ResNetBlock(1, 64).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() == 1 else 1.0 / max(1, p[0].numel()) ** 0.5))
+        blk.conv2.groupnorm.weight.add_(1.0); blk.conv3.groupnorm.weight.add_(1.0)
+    x = torch.randn(B, 1, D, H, W, generator=g).to(DEV)
+    with torch.no_grad():
+        r = blk.lift(x)
+        o_fast = blk._conv2_of_lifted_volume(x, r)
+        o_mfma = blk.conv2(r, stats=True)
+        out = blk(x)
+        # torch fp32 reference of the whole block
+        xr = F.conv3d(x, blk.conv1.weight, blk.conv1.bias)
+        t = F.relu(F.conv3d(F.group_norm(xr, 8, blk.conv2.groupnorm.weight, blk.conv2.groupnorm.bias, 1e-5), blk.conv2.conv.weight, padding=1))
+        ref2 = t.permute(0, 2, 3, 4, 1)
+        t = F.conv3d(F.group_norm(t, 8, blk.conv3.groupnorm.weight, blk.conv3.groupnorm.bias, 1e-5), blk.conv3.conv.weight, padding=1)
+        ref = F.relu(t + xr).permute(0, 2, 3, 4, 1)
+    assert rel_err(o_fast, ref2) < 1e-2 and rel_err(o_mfma, ref2) < 2e-2
+    assert rel_err(o_fast, ref2) <= rel_err(o_mfma, ref2) + 2e-3            # computed from the unrounded lift: no worse than the bf16 path
+    assert rel_err(out, ref) < 2e-2
+    gamma, beta = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    s1, t1 = K.groupnorm_scale_shift(o_fast, gamma, beta, 8)
+    s0, t0 = K.groupnorm_scale_shift(o_fast.clone(), gamma, beta, 8)
+    assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
