@@ -9,6 +9,7 @@ libgfe_hip.so on channels-last bf16 activations (B, D, H, W, C).  Inference only
 classify_mamba.py:53,100).
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from gfe_hip import nn_ops as K
@@ -103,12 +104,36 @@ class ResNetBlock(nn.Module):
         weff, tab = K.conv_c1_k3_tables(w_oct, scale, shift, w1, b1)
         return K.conv_c1_k3(x, weff, tab, relu=sc.relu)
 
+    def _conv2_through_lift(self, x, r):
+        """conv2(GroupNorm(conv1(x))) for a multi-channel x: conv1 is a 1x1x1 linear map Cin -> C (C = 2 Cin in the encoders) and
+        GroupNorm is affine per (sample, channel), so the C -> C convolution equals a Cin -> C convolution of x itself with per-sample
+        weights W_eff[o][tap][i] = sum_c W2[o][c][tap] s_c W1[c][i] (a 0.06 GFLOP matrix product per sample) and the boundary-class
+        bias table of s_c b1_c + t_c: HALF the MFMA work and half the activation staging of conv2 (the encoders' 64 -> 128 and
+        128 -> 256 levels)."""
+        c1, sc = self.conv1, self.conv2
+        gn, conv = sc.groupnorm, sc.conv
+        cin, c, cout = c1.in_channels, c1.out_channels, conv.out_channels
+        w32, w2m, w1, b1, g, b = self._pack2.get(
+            [conv.weight, c1.weight, c1.bias, gn.weight, gn.bias],
+            lambda: (lambda wp: (wp, wp.permute(1, 2, 0, 3).reshape(27 * wp.shape[2], -1)[:, :c].contiguous(),
+                                 _f32(c1.weight).view(c, cin), _f32(c1.bias), _f32(gn.weight), _f32(gn.bias)))(K.pack_conv3(conv.weight, torch.float32)))
+        scale, shift = K.groupnorm_scale_shift(r, g, b, gn.num_groups, gn.eps)                 # (B, C) from r's partials
+        B, cp, nslab = scale.shape[0], w32.shape[2], (cin + 31) // 32
+        weff = torch.matmul(w2m.unsqueeze(0) * scale.unsqueeze(1), w1)                          # (B, 27*cp, Cin)
+        if cin % 32:
+            weff = F.pad(weff, (0, nslab * 32 - cin))
+        weff = weff.view(B, 27, cp, nslab, 32).permute(0, 3, 1, 2, 4).contiguous().to(K.BF16)  # per-sample packed weights
+        _, tab = K.fold_groupnorm(w32, scale, scale * b1 + shift, K.CONV3_TAPS, c, cout)       # only the bias table is used
+        return K.conv_igemm(x, weff, K.CONV3_TAPS, cout, bias_tab=tab, relu=sc.relu, stats=True)
+
     def forward(self, x):
         r = self.lift(x)                                  # r and o carry their GroupNorm partials (written by the producing kernel)
         c1 = self.conv1
-        if (not isinstance(c1, nn.Identity) and c1.in_channels == 1 and c1.out_channels == 64 and x.dim() == 5 and x.shape[1] == 1
-                and getattr(r, "gn_partials", None) is not None):
+        lifted = not isinstance(c1, nn.Identity) and getattr(r, "gn_partials", None) is not None
+        if lifted and c1.in_channels == 1 and c1.out_channels == 64 and x.dim() == 5 and x.shape[1] == 1:
             o = self._conv2_of_lifted_volume(x, r)
+        elif lifted and c1.in_channels >= 32 and c1.in_channels % 8 == 0 and x.dim() == 5 and x.shape[-1] == c1.in_channels:
+            o = self._conv2_through_lift(x, r)
         else:
             o = self.conv2(r, stats=True)
         return self.conv3(o, residual=r)

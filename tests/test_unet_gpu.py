@@ -353,3 +353,32 @@ def test_first_block_collapsed_conv2_matches_the_mfma_path(shape):
     s1, t1 = K.groupnorm_scale_shift(o_fast, gamma, beta, 8)
     s0, t0 = K.groupnorm_scale_shift(o_fast.clone(), gamma, beta, 8)
     assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
+
+
+@pytest.mark.parametrize("cin,shape", [(64, (2, 8, 16, 12)), (128, (1, 6, 8, 8)), (64, (1, 5, 9, 7))])
+def test_encoder_block_conv2_through_the_lift_matches_torch(cin, shape):
+    """ResNetBlock(Cin -> 2 Cin): conv2(GroupNorm(conv1(x))) computed as a Cin -> 2 Cin convolution of x with per-sample effective
+    weights (half the MFMA work) against the generic path through r and torch fp32 (buildingblocks.py:191-229)."""
+    from pytorch3dunet.unet3d.buildingblocks import ResNetBlock
+    B, D, H, W = shape
+    c = 2 * cin
+    g = torch.Generator().manual_seed(cin + D)
+    blk = ResNetBlock(cin, c).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() == 1 else 1.0 / max(1, p[0].numel()) ** 0.5))
+        blk.conv2.groupnorm.weight.add_(1.0); blk.conv3.groupnorm.weight.add_(1.0)
+    x = torch.randn(B, D, H, W, cin, generator=g).to(BF).to(DEV)
+    with torch.no_grad():
+        r = blk.lift(x)
+        o_fast = blk._conv2_through_lift(x, r)
+        o_slow = blk.conv2(r, stats=True)
+        out = blk(x)
+        xn = x.float().permute(0, 4, 1, 2, 3)
+        xr = F.conv3d(xn, blk.conv1.weight, blk.conv1.bias)
+        t = F.relu(F.conv3d(F.group_norm(xr, 8, blk.conv2.groupnorm.weight, blk.conv2.groupnorm.bias, 1e-5), blk.conv2.conv.weight, padding=1))
+        ref2 = t.permute(0, 2, 3, 4, 1)
+        t = F.conv3d(F.group_norm(t, 8, blk.conv3.groupnorm.weight, blk.conv3.groupnorm.bias, 1e-5), blk.conv3.conv.weight, padding=1)
+        ref = F.relu(t + xr).permute(0, 2, 3, 4, 1)
+    assert rel_err(o_fast, ref2) < 2e-2 and rel_err(o_slow, ref2) < 2e-2
+    assert rel_err(out, ref) < 2e-2
