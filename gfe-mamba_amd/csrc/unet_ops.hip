@@ -240,24 +240,29 @@ static unsigned grid_for(int64_t total) {
 //     y_o(v) = sum_tap Weff[o][tap] x(v + tap) + sum_{tap inside} Beff[o][tap],   Weff = sum_c W[o][c][tap] s_c w1_c,
 //     Beff = sum_c W[o][c][tap] (s_c b1_c + t_c)   (the second term is the usual boundary-class bias table: the reference pads x_hat
 //     with zeros AFTER the norm).  196 GFLOP per volume become 0.24, and the kernel is bound by writing y.
-// One block = 8x8x8 voxels, one thread per voxel: 27 neighbours from an LDS halo tile, 64 accumulators, weights as LDS broadcasts.
+// One block = 8x8x8 voxels, 256 threads, a thread owns TWO voxels (planes z and z + 4) x 64 accumulators.  The weights are LDS
+// broadcasts (a float4 read costs a full LDS pass even when every lane reads the same address -- with one voxel per thread the kernel
+// was bound by exactly those reads, 0.73 ms at 96^3, B=8); each read now serves two voxels.  The tap loop is a real loop (the x
+// neighbours come from the LDS halo tile per tap, not from 54 registers), which also keeps LLVM from hoisting a tile's 432 weight reads.
 // Also writes the GroupNorm partials of y (8-channel sums, slot = block) for the next SingleConv.
 typedef __attribute__((ext_vector_type(2))) __bf16 c1_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float c1_f32x2;
 template <typename TI>
-__global__ __launch_bounds__(512) void conv3d_c1_k3_kernel(const TI* __restrict__ x, const float* __restrict__ weff, const float* __restrict__ tab,
+__global__ __launch_bounds__(256) void conv3d_c1_k3_kernel(const TI* __restrict__ x, const float* __restrict__ weff, const float* __restrict__ tab,
                                                            bf16_t* __restrict__ y, float* __restrict__ ws, int nblk, int D, int H, int W, int relu) {
     constexpr int C = 64;
     __shared__ float xt[10 * 10 * 10];
     __shared__ __attribute__((aligned(16))) float wl[27 * C];
     __shared__ __attribute__((aligned(16))) float tab0[C];
-    __shared__ float red[8 * 16];
+    __shared__ float red[4 * 16];
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntd = (D + 7) >> 3, nth = (H + 7) >> 3, ntw = (W + 7) >> 3, ntiles = ntd * nth * ntw;
     const int per = (ntiles + nblk - 1) / nblk, t_begin = blk * per, t_end = min(ntiles, t_begin + per);
     const size_t S = (size_t)D * H * W;
-    for (int i = tid; i < 27 * C; i += 512) wl[i] = weff[(size_t)b * 27 * C + i];
+    for (int i = tid; i < 27 * C; i += 256) wl[i] = weff[(size_t)b * 27 * C + i];
     if (tid < C) tab0[tid] = tab[(size_t)b * 64 * C + tid];
     const int lz = tid >> 6, ly = (tid >> 3) & 7, lx = tid & 7;
+    const int xbase = (lz * 10 + ly) * 10 + lx;                // halo index of the (-1,-1,-1) neighbour of voxel 0; voxel 1 is 400 further
     float gs[8], gq[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
@@ -265,51 +270,63 @@ __global__ __launch_bounds__(512) void conv3d_c1_k3_kernel(const TI* __restrict_
         const int tw = t % ntw, th = (t / ntw) % nth, td = t / (ntw * nth);
         const int d0 = td * 8, h0 = th * 8, w0 = tw * 8;
         __syncthreads();                                        // (previous tile's readers are done; first pass: wl / tab0 visible)
-        for (int i = tid; i < 1000; i += 512) {
+        for (int i = tid; i < 1000; i += 256) {
             const int hz = i / 100, hy = (i / 10) % 10, hx = i % 10;
             const int gd = d0 + hz - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
             xt[i] = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
                         ? IO<TI>::ld(x + (size_t)b * S + ((size_t)gd * H + gh) * W + gw) : 0.f;
         }
         __syncthreads();
-        const int gd = d0 + lz, gh = h0 + ly, gw = w0 + lx;
-        if (gd < D && gh < H && gw < W) {
-            float xv[27];
+        const int gh = h0 + ly, gw = w0 + lx;
+        if (d0 + lz < D && gh < H && gw < W) {
+            const int hw_cls = ((gh == 0) << 2) | ((gh == H - 1) << 3) | ((gw == 0) << 4) | ((gw == W - 1) << 5);
+            c1_f32x2 acc[2][C / 2];                              // packed pairs: v_pk_fma_f32
 #pragma unroll
-            for (int k = 0; k < 27; ++k) xv[k] = xt[((lz + k / 9) * 10 + (ly + (k / 3) % 3)) * 10 + lx + k % 3];
-            const int cls = (gd == 0) | ((gd == D - 1) << 1) | ((gh == 0) << 2) | ((gh == H - 1) << 3) | ((gw == 0) << 4) | ((gw == W - 1) << 5);
-            float acc[C];
-            const float4* br = cls == 0 ? reinterpret_cast<const float4*>(tab0) : reinterpret_cast<const float4*>(tab + ((size_t)b * 64 + cls) * C);
+            for (int v = 0; v < 2; ++v) {
+                const int gd = d0 + lz + 4 * v;
+                const int cls = hw_cls | (gd == 0) | ((gd == D - 1) << 1);
+                const float4* br = (cls == 0 || gd >= D) ? reinterpret_cast<const float4*>(tab0) : reinterpret_cast<const float4*>(tab + ((size_t)b * 64 + cls) * C);
 #pragma unroll
-            for (int c4 = 0; c4 < C / 4; ++c4) { const float4 v = br[c4]; acc[4 * c4] = v.x; acc[4 * c4 + 1] = v.y; acc[4 * c4 + 2] = v.z; acc[4 * c4 + 3] = v.w; }
-#pragma unroll
+                for (int c4 = 0; c4 < C / 4; ++c4) { const float4 bv = br[c4]; acc[v][2 * c4] = c1_f32x2{bv.x, bv.y}; acc[v][2 * c4 + 1] = c1_f32x2{bv.z, bv.w}; }
+            }
+#pragma unroll 1
             for (int k = 0; k < 27; ++k) {
+                const int kd = k / 9, kr = k - kd * 9, kh = kr / 3, kw = kr - kh * 3;
+                const int xo = xbase + (kd * 10 + kh) * 10 + kw;
+                const float xs0 = xt[xo], xs1 = xt[xo + 400];
+                const c1_f32x2 x0 = c1_f32x2{xs0, xs0}, x1 = c1_f32x2{xs1, xs1};
                 const float4* wr = reinterpret_cast<const float4*>(wl + k * C);
 #pragma unroll
                 for (int c4 = 0; c4 < C / 4; ++c4) {
-                    const float4 wv = wr[c4];                   // same address in every lane: an LDS broadcast
-                    acc[4 * c4] = fmaf(wv.x, xv[k], acc[4 * c4]); acc[4 * c4 + 1] = fmaf(wv.y, xv[k], acc[4 * c4 + 1]);
-                    acc[4 * c4 + 2] = fmaf(wv.z, xv[k], acc[4 * c4 + 2]); acc[4 * c4 + 3] = fmaf(wv.w, xv[k], acc[4 * c4 + 3]);
+                    const float4 wv = wr[c4];                   // same address in every lane: an LDS broadcast, used for both voxels
+                    const c1_f32x2 wa = c1_f32x2{wv.x, wv.y}, wb = c1_f32x2{wv.z, wv.w};
+                    acc[0][2 * c4] = wa * x0 + acc[0][2 * c4]; acc[0][2 * c4 + 1] = wb * x0 + acc[0][2 * c4 + 1];
+                    acc[1][2 * c4] = wa * x1 + acc[1][2 * c4]; acc[1][2 * c4 + 1] = wb * x1 + acc[1][2 * c4 + 1];
                 }
             }
-            bf16_t* yo = y + ((size_t)b * S + ((size_t)gd * H + gh) * W + gw) * C;
 #pragma unroll
-            for (int o8 = 0; o8 < 8; ++o8) {
-                uint32_t pk[4];
+            for (int v = 0; v < 2; ++v) {
+                const int gd = d0 + lz + 4 * v;
+                if (gd >= D) continue;
+                bf16_t* yo = y + ((size_t)b * S + ((size_t)gd * H + gh) * W + gw) * C;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a0 = acc[8 * o8 + 2 * j], a1 = acc[8 * o8 + 2 * j + 1];
-                    if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
-                    pk[j] = pack_bf16x2(a0, a1);
-                    const c1_bf16x2 v = __builtin_bit_cast(c1_bf16x2, pk[j]);
-                    gs[o8] = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(c1_bf16x2, 0x3f803f80u), gs[o8], false);
-                    gq[o8] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[o8], false);
+                for (int o8 = 0; o8 < 8; ++o8) {
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float a0 = acc[v][4 * o8 + j][0], a1 = acc[v][4 * o8 + j][1];
+                        if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+                        pk[j] = pack_bf16x2(a0, a1);
+                        const c1_bf16x2 pv = __builtin_bit_cast(c1_bf16x2, pk[j]);
+                        gs[o8] = __builtin_amdgcn_fdot2_f32_bf16(pv, __builtin_bit_cast(c1_bf16x2, 0x3f803f80u), gs[o8], false);
+                        gq[o8] = __builtin_amdgcn_fdot2_f32_bf16(pv, pv, gq[o8], false);
+                    }
+                    reinterpret_cast<uint4*>(yo)[o8] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
-                reinterpret_cast<uint4*>(yo)[o8] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
         }
     }
-    // GroupNorm partials of what this block stored: per 8-channel octet, wave reduction then the 8 waves through LDS (fixed order)
+    // GroupNorm partials of what this block stored: per 8-channel octet, wave reduction then the 4 waves through LDS (fixed order)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float s_ = gs[i], q_ = gq[i];
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(512) void conv3d_c1_k3_kernel(const TI* __restrict_
     if (tid < 2 * C) {
         const int st = tid >> 6, c = tid & 63;
         float v = 0.f;                    // the 8-channel sum goes to the first channel of the octet, zeros to the other seven
-        if ((c & 7) == 0) for (int wv_ = 0; wv_ < 8; ++wv_) v += red[wv_ * 16 + st * 8 + (c >> 3)];
+        if ((c & 7) == 0) for (int wv_ = 0; wv_ < 4; ++wv_) v += red[wv_ * 16 + st * 8 + (c >> 3)];
         ws[(((size_t)b * nblk + blk) * 2 + st) * C + c] = v;
     }
 }
@@ -386,7 +403,7 @@ int gfe_conv_in1_stats(const void* x, const float* w, const float* bias, void* y
 
 int gfe_conv3d_c1_k3_nblk(int64_t B, int64_t D, int64_t H, int64_t W) {
     const int64_t tiles = ceil_div(D, 8) * ceil_div(H, 8) * ceil_div(W, 8);
-    const int64_t want = B > 0 ? (256 + B - 1) / B : 1;           // ~256 blocks in all
+    const int64_t want = B > 0 ? (512 + B - 1) / B : 1;           // ~512 four-wave blocks in all
     return (int)(tiles < want ? tiles : want);
 }
 
@@ -398,9 +415,9 @@ int gfe_conv3d_c1_k3(const void* x, const float* weff, const float* bias_tab, vo
     GFE_REQUIRE(stats_nblk == nblk, GFE_ERR_SHAPE);
     const dim3 grid((unsigned)nblk, (unsigned)B);
     if (in_dtype == GFE_F32)
-        hipLaunchKernelGGL((conv3d_c1_k3_kernel<float>), grid, dim3(512), 0, (hipStream_t)stream, (const float*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
+        hipLaunchKernelGGL((conv3d_c1_k3_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
     else if (in_dtype == GFE_BF16)
-        hipLaunchKernelGGL((conv3d_c1_k3_kernel<bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
+        hipLaunchKernelGGL((conv3d_c1_k3_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
     else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }
