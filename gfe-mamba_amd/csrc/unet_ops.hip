@@ -240,10 +240,11 @@ static unsigned grid_for(int64_t total) {
 //     y_o(v) = sum_tap Weff[o][tap] x(v + tap) + sum_{tap inside} Beff[o][tap],   Weff = sum_c W[o][c][tap] s_c w1_c,
 //     Beff = sum_c W[o][c][tap] (s_c b1_c + t_c)   (the second term is the usual boundary-class bias table: the reference pads x_hat
 //     with zeros AFTER the norm).  196 GFLOP per volume become 0.24, and the kernel is bound by writing y.
-// One block = 8x8x8 voxels, 256 threads, a thread owns TWO voxels (planes z and z + 4) x 64 accumulators.  The weights are LDS
-// broadcasts (a float4 read costs a full LDS pass even when every lane reads the same address -- with one voxel per thread the kernel
-// was bound by exactly those reads, 0.73 ms at 96^3, B=8); each read now serves two voxels.  The tap loop is a real loop (the x
-// neighbours come from the LDS halo tile per tap, not from 54 registers), which also keeps LLVM from hoisting a tile's 432 weight reads.
+// One block = 8x8x8 voxels, 256 threads, a thread owns TWO voxels (planes z and z + 4) x 64 packed-f32 accumulators.  The per-sample
+// weights are read with wave-uniform addresses, i.e. as scalar loads into SGPR operands of v_pk_fma_f32 (staged in LDS they cost a
+// full LDS pass per float4 even as broadcasts: 0.73 ms with one voxel per thread, 0.56 with two, 0.51 like this); the x neighbours
+// come from an LDS halo tile per tap (a rolled tap loop: the unrolled forms spill catastrophically), and the next tile's halo is
+// fetched into registers while the current tile is computed.
 // Also writes the GroupNorm partials of y (8-channel sums, slot = block) for the next SingleConv.
 typedef __attribute__((ext_vector_type(2))) __bf16 c1_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float c1_f32x2;
@@ -252,31 +253,42 @@ __global__ __launch_bounds__(256) void conv3d_c1_k3_kernel(const TI* __restrict_
                                                            bf16_t* __restrict__ y, float* __restrict__ ws, int nblk, int D, int H, int W, int relu) {
     constexpr int C = 64;
     __shared__ float xt[10 * 10 * 10];
-    __shared__ __attribute__((aligned(16))) float wl[27 * C];
     __shared__ __attribute__((aligned(16))) float tab0[C];
     __shared__ float red[4 * 16];
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntd = (D + 7) >> 3, nth = (H + 7) >> 3, ntw = (W + 7) >> 3, ntiles = ntd * nth * ntw;
     const int per = (ntiles + nblk - 1) / nblk, t_begin = blk * per, t_end = min(ntiles, t_begin + per);
     const size_t S = (size_t)D * H * W;
-    for (int i = tid; i < 27 * C; i += 256) wl[i] = weff[(size_t)b * 27 * C + i];
     if (tid < C) tab0[tid] = tab[(size_t)b * 64 * C + tid];
     const int lz = tid >> 6, ly = (tid >> 3) & 7, lx = tid & 7;
     const int xbase = (lz * 10 + ly) * 10 + lx;                // halo index of the (-1,-1,-1) neighbour of voxel 0; voxel 1 is 400 further
     float gs[8], gq[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+    // the halo tile of the NEXT tile is fetched into registers before the current tile is computed (4 values per thread), so its
+    // global-memory latency is not exposed between the two barriers
+    float pre[4];
+    auto fetch = [&](int t) {
+        const int tw = t % ntw, th = (t / ntw) % nth, td = t / (ntw * nth);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            const int hz = i / 100, hy = (i / 10) % 10, hx = i % 10;
+            const int gd = td * 8 + hz - 1, gh = th * 8 + hy - 1, gw = tw * 8 + hx - 1;
+            pre[j] = (i < 1000 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+                         ? IO<TI>::ld(x + (size_t)b * S + ((size_t)gd * H + gh) * W + gw) : 0.f;
+        }
+    };
+    if (t_begin < t_end) fetch(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
         const int tw = t % ntw, th = (t / ntw) % nth, td = t / (ntw * nth);
         const int d0 = td * 8, h0 = th * 8, w0 = tw * 8;
-        __syncthreads();                                        // (previous tile's readers are done; first pass: wl / tab0 visible)
-        for (int i = tid; i < 1000; i += 256) {
-            const int hz = i / 100, hy = (i / 10) % 10, hx = i % 10;
-            const int gd = d0 + hz - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
-            xt[i] = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-                        ? IO<TI>::ld(x + (size_t)b * S + ((size_t)gd * H + gh) * W + gw) : 0.f;
-        }
+        __syncthreads();                                        // (previous tile's readers are done; first pass: tab0 visible)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (tid + 256 * j < 1000) xt[tid + 256 * j] = pre[j];
         __syncthreads();
+        if (t + 1 < t_end) fetch(t + 1);
         const int gh = h0 + ly, gw = w0 + lx;
         if (d0 + lz < D && gh < H && gw < W) {
             const int hw_cls = ((gh == 0) << 2) | ((gh == H - 1) << 3) | ((gw == 0) << 4) | ((gw == W - 1) << 5);
@@ -289,13 +301,14 @@ __global__ __launch_bounds__(256) void conv3d_c1_k3_kernel(const TI* __restrict_
 #pragma unroll
                 for (int c4 = 0; c4 < C / 4; ++c4) { const float4 bv = br[c4]; acc[v][2 * c4] = c1_f32x2{bv.x, bv.y}; acc[v][2 * c4 + 1] = c1_f32x2{bv.z, bv.w}; }
             }
-#pragma unroll 1
+            const float* wsm = weff + (size_t)b * 27 * C;       // wave-uniform address: scalar loads, the weights are SGPR operands of the fma
+#pragma unroll 3
             for (int k = 0; k < 27; ++k) {
                 const int kd = k / 9, kr = k - kd * 9, kh = kr / 3, kw = kr - kh * 3;
                 const int xo = xbase + (kd * 10 + kh) * 10 + kw;
                 const float xs0 = xt[xo], xs1 = xt[xo + 400];
                 const c1_f32x2 x0 = c1_f32x2{xs0, xs0}, x1 = c1_f32x2{xs1, xs1};
-                const float4* wr = reinterpret_cast<const float4*>(wl + k * C);
+                const float4* wr = reinterpret_cast<const float4*>(wsm + k * C);
 #pragma unroll
                 for (int c4 = 0; c4 < C / 4; ++c4) {
                     const float4 wv = wr[c4];                   // same address in every lane: an LDS broadcast, used for both voxels
