@@ -416,7 +416,7 @@ int gfe_conv_in1_stats(const void* x, const float* w, const float* bias, void* y
 
 int gfe_conv3d_c1_k3_nblk(int64_t B, int64_t D, int64_t H, int64_t W) {
     const int64_t tiles = ceil_div(D, 8) * ceil_div(H, 8) * ceil_div(W, 8);
-    const int64_t want = B > 0 ? (512 + B - 1) / B : 1;           // ~512 four-wave blocks in all
+    const int64_t want = B > 0 ? (768 + B - 1) / B : 1;           // ~768 four-wave blocks in all (3 per CU: 165 VGPRs)
     return (int)(tiles < want ? tiles : want);
 }
 
