@@ -356,6 +356,61 @@ __global__ __launch_bounds__(256) void conv3d_c1_k3_kernel(const TI* __restrict_
     }
 }
 
+
+// ---- GroupNorm affine of a 1x1x1 lift of a one-channel volume, without materialising the lift ---------------------------------
+// r_c = w_c x + b_c per voxel, so the per-(sample, group) statistics GroupNorm needs follow from the first two moments of x:
+//   E[r_c] = w_c E[x] + b_c,   E[r_c^2] = w_c^2 E[x^2] + 2 w_c b_c E[x] + b_c^2,   averaged over the group's channels.
+__global__ __launch_bounds__(256) void vol_moments_kernel(const float* __restrict__ x, double* __restrict__ part, int64_t S, int nblk) {
+    __shared__ double rs[4], rq[4];
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (size_t)b * S;
+    double s = 0.0, q = 0.0;
+    const int64_t n4 = ((uintptr_t)xb % 16 == 0) ? S / 4 : 0;
+    for (int64_t i = (int64_t)blk * 256 + tid; i < n4; i += (int64_t)nblk * 256) {
+        const float4 v = reinterpret_cast<const float4*>(xb)[i];
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blk * 256 + tid; i < S; i += (int64_t)nblk * 256) { const double v = xb[i]; s += v; q += v * v; }
+    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
+    if ((tid & 63) == 0) { rs[tid >> 6] = s; rq[tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) { part[((size_t)b * nblk + blk) * 2] = rs[0] + rs[1] + rs[2] + rs[3]; part[((size_t)b * nblk + blk) * 2 + 1] = rq[0] + rq[1] + rq[2] + rq[3]; }
+}
+__global__ __launch_bounds__(256) void lift_gn_affine_kernel(const double* __restrict__ part, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                                                             float* __restrict__ shift, int64_t S, int C, int G, int nblk, float eps) {
+    __shared__ double mom[2];
+    __shared__ double gm[2 * 256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nblk; ++k) { s += part[((size_t)b * nblk + k) * 2]; q += part[((size_t)b * nblk + k) * 2 + 1]; }
+        mom[0] = s / (double)S; mom[1] = q / (double)S;
+    }
+    __syncthreads();
+    const int cg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        double m1 = 0.0, m2 = 0.0;
+        for (int j = 0; j < cg; ++j) {
+            const double wc = w[g * cg + j], bc = bias[g * cg + j];
+            m1 += wc * mom[0] + bc;
+            m2 += wc * wc * mom[1] + 2.0 * wc * bc * mom[0] + bc * bc;
+        }
+        m1 /= cg; m2 /= cg;
+        double var = m2 - m1 * m1;                 // biased variance, as nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        gm[g] = m1; gm[G + g] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cg;
+        const float sc = (float)gm[G + g] * gamma[c];
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = beta[c] - (float)gm[g] * sc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -432,6 +487,17 @@ int gfe_conv3d_c1_k3(const void* x, const float* weff, const float* bias_tab, vo
     else if (in_dtype == GFE_BF16)
         hipLaunchKernelGGL((conv3d_c1_k3_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
     else return GFE_ERR_DTYPE;
+    return gfe_launch_status();
+}
+
+int gfe_lift_groupnorm_affine(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                              float* scale, float* shift, double* ws, int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream) {
+    GFE_REQUIRE(x && w && bias && gamma && beta && scale && shift && ws, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && S > 0 && C > 0 && G > 0 && G <= 256 && C % G == 0, GFE_ERR_SHAPE);
+    const int nblk = 64;                                           // ws: B * 64 * 2 doubles
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vol_moments_kernel, dim3(nblk, (unsigned)B), dim3(256), 0, st, x, ws, S, nblk);
+    hipLaunchKernelGGL(lift_gn_affine_kernel, dim3((unsigned)B), dim3(256), 0, st, ws, w, bias, gamma, beta, scale, shift, S, (int)C, (int)G, nblk, eps);
     return gfe_launch_status();
 }
 

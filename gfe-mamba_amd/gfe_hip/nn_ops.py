@@ -231,6 +231,29 @@ def conv_c1_k3_tables(w32_oct, scale, shift, w1, b1):
     return both[0].contiguous(), torch.matmul(m, both[1]).contiguous()
 
 
+def lift_groupnorm_affine(x, w1, b1, gamma, beta, groups, eps=1e-5):
+    """GroupNorm scale / shift (B, C) of r = w1 x + b1 for a one-channel volume x (B, 1, D, H, W) f32, from the moments of x."""
+    B = x.shape[0]
+    S = x.numel() // B
+    C = w1.numel()
+    ss = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(B * 128, dtype=torch.float64, device=x.device)
+    call("gfe_lift_groupnorm_affine", ptr(x), ptr(w1), ptr(b1), ptr(gamma), ptr(beta), ptr(ss[0]), ptr(ss[1]), ptr(ws), B, S, C, groups, eps, stream())
+    return ss[0], ss[1]
+
+
+def conv3_lift_residual(x, w_packed, tab, cout, vol, lift_w, lift_b, relu=True):
+    """27-tap conv of x (B, D, H, W, Cin) bf16 with per-sample folded weights + bias table, plus the residual w[c] * vol + b[c]
+    recomputed in the epilogue from the one-channel volume (gfe_conv3d_k3_lift_residual)."""
+    B, D, H, W, cin = x.shape
+    assert x.dtype == BF16 and x.is_contiguous() and vol.dtype == torch.float32 and vol.is_contiguous() and w_packed.dim() == 5
+    out = torch.empty((B, D, H, W, cout), dtype=BF16, device=x.device)
+    _, tptr = _i8(CONV3_TAPS)
+    call("gfe_conv3d_k3_lift_residual", ptr(x), ptr(w_packed), w_packed.stride(0), ptr(tab), ptr(out), B, D, H, W, cin, cout, tptr, int(relu),
+         ptr(vol), ptr(lift_w), ptr(lift_b), stream())
+    return out
+
+
 def conv_c1_k3(x, weff, tab, relu=True):
     """x: (B, 1, D, H, W) f32|bf16 -> (B, D, H, W, 64) bf16 with its GroupNorm partials attached (`y.gn_partials`)."""
     B, _, D, H, W = x.shape

@@ -91,18 +91,26 @@ class ResNetBlock(nn.Module):
         w, b = self._pack.get([c1.weight, c1.bias], lambda: (K.pack_conv1(c1.weight), _f32(c1.bias)))
         return K.conv_igemm(x, w, [(0, 0, 0)], c1.out_channels, bias=b, stats=True)
 
-    def _conv2_of_lifted_volume(self, x, r):
-        """conv2(GroupNorm(conv1(x))) for a ONE-channel x: GroupNorm is affine per (sample, channel) and conv1 is w1 x + b1, so the
-        64 -> 64 convolution is a one-channel 27-tap convolution of x with per-sample effective weights (gfe_conv3d_c1_k3): 0.2 ms
-        instead of the 1.5 ms MFMA conv at 96^3, and computed from the unrounded lift."""
-        c1, sc = self.conv1, self.conv2
-        gn = sc.groupnorm
-        w_oct, w1, b1 = self._pack2.get([sc.conv.weight, c1.weight, c1.bias],
-                                        lambda: (_f32(sc.conv.weight).reshape(sc.conv.out_channels, sc.conv.in_channels, 27).contiguous(),
-                                                 _f32(c1.weight).view(-1), _f32(c1.bias)))
-        scale, shift = K.groupnorm_scale_shift(r, _f32(gn.weight), _f32(gn.bias), gn.num_groups, gn.eps)      # from r's partials
+    def _first_block(self, x):
+        """The whole block for a ONE-channel x without ever materialising r = conv1(x) = w1 x + b1 (906 MB at 96^3, B=8):
+          * GroupNorm is affine per (sample, channel) and its statistics of r follow from the first two moments of x
+            (gfe_lift_groupnorm_affine);
+          * conv2(GroupNorm(r)) is then a one-channel 27-tap convolution of x with per-sample effective weights
+            (gfe_conv3d_c1_k3: 0.5 ms instead of the 1.5 ms MFMA conv, and computed from the unrounded lift);
+          * conv3's residual r is recomputed from x in the conv epilogue (gfe_conv3d_k3_lift_residual)."""
+        c1, sc2, sc3 = self.conv1, self.conv2, self.conv3
+        gn2, gn3, cv3 = sc2.groupnorm, sc3.groupnorm, sc3.conv
+        w_oct, w1, b1, g2, be2, w32_3, g3, be3 = self._pack2.get(
+            [sc2.conv.weight, c1.weight, c1.bias, gn2.weight, gn2.bias, cv3.weight, gn3.weight, gn3.bias],
+            lambda: (_f32(sc2.conv.weight).reshape(sc2.conv.out_channels, sc2.conv.in_channels, 27).contiguous(), _f32(c1.weight).view(-1),
+                     _f32(c1.bias), _f32(gn2.weight), _f32(gn2.bias), K.pack_conv3(cv3.weight, torch.float32), _f32(gn3.weight), _f32(gn3.bias)))
+        x = x.contiguous()
+        scale, shift = K.lift_groupnorm_affine(x, w1, b1, g2, be2, gn2.num_groups, gn2.eps)
         weff, tab = K.conv_c1_k3_tables(w_oct, scale, shift, w1, b1)
-        return K.conv_c1_k3(x, weff, tab, relu=sc.relu)
+        o = K.conv_c1_k3(x, weff, tab, relu=sc2.relu)                               # carries its GroupNorm partials
+        s3, t3 = K.groupnorm_scale_shift(o, g3, be3, gn3.num_groups, gn3.eps)
+        wb, tab3 = K.fold_groupnorm(w32_3, s3, t3, K.CONV3_TAPS, cv3.in_channels, cv3.out_channels)
+        return K.conv3_lift_residual(o, wb, tab3, cv3.out_channels, x, w1, b1, relu=True)      # relu(conv3 + r): buildingblocks.py:226-229
 
     def _conv2_through_lift(self, x, r):
         """conv2(GroupNorm(conv1(x))) for a multi-channel x: conv1 is a 1x1x1 linear map Cin -> C (C = 2 Cin in the encoders) and
@@ -127,12 +135,13 @@ class ResNetBlock(nn.Module):
         return K.conv_igemm(x, weff, K.CONV3_TAPS, cout, bias_tab=tab, relu=sc.relu, stats=True)
 
     def forward(self, x):
-        r = self.lift(x)                                  # r and o carry their GroupNorm partials (written by the producing kernel)
         c1 = self.conv1
+        if (not isinstance(c1, nn.Identity) and c1.in_channels == 1 and c1.out_channels == 64 and x.dim() == 5 and x.shape[1] == 1
+                and x.dtype == torch.float32 and self.conv3.conv.out_channels == 64):
+            return self._first_block(x)
+        r = self.lift(x)                                  # r and o carry their GroupNorm partials (written by the producing kernel)
         lifted = not isinstance(c1, nn.Identity) and getattr(r, "gn_partials", None) is not None
-        if lifted and c1.in_channels == 1 and c1.out_channels == 64 and x.dim() == 5 and x.shape[1] == 1:
-            o = self._conv2_of_lifted_volume(x, r)
-        elif lifted and c1.in_channels >= 32 and c1.in_channels % 8 == 0 and x.dim() == 5 and x.shape[-1] == c1.in_channels:
+        if lifted and c1.in_channels >= 32 and c1.in_channels % 8 == 0 and x.dim() == 5 and x.shape[-1] == c1.in_channels:
             o = self._conv2_through_lift(x, r)
         else:
             o = self.conv2(r, stats=True)

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 18
+#define GFE_ABI_VERSION 19
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -296,6 +296,17 @@ int gfe_interleave_rows_bf16(const float* in, void* out, int64_t B, int64_t R, i
 int gfe_conv3d_c1_k3_nblk(int64_t B, int64_t D, int64_t H, int64_t W);
 int gfe_conv3d_c1_k3(const void* x, const float* weff, const float* bias_tab, void* y, float* stats_ws, int64_t stats_nblk,
                      int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int in_dtype, int relu, void* stream);
+
+/* The first ResNetBlock without its lifted tensor r = conv1(x) (one-channel x):
+ *  - gfe_lift_groupnorm_affine: the GroupNorm(G groups) scale / shift (B, C) of r_c = w_c x + b_c from the first two moments of x
+ *    (x: (B, S) f32; ws: B * 128 doubles of scratch);
+ *  - gfe_conv3d_k3_lift_residual: gfe_conv3d_igemm for a stride-1 27-tap 64-channel conv (per-sample folded weights + bias table as
+ *    usual, no statistics) whose residual is r, recomputed in the epilogue from vol (B, D, H, W) f32 and the lift's lift_w / lift_b (64). */
+int gfe_lift_groupnorm_affine(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                              float* scale, float* shift, double* ws, int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream);
+int gfe_conv3d_k3_lift_residual(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, void* y,
+                                int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, const int8_t* tap_offsets, int relu,
+                                const float* vol, const float* lift_w, const float* lift_b, void* stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------------
  * adaptive_normal (utils/data_normalization.py:20-48, applied per volume at dataloader/pic_table_loader.py:107): lo / hi = the order

@@ -337,9 +337,15 @@ def test_first_block_collapsed_conv2_matches_the_mfma_path(shape):
     x = torch.randn(B, 1, D, H, W, generator=g).to(DEV)
     with torch.no_grad():
         r = blk.lift(x)
-        o_fast = blk._conv2_of_lifted_volume(x, r)
         o_mfma = blk.conv2(r, stats=True)
-        out = blk(x)
+        out_generic = blk.conv3(o_mfma, residual=r)         # the block through the lifted tensor and the generic MFMA convs
+        out = blk(x)                                        # the block as the product runs it (no lifted tensor at all)
+        gn2 = blk.conv2.groupnorm
+        s_a, t_a = K.lift_groupnorm_affine(x, blk.conv1.weight.view(-1).float(), blk.conv1.bias.float(), gn2.weight.float(), gn2.bias.float(), 8)
+        s_r, t_r = K.groupnorm_scale_shift(r.clone(), gn2.weight.float(), gn2.bias.float(), 8)
+        weff, tab = K.conv_c1_k3_tables(blk.conv2.conv.weight.float().reshape(64, 64, 27).contiguous(), s_a, t_a,
+                                        blk.conv1.weight.view(-1).float(), blk.conv1.bias.float())
+        o_fast = K.conv_c1_k3(x, weff, tab, relu=True)
         # torch fp32 reference of the whole block
         xr = F.conv3d(x, blk.conv1.weight, blk.conv1.bias)
         t = F.relu(F.conv3d(F.group_norm(xr, 8, blk.conv2.groupnorm.weight, blk.conv2.groupnorm.bias, 1e-5), blk.conv2.conv.weight, padding=1))
@@ -348,7 +354,8 @@ def test_first_block_collapsed_conv2_matches_the_mfma_path(shape):
         ref = F.relu(t + xr).permute(0, 2, 3, 4, 1)
     assert rel_err(o_fast, ref2) < 1e-2 and rel_err(o_mfma, ref2) < 2e-2
     assert rel_err(o_fast, ref2) <= rel_err(o_mfma, ref2) + 2e-3            # computed from the unrounded lift: no worse than the bf16 path
-    assert rel_err(out, ref) < 2e-2
+    assert rel_err(out, ref) < 2e-2 and rel_err(out_generic, ref) < 2e-2
+    assert rel_err(s_a, s_r) < 1e-2 and rel_err(t_a, t_r) < 1e-2       # analytic statistics vs statistics of the bf16-rounded lift
     gamma, beta = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
     s1, t1 = K.groupnorm_scale_shift(o_fast, gamma, beta, 8)
     s0, t0 = K.groupnorm_scale_shift(o_fast.clone(), gamma, beta, 8)
