@@ -240,39 +240,57 @@ static unsigned grid_for(int64_t total) {
 //     y_o(v) = sum_tap Weff[o][tap] x(v + tap) + sum_{tap inside} Beff[o][tap],   Weff = sum_c W[o][c][tap] s_c w1_c,
 //     Beff = sum_c W[o][c][tap] (s_c b1_c + t_c)   (the second term is the usual boundary-class bias table: the reference pads x_hat
 //     with zeros AFTER the norm).  196 GFLOP per volume become 0.24, and the kernel is bound by writing y.
-// One block = 8x8x8 voxels, 256 threads, a thread owns TWO voxels (planes z and z + 4) x 64 packed-f32 accumulators.  The per-sample
-// weights are read with wave-uniform addresses, i.e. as scalar loads into SGPR operands of v_pk_fma_f32 (staged in LDS they cost a
-// full LDS pass per float4 even as broadcasts: 0.73 ms with one voxel per thread, 0.56 with two, 0.51 like this); the x neighbours
-// come from an LDS halo tile per tap (a rolled tap loop: the unrolled forms spill catastrophically), and the next tile's halo is
-// fetched into registers while the current tile is computed.
-// Also writes the GroupNorm partials of y (8-channel sums, slot = block) for the next SingleConv.
+// It runs on the matrix cores: per 16 voxels the B operand is the voxels' 27 neighbours (padded to K = 32, gathered from an LDS halo
+// tile and rounded to bf16: 8 taps per lane), the A operand the sample's effective weights (64 channels x 32, bf16, loaded once per
+// block into registers with the same row permutation as the conv kernel, so a lane ends up with 16 consecutive channels of one voxel)
+// -- four v_mfma_f32_16x16x32_bf16 per 16 voxels, and the kernel is bound by writing y.  (A VALU formulation, one or two voxels per
+// thread x 64 f32 accumulators, took 0.73 / 0.51 ms at 96^3, B=8: LDS-broadcast- resp. scalar-load-bound.)
+// One block = 8 waves = the 8 d-planes of an 8x8x8 tile, 4 voxel tiles of 2 x 8 voxels per wave, as in conv3d.hip; the next tile's halo is
+// fetched into registers while the current one is computed.  Also writes the GroupNorm partials of y (8-channel sums, slot = block).
 typedef __attribute__((ext_vector_type(2))) __bf16 c1_bf16x2;
-typedef __attribute__((ext_vector_type(2))) float c1_f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 c1_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float c1_f32x4;
 template <typename TI>
-__global__ __launch_bounds__(256) void conv3d_c1_k3_kernel(const TI* __restrict__ x, const float* __restrict__ weff, const float* __restrict__ tab,
+__global__ __launch_bounds__(512) void conv3d_c1_k3_kernel(const TI* __restrict__ x, const float* __restrict__ weff, const float* __restrict__ tab,
                                                            bf16_t* __restrict__ y, float* __restrict__ ws, int nblk, int D, int H, int W, int relu) {
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int C = 64;
     __shared__ float xt[10 * 10 * 10];
     __shared__ __attribute__((aligned(16))) float tab0[C];
-    __shared__ float red[4 * 16];
+    __shared__ float red[8 * 16];
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
     const int ntd = (D + 7) >> 3, nth = (H + 7) >> 3, ntw = (W + 7) >> 3, ntiles = ntd * nth * ntw;
     const int per = (ntiles + nblk - 1) / nblk, t_begin = blk * per, t_end = min(ntiles, t_begin + per);
     const size_t S = (size_t)D * H * W;
     if (tid < C) tab0[tid] = tab[(size_t)b * 64 * C + tid];
-    const int lz = tid >> 6, ly = (tid >> 3) & 7, lx = tid & 7;
-    const int xbase = (lz * 10 + ly) * 10 + lx;                // halo index of the (-1,-1,-1) neighbour of voxel 0; voxel 1 is 400 further
-    float gs[8], gq[8];
+    // A operand: lane (lq, lr) holds k = 8 lq .. 8 lq + 7 (taps; 27..31 are zero) of MFMA row lr of channel tile ct, where row m stands
+    // for channel (m >> 2) * 16 + 4 ct + (m & 3) -- the output rows 4 lq + r of tile ct are then channels lq * 16 + 4 ct + r
+    c1_bf16x8 wfrag[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
-    // the halo tile of the NEXT tile is fetched into registers before the current tile is computed (4 values per thread), so its
-    // global-memory latency is not exposed between the two barriers
-    float pre[4];
+    for (int ct = 0; ct < 4; ++ct) {
+        const int ch = (lr >> 2) * 16 + 4 * ct + (lr & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 8 * lq + j;
+            wfrag[ct][j] = (__bf16)(t < 27 ? weff[((size_t)b * 27 + t) * C + ch] : 0.f);
+        }
+    }
+    // B operand gather: LDS offsets of this lane's 8 taps relative to a voxel's halo position (tap t -> (t/9, (t/3)%3, t%3))
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 8 * lq + j, tt = t < 27 ? t : 0;
+        toff[j] = ((tt / 9) * 10 + (tt / 3) % 3) * 10 + tt % 3;
+    }
+    const bool lastq = lq == 3;                                  // taps 27..31 do not exist: zeros (the weights there are zero as well)
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
+    float pre[2];
     auto fetch = [&](int t) {
         const int tw = t % ntw, th = (t / ntw) % nth, td = t / (ntw * nth);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 256 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 512 * j;
             const int hz = i / 100, hy = (i / 10) % 10, hx = i % 10;
             const int gd = td * 8 + hz - 1, gh = th * 8 + hy - 1, gw = tw * 8 + hx - 1;
             pre[j] = (i < 1000 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
@@ -285,77 +303,69 @@ __global__ __launch_bounds__(256) void conv3d_c1_k3_kernel(const TI* __restrict_
         const int d0 = td * 8, h0 = th * 8, w0 = tw * 8;
         __syncthreads();                                        // (previous tile's readers are done; first pass: tab0 visible)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (tid + 256 * j < 1000) xt[tid + 256 * j] = pre[j];
+        for (int j = 0; j < 2; ++j)
+            if (tid + 512 * j < 1000) xt[tid + 512 * j] = pre[j];
         __syncthreads();
         if (t + 1 < t_end) fetch(t + 1);
-        const int gh = h0 + ly, gw = w0 + lx;
-        if (d0 + lz < D && gh < H && gw < W) {
-            const int hw_cls = ((gh == 0) << 2) | ((gh == H - 1) << 3) | ((gw == 0) << 4) | ((gw == W - 1) << 5);
-            c1_f32x2 acc[2][C / 2];                              // packed pairs: v_pk_fma_f32
+        const int gd = d0 + wave;
+        if (gd >= D) continue;                                  // (no barrier below in this iteration)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int gd = d0 + lz + 4 * v;
-                const int cls = hw_cls | (gd == 0) | ((gd == D - 1) << 1);
-                const float4* br = (cls == 0 || gd >= D) ? reinterpret_cast<const float4*>(tab0) : reinterpret_cast<const float4*>(tab + ((size_t)b * 64 + cls) * C);
+        for (int xt_ = 0; xt_ < 4; ++xt_) {
+            const int ly = 2 * xt_ + (lr >> 3), lx = lr & 7;
+            const int vbase = (wave * 10 + ly) * 10 + lx;        // halo index of the voxel's (-1, -1, -1) neighbour
+            c1_bf16x8 xf;
 #pragma unroll
-                for (int c4 = 0; c4 < C / 4; ++c4) { const float4 bv = br[c4]; acc[v][2 * c4] = c1_f32x2{bv.x, bv.y}; acc[v][2 * c4 + 1] = c1_f32x2{bv.z, bv.w}; }
+            for (int j = 0; j < 8; ++j) {
+                const float v = xt[vbase + toff[j]];
+                xf[j] = (__bf16)((lastq && j >= 3) ? 0.f : v);
             }
-            const float* wsm = weff + (size_t)b * 27 * C;       // wave-uniform address: scalar loads, the weights are SGPR operands of the fma
-#pragma unroll 3
-            for (int k = 0; k < 27; ++k) {
-                const int kd = k / 9, kr = k - kd * 9, kh = kr / 3, kw = kr - kh * 3;
-                const int xo = xbase + (kd * 10 + kh) * 10 + kw;
-                const float xs0 = xt[xo], xs1 = xt[xo + 400];
-                const c1_f32x2 x0 = c1_f32x2{xs0, xs0}, x1 = c1_f32x2{xs1, xs1};
-                const float4* wr = reinterpret_cast<const float4*>(wsm + k * C);
+            c1_f32x4 acc[4];
 #pragma unroll
-                for (int c4 = 0; c4 < C / 4; ++c4) {
-                    const float4 wv = wr[c4];                   // same address in every lane: an LDS broadcast, used for both voxels
-                    const c1_f32x2 wa = c1_f32x2{wv.x, wv.y}, wb = c1_f32x2{wv.z, wv.w};
-                    acc[0][2 * c4] = wa * x0 + acc[0][2 * c4]; acc[0][2 * c4 + 1] = wb * x0 + acc[0][2 * c4 + 1];
-                    acc[1][2 * c4] = wa * x1 + acc[1][2 * c4]; acc[1][2 * c4 + 1] = wb * x1 + acc[1][2 * c4 + 1];
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[ct], xf, c1_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int gh = h0 + ly, gw = w0 + lx;
+            if (gh >= H || gw >= W) continue;
+            const int cls = (gd == 0) | ((gd == D - 1) << 1) | ((gh == 0) << 2) | ((gh == H - 1) << 3) | ((gw == 0) << 4) | ((gw == W - 1) << 5);
+            const float4* br = cls == 0 ? reinterpret_cast<const float4*>(tab0 + lq * 16) : reinterpret_cast<const float4*>(tab + ((size_t)b * 64 + cls) * C + lq * 16);
+            bf16_t* yo = y + ((size_t)b * S + ((size_t)gd * H + gh) * W + gw) * C + lq * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float4 bv = br[2 * h + jj];
+                    c1_f32x4 a = acc[2 * h + jj];
+                    a[0] += bv.x; a[1] += bv.y; a[2] += bv.z; a[3] += bv.w;
+                    if (relu) { a[0] = a[0] > 0.f ? a[0] : 0.f; a[1] = a[1] > 0.f ? a[1] : 0.f; a[2] = a[2] > 0.f ? a[2] : 0.f; a[3] = a[3] > 0.f ? a[3] : 0.f; }
+                    pk[2 * jj] = pack_bf16x2(a[0], a[1]); pk[2 * jj + 1] = pack_bf16x2(a[2], a[3]);
                 }
-            }
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int gd = d0 + lz + 4 * v;
-                if (gd >= D) continue;
-                bf16_t* yo = y + ((size_t)b * S + ((size_t)gd * H + gh) * W + gw) * C;
-#pragma unroll
-                for (int o8 = 0; o8 < 8; ++o8) {
-                    uint32_t pk[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float a0 = acc[v][4 * o8 + j][0], a1 = acc[v][4 * o8 + j][1];
-                        if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
-                        pk[j] = pack_bf16x2(a0, a1);
-                        const c1_bf16x2 pv = __builtin_bit_cast(c1_bf16x2, pk[j]);
-                        gs[o8] = __builtin_amdgcn_fdot2_f32_bf16(pv, __builtin_bit_cast(c1_bf16x2, 0x3f803f80u), gs[o8], false);
-                        gq[o8] = __builtin_amdgcn_fdot2_f32_bf16(pv, pv, gq[o8], false);
-                    }
-                    reinterpret_cast<uint4*>(yo)[o8] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const c1_bf16x2 pv = __builtin_bit_cast(c1_bf16x2, pk[jj]);
+                    gs[h] = __builtin_amdgcn_fdot2_f32_bf16(pv, __builtin_bit_cast(c1_bf16x2, 0x3f803f80u), gs[h], false);
+                    gq[h] = __builtin_amdgcn_fdot2_f32_bf16(pv, pv, gq[h], false);
                 }
+                reinterpret_cast<uint4*>(yo)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
         }
     }
-    // GroupNorm partials of what this block stored: per 8-channel octet, wave reduction then the 4 waves through LDS (fixed order)
+    // GroupNorm partials of what this block stored: octet lq * 2 + h; the 16 voxel lanes of a row, then the 8 waves through LDS (fixed order)
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float s_ = gs[i], q_ = gq[i];
+    for (int h = 0; h < 2; ++h) {
+        float s_ = gs[h], q_ = gq[h];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { s_ += __shfl_xor(s_, m, 64); q_ += __shfl_xor(q_, m, 64); }
-        if (lane == 0) { red[wave * 16 + i] = s_; red[wave * 16 + 8 + i] = q_; }
+        for (int m = 8; m >= 1; m >>= 1) { s_ += __shfl_xor(s_, m, 64); q_ += __shfl_xor(q_, m, 64); }
+        if (lr == 0) { red[wave * 16 + lq * 2 + h] = s_; red[wave * 16 + 8 + lq * 2 + h] = q_; }
     }
     __syncthreads();
     if (tid < 2 * C) {
         const int st = tid >> 6, c = tid & 63;
         float v = 0.f;                    // the 8-channel sum goes to the first channel of the octet, zeros to the other seven
-        if ((c & 7) == 0) for (int wv_ = 0; wv_ < 4; ++wv_) v += red[wv_ * 16 + st * 8 + (c >> 3)];
+        if ((c & 7) == 0) for (int wv_ = 0; wv_ < 8; ++wv_) v += red[wv_ * 16 + st * 8 + (c >> 3)];
         ws[(((size_t)b * nblk + blk) * 2 + st) * C + c] = v;
     }
+#endif
 }
-
 
 // ---- GroupNorm affine of a 1x1x1 lift of a one-channel volume, without materialising the lift ---------------------------------
 // r_c = w_c x + b_c per voxel, so the per-(sample, group) statistics GroupNorm needs follow from the first two moments of x:
@@ -471,7 +481,7 @@ int gfe_conv_in1_stats(const void* x, const float* w, const float* bias, void* y
 
 int gfe_conv3d_c1_k3_nblk(int64_t B, int64_t D, int64_t H, int64_t W) {
     const int64_t tiles = ceil_div(D, 8) * ceil_div(H, 8) * ceil_div(W, 8);
-    const int64_t want = B > 0 ? (768 + B - 1) / B : 1;           // ~768 four-wave blocks in all (3 per CU: 165 VGPRs)
+    const int64_t want = B > 0 ? (512 + B - 1) / B : 1;           // ~512 eight-wave blocks in all
     return (int)(tiles < want ? tiles : want);
 }
 
@@ -483,9 +493,9 @@ int gfe_conv3d_c1_k3(const void* x, const float* weff, const float* bias_tab, vo
     GFE_REQUIRE(stats_nblk == nblk, GFE_ERR_SHAPE);
     const dim3 grid((unsigned)nblk, (unsigned)B);
     if (in_dtype == GFE_F32)
-        hipLaunchKernelGGL((conv3d_c1_k3_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
+        hipLaunchKernelGGL((conv3d_c1_k3_kernel<float>), grid, dim3(512), 0, (hipStream_t)stream, (const float*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
     else if (in_dtype == GFE_BF16)
-        hipLaunchKernelGGL((conv3d_c1_k3_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
+        hipLaunchKernelGGL((conv3d_c1_k3_kernel<bf16_t>), grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x, weff, bias_tab, (bf16_t*)y, stats_ws, nblk, (int)D, (int)H, (int)W, relu);
     else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }
