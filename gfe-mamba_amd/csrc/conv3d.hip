@@ -90,6 +90,7 @@ constexpr unsigned OOB = 0x80000000u;          // buffer offset beyond num_recor
 struct ConvParams {
     const bf16_t* x; const bf16_t* w; const float* bias; const float* bias_tab; const bf16_t* res; bf16_t* y;
     const float* res1_x; const float* res1_w; const float* res1_b;   // residual computed on the fly from a one-channel volume: w[c] * x + b[c]
+    const float* out1_w; float out1_b; float* out1_y;                  // OUT1: a 1x1x1 conv Cout -> 1 of the result instead of storing the result
     long long w_batch_stride;                  // elements between per-sample weight sets (0: shared)
     int B, D, H, W, Cin, Cout, CoutPad;
     int OD, OH, OW;
@@ -115,7 +116,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define GFE_STAMP(slot) do {} while (0)
 #endif
 
-template <int NT, int TPS, bool REG27, bool STATS, bool MC, bool RES1 = false>
+template <int NT, int TPS, bool REG27, bool STATS, bool MC, bool RES1 = false, bool OUT1 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer/LDS-DMA builtins)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     if constexpr (RES1) { if (tid < 64) { sR1[tid] = p.res1_w[tid]; sR1[64 + tid] = p.res1_b[tid]; } }      // visible after the first stage barrier
+    if constexpr (OUT1) { if (tid < 64) sR1[tid] = p.out1_w[tid]; }
     const int ntiles = p.B * p.ntd * p.nth * p.ntw * (MC ? p.ncls : 1);       // work items: (tile, class) with the class innermost
     // XCD-aware placement: blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so the blocks of one XCD
     // get ADJACENT tile ranges -- halo planes shared by neighbouring ranges are then served by that XCD's own L2 instead of being
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                             acc[xt][i][2] += fmaf(wv.z, xval, bv.z); acc[xt][i][3] += fmaf(wv.w, xval, bv.w);
                         }
                     }
+                    float o1 = 0.f;
                     uint4 rv[2];
                     if (res_t) { const uint4* rp = reinterpret_cast<const uint4*>(res_t + o); rv[0] = rp[0]; rv[1] = rp[1]; }
 #pragma unroll
@@ -485,7 +488,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                                 gq[h] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[h], false);
                             }
                         }
-                        reinterpret_cast<uint4*>(y_t + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        if constexpr (OUT1) {
+                            // the generator's final 1x1x1 conv (Cout -> 1) applied to the rounded result; the result itself is not needed
+                            const float4* w4 = reinterpret_cast<const float4*>(sR1 + c0 + 8 * h);
+                            const float4 wa = w4[0], wb = w4[1];
+                            o1 = fmaf(bf16lo_to_f32(pk[0]), wa.x, o1); o1 = fmaf(bf16hi_to_f32(pk[0]), wa.y, o1);
+                            o1 = fmaf(bf16lo_to_f32(pk[1]), wa.z, o1); o1 = fmaf(bf16hi_to_f32(pk[1]), wa.w, o1);
+                            o1 = fmaf(bf16lo_to_f32(pk[2]), wb.x, o1); o1 = fmaf(bf16hi_to_f32(pk[2]), wb.y, o1);
+                            o1 = fmaf(bf16lo_to_f32(pk[3]), wb.z, o1); o1 = fmaf(bf16hi_to_f32(pk[3]), wb.w, o1);
+                        } else {
+                            reinterpret_cast<uint4*>(y_t + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        }
+                    }
+                    if constexpr (OUT1) {
+                        o1 += __shfl_xor(o1, 16, 64);                           // the four channel quads of the voxel (lanes 16 apart)
+                        o1 += __shfl_xor(o1, 32, 64);
+                        if (lq == 0) p.out1_y[((size_t)b * p.D + cd) * p.H * p.W + (size_t)ch_ * p.W + cw_] = o1 + p.out1_b;
                     }
                 }
               }
@@ -672,10 +690,10 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     tab[((size_t)b * 64 + cls) * CoutPad + ch] = acc;
 }
 
-template <int NT, int TPS, bool REG27, bool STATS, bool MC = false, bool RES1 = false>
+template <int NT, int TPS, bool REG27, bool STATS, bool MC = false, bool RES1 = false, bool OUT1 = false>
 int conv_launch(const ConvParams& p, hipStream_t st) {
     constexpr int W_PIECES = (TPS * NT * 16 + 15) / 16;
-    const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * NT * 16 * sizeof(float) + (RES1 ? 512 : 0);
+    const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * NT * 16 * sizeof(float) + ((RES1 || OUT1) ? 512 : 0);
     const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw * (MC ? p.ncls : 1);
     if (tiles > 0x7fffffff) return GFE_ERR_SHAPE;
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
@@ -683,8 +701,8 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     q.tiles_per_block = (int)ceil_div(tiles, 256);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1>), grid, dim3(NTHREADS), lds, st, q);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1, OUT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1, OUT1>), grid, dim3(NTHREADS), lds, st, q);
     return gfe_launch_status();
 }
 
@@ -742,8 +760,9 @@ static int conv_igemm_impl(const void* x, const void* w_packed, int64_t w_batch_
                            int ntaps, const int8_t* tap_offsets /* host, ntaps x 3 (dd,dh,dw) */,
                            int ostride, int op_d, int op_h, int op_w, int oshift, int relu,
                            float* stats_ws, int64_t stats_nblk, int64_t stats_slot0,
-                           const float* res1_x, const float* res1_w, const float* res1_b, void* stream) {
-    GFE_REQUIRE(x && w_packed && y && tap_offsets, GFE_ERR_NULL);
+                           const float* res1_x, const float* res1_w, const float* res1_b,
+                           const float* out1_w, float out1_b, float* out1_y, void* stream) {
+    GFE_REQUIRE(x && w_packed && (y || out1_y) && tap_offsets, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
     GFE_REQUIRE(ostride == 1 || ostride == 2, GFE_ERR_SHAPE);
@@ -752,6 +771,7 @@ static int conv_igemm_impl(const void* x, const void* w_packed, int64_t w_batch_
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = bias; p.bias_tab = bias_tab;
     p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = w_batch_stride;
     p.res1_x = res1_x; p.res1_w = res1_w; p.res1_b = res1_b;
+    p.out1_w = out1_w; p.out1_b = out1_b; p.out1_y = out1_y;
     p.B = (int)B; p.D = (int)D; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.CoutPad = gfe_conv3d_cout_pad(Cout);
     p.OD = (int)OD; p.OH = (int)OH; p.OW = (int)OW;
@@ -807,6 +827,11 @@ static int conv_igemm_impl(const void* x, const void* w_packed, int64_t w_batch_
     }
     if (NT == 1) return conv_launch<1, 3, false, false>(p, st);
     if (NT == 2) return conv_launch<2, 3, false, false>(p, st);
+    if (out1_y) {
+        // final 1x1x1 conv fused: only the plain 27-tap 64-channel variant carries that epilogue
+        GFE_REQUIRE(out1_w && !res1_x && reg27 && NT == 4 && Cout == 64, GFE_ERR_SHAPE);
+        return conv_launch<4, 3, true, false, false, false, true>(p, st);
+    }
     if (res1_x) {
         // residual from a one-channel volume: only the plain 27-tap 64-channel variant carries that epilogue
         GFE_REQUIRE(res1_w && res1_b && !res && reg27 && NT == 4 && Cout == 64, GFE_ERR_SHAPE);
@@ -823,7 +848,7 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
                      int ostride, int op_d, int op_h, int op_w, int oshift, int relu,
                      float* stats_ws, int64_t stats_nblk, int64_t stats_slot0, void* stream) {
     return conv_igemm_impl(x, w_packed, w_batch_stride, bias, bias_tab, res, y, B, D, H, W, Cin, Cout, OD, OH, OW, ntaps, tap_offsets,
-                           ostride, op_d, op_h, op_w, oshift, relu, stats_ws, stats_nblk, stats_slot0, nullptr, nullptr, nullptr, stream);
+                           ostride, op_d, op_h, op_w, oshift, relu, stats_ws, stats_nblk, stats_slot0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, stream);
 }
 
 int gfe_conv3d_k3_lift_residual(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, void* y,
@@ -831,7 +856,15 @@ int gfe_conv3d_k3_lift_residual(const void* x, const void* w_packed, int64_t w_b
                                 const float* vol, const float* lift_w, const float* lift_b, void* stream) {
     GFE_REQUIRE(vol && lift_w && lift_b, GFE_ERR_NULL);
     return conv_igemm_impl(x, w_packed, w_batch_stride, nullptr, bias_tab, nullptr, y, B, D, H, W, Cin, Cout, D, H, W, 27, tap_offsets,
-                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, vol, lift_w, lift_b, stream);
+                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, vol, lift_w, lift_b, nullptr, 0.f, nullptr, stream);
+}
+
+int gfe_conv3d_k3_out1(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, const void* res,
+                       int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, const int8_t* tap_offsets, int relu,
+                       const float* out_w, float out_b, float* out_y, void* stream) {
+    GFE_REQUIRE(out_w && out_y, GFE_ERR_NULL);
+    return conv_igemm_impl(x, w_packed, w_batch_stride, nullptr, bias_tab, res, nullptr, B, D, H, W, Cin, Cout, D, H, W, 27, tap_offsets,
+                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, nullptr, nullptr, nullptr, out_w, out_b, out_y, stream);
 }
 
 int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* cls_woff, const int* cls_ntaps, const int8_t* cls_parity,
@@ -873,7 +906,7 @@ int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* c
     ConvParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = nullptr; p.bias_tab = nullptr;
     p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = 0;
-    p.res1_x = nullptr; p.res1_w = nullptr; p.res1_b = nullptr;
+    p.res1_x = nullptr; p.res1_w = nullptr; p.res1_b = nullptr; p.out1_w = nullptr; p.out1_b = 0.f; p.out1_y = nullptr;
     p.B = (int)B; p.D = (int)D; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.CoutPad = gfe_conv3d_cout_pad(Cout);
     p.OD = (int)OD; p.OH = (int)OH; p.OW = (int)OW;

@@ -254,6 +254,18 @@ def conv3_lift_residual(x, w_packed, tab, cout, vol, lift_w, lift_b, relu=True):
     return out
 
 
+def conv3_out1(x, w_packed, tab, cout, res, out_w, out_b, relu=True):
+    """27-tap conv of x (per-sample folded weights + bias table) + bf16 residual + ReLU, followed by the final 1x1x1 conv cout -> 1:
+    returns (B, 1, D, H, W) f32; the 64-channel tensor in between is never stored (gfe_conv3d_k3_out1)."""
+    B, D, H, W, cin = x.shape
+    assert x.dtype == BF16 and x.is_contiguous() and w_packed.dim() == 5 and (res is None or (res.dtype == BF16 and res.is_contiguous()))
+    y = torch.empty((B, 1, D, H, W), dtype=torch.float32, device=x.device)
+    _, tptr = _i8(CONV3_TAPS)
+    call("gfe_conv3d_k3_out1", ptr(x), ptr(w_packed), w_packed.stride(0), ptr(tab), ptr(res), B, D, H, W, cin, cout, tptr, int(relu),
+         ptr(out_w), float(out_b), ptr(y), stream())
+    return y
+
+
 def conv_c1_k3(x, weff, tab, relu=True):
     """x: (B, 1, D, H, W) f32|bf16 -> (B, D, H, W, 64) bf16 with its GroupNorm partials attached (`y.gn_partials`)."""
     B, _, D, H, W = x.shape

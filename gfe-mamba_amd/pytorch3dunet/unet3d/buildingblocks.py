@@ -51,7 +51,7 @@ class SingleConv(nn.Sequential):
         self.relu = 'r' in order
         self._pack = _PackCache()
 
-    def forward(self, x, residual=None, stats=False):
+    def forward(self, x, residual=None, stats=False, out1=None):
         """x: (B, D, H, W, Cin) bf16; optional residual is added before the (forced) ReLU: ResNetBlock tail.
         stats: the output feeds another SingleConv -> its GroupNorm partials are produced by this conv's epilogue."""
         gn, conv = self.groupnorm, self.conv
@@ -60,6 +60,8 @@ class SingleConv(nn.Sequential):
         scale, shift = K.groupnorm_scale_shift(x, g, b, gn.num_groups, gn.eps)
         # GroupNorm is folded into per-sample weights + a boundary-class bias table: the conv itself streams raw activations
         wb, tab = K.fold_groupnorm(w32, scale, shift, K.CONV3_TAPS, conv.in_channels, conv.out_channels)
+        if out1 is not None:            # (w (C,), b): the generator's final 1x1x1 conv, fused into this conv's epilogue
+            return K.conv3_out1(x, wb, tab, conv.out_channels, residual, out1[0], out1[1], relu=self.relu or residual is not None)
         return K.conv_igemm(x, wb, K.CONV3_TAPS, conv.out_channels, bias_tab=tab, res=residual, relu=self.relu or residual is not None,
                             stats=True if stats else None)
 
@@ -134,7 +136,8 @@ class ResNetBlock(nn.Module):
         _, tab = K.fold_groupnorm(w32, scale, scale * b1 + shift, K.CONV3_TAPS, c, cout)       # only the bias table is used
         return K.conv_igemm(x, weff, K.CONV3_TAPS, cout, bias_tab=tab, relu=sc.relu, stats=True)
 
-    def forward(self, x):
+    def forward(self, x, out1=None):
+        """out1 = (w, b) of a following 1x1x1 conv C -> 1 (the generator's final_conv): returns that conv's output instead of the block's."""
         c1 = self.conv1
         if (not isinstance(c1, nn.Identity) and c1.in_channels == 1 and c1.out_channels == 64 and x.dim() == 5 and x.shape[1] == 1
                 and x.dtype == torch.float32 and self.conv3.conv.out_channels == 64):
@@ -145,6 +148,8 @@ class ResNetBlock(nn.Module):
             o = self._conv2_through_lift(x, r)
         else:
             o = self.conv2(r, stats=True)
+        if out1 is not None and isinstance(c1, nn.Identity) and self.conv3.conv.out_channels == 64:
+            return self.conv3(o, residual=r, out1=out1)
         return self.conv3(o, residual=r)
 
 
@@ -212,9 +217,14 @@ class Decoder(nn.Module):
                                          order=conv_layer_order, num_groups=num_groups, padding=padding,
                                          dropout_prob=dropout_prob, is3d=is3d)
 
-    def forward(self, encoder_features, x):
+    def forward(self, encoder_features, x, out1=None):
         x = self.upsampling(encoder_features, x)          # upsample + nearest resize + sum join, one fused epilogue
-        return self.basic_module(x)
+        return self.basic_module(x, out1=out1) if out1 is not None else self.basic_module(x)
+
+    def fuses_out1(self):
+        """True when forward(..., out1=(w, b)) returns the final 1x1x1 conv's output (the 64-channel identity-lift block)."""
+        bm = self.basic_module
+        return isinstance(bm.conv1, nn.Identity) and bm.conv3.conv.out_channels == 64
 
 
 def create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob,

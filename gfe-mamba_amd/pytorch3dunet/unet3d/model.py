@@ -73,15 +73,20 @@ class Mid_UNet_vit(nn.Module):
         mid_input = K.fold_mid(x, md1=8)                                      # model.py:150
         mid_output = self.mid(mid_input)
         x = K.fold_mid(mid_output, md1=8, inverse=True, shape=(d, h, w))      # model.py:152
-        dec_feats = []
-        for dec, ef in zip(self.decoders, feats):
-            x = dec(ef, x)
-            if output_mid:
-                dec_feats.append(x)
         fc = self.final_conv
         fw, fb = self._fc_pack.get([fc.weight, fc.bias], lambda: (fc.weight.detach().float().view(-1).contiguous(),
                                                                   float(fc.bias.detach().float().cpu().item())))
-        pet = K.conv_out1(x, fw, fb)
+        dec_feats = []
+        pet = None
+        for i, (dec, ef) in enumerate(zip(self.decoders, feats)):
+            if i == len(self.decoders) - 1 and not output_mid and dec.fuses_out1():
+                pet = dec(ef, x, out1=(fw, fb))              # final_conv in the last conv's epilogue: its 64-channel input is never stored
+                break
+            x = dec(ef, x)
+            if output_mid:
+                dec_feats.append(x)
+        if pet is None:
+            pet = K.conv_out1(x, fw, fb)
         if not self.training and self.final_activation is not None:
             pet = self.final_activation(pet)
         if output_mid:

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 19
+#define GFE_ABI_VERSION 20
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -307,6 +307,13 @@ int gfe_lift_groupnorm_affine(const float* x, const float* w, const float* bias,
 int gfe_conv3d_k3_lift_residual(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, void* y,
                                 int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, const int8_t* tap_offsets, int relu,
                                 const float* vol, const float* lift_w, const float* lift_b, void* stream);
+
+/* gfe_conv3d_igemm for a stride-1 27-tap 64-channel conv (per-sample folded weights + bias table, optional bf16 residual, ReLU) that is
+ * followed by the generator's final 1x1x1 conv Cout -> 1 (model.py:123, 165): the 64-channel result is rounded to bf16 as usual but
+ * not stored; out_y (B, D, H, W) f32 = sum_c out_w[c] * result_c + out_b. */
+int gfe_conv3d_k3_out1(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, const void* res,
+                       int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, const int8_t* tap_offsets, int relu,
+                       const float* out_w, float out_b, float* out_y, void* stream);
 
 /* ---- input pipeline ------------------------------------------------------------------------------------
  * adaptive_normal (utils/data_normalization.py:20-48, applied per volume at dataloader/pic_table_loader.py:107): lo / hi = the order

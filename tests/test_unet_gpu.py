@@ -389,3 +389,17 @@ def test_encoder_block_conv2_through_the_lift_matches_torch(cin, shape):
         ref = F.relu(t + xr).permute(0, 2, 3, 4, 1)
     assert rel_err(o_fast, ref2) < 2e-2 and rel_err(o_slow, ref2) < 2e-2
     assert rel_err(out, ref) < 2e-2
+
+
+def test_final_conv_fused_into_the_last_conv_matches_the_separate_kernel():
+    """Real-width generator at 32^3: `pet` from the last decoder conv with final_conv in its epilogue (default) against the path that
+    stores the 64-channel tensor and runs gfe_conv_out1 on it (taken when the decoder features are requested)."""
+    from gfe_hip.step import build_models
+    gen, _, _ = build_models(vol=(32, 32, 32), f_maps=(64, 128, 256), vit_kwargs=dict(dim=64, depth=1, heads=2, dim_head=16, mlp_dim=128), seed=5)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 32, 32, 32, generator=g).clamp(-1, 1).to(DEV)
+    with torch.no_grad():
+        pet_fused = gen(x)
+        _, dec_feats, pet_sep = gen(x, output_mid=True)
+    assert pet_fused.shape == pet_sep.shape == (2, 1, 32, 32, 32) and pet_fused.dtype == torch.float32
+    assert rel_err(pet_fused, pet_sep) < 2e-2          # two generator runs differ by ~5e-3 on their own (split-K / fold f32 atomics)
