@@ -10,11 +10,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def measured_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v12.json: FETCH_SIZE x2 as the
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v13.json: FETCH_SIZE x2 as the
     gfx950 correction prescribes + WRITE_SIZE, separate passes); None when the file does not travel with the tree."""
     import json
     import os
-    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01", "traffic_v12.json")
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01", "traffic_v13.json")
     try:
         return float(json.load(open(f))[key]["traffic_bytes"])
     except (OSError, KeyError, ValueError):
