@@ -403,3 +403,31 @@ def test_final_conv_fused_into_the_last_conv_matches_the_separate_kernel():
         _, dec_feats, pet_sep = gen(x, output_mid=True)
     assert pet_fused.shape == pet_sep.shape == (2, 1, 32, 32, 32) and pet_fused.dtype == torch.float32
     assert rel_err(pet_fused, pet_sep) < 2e-2          # two generator runs differ by ~5e-3 on their own (split-K / fold f32 atomics)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 9, 7), (2, 8, 16, 8), (1, 1, 1, 1)])
+def test_decoder_block_with_fused_final_conv_on_ragged_shapes(shape):
+    """ResNetBlock(64, 64)(x, out1=(w, b)) -- the last decoder block with the generator's final 1x1x1 conv in its last conv's epilogue
+    (gfe_conv3d_k3_out1) -- against the block followed by gfe_conv_out1 and against torch fp32, on sizes that are not tile multiples."""
+    from gfe_hip import nn_ops as K
+    from pytorch3dunet.unet3d.buildingblocks import ResNetBlock
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(7 * D + W)
+    blk = ResNetBlock(64, 64).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() == 1 else 1.0 / max(1, p[0].numel()) ** 0.5))
+        blk.conv2.groupnorm.weight.add_(1.0); blk.conv3.groupnorm.weight.add_(1.0)
+    fw = (torch.randn(64, generator=g) / 8).to(DEV)
+    fb = 0.37
+    x = torch.randn(B, D, H, W, 64, generator=g).to(BF).to(DEV)
+    x.gn_partials = None
+    with torch.no_grad():
+        fused = blk(x, out1=(fw, fb))
+        sep = K.conv_out1(blk(x), fw, fb)
+        xn = x.float().permute(0, 4, 1, 2, 3)
+        t = F.relu(F.conv3d(F.group_norm(xn, 8, blk.conv2.groupnorm.weight, blk.conv2.groupnorm.bias, 1e-5), blk.conv2.conv.weight, padding=1))
+        t = F.conv3d(F.group_norm(t, 8, blk.conv3.groupnorm.weight, blk.conv3.groupnorm.bias, 1e-5), blk.conv3.conv.weight, padding=1)
+        ref = (F.relu(t + xn) * fw.view(1, 64, 1, 1, 1)).sum(1, keepdim=True) + fb
+    assert fused.shape == (B, 1, D, H, W) and fused.dtype == torch.float32
+    assert rel_err(fused, sep) < 5e-3 and rel_err(fused, ref) < 2e-2
