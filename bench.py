@@ -12,8 +12,13 @@ workload `scan`: BASELINE config 2, the fused selective scan alone (L=4096, ED=1
 workload `vit3d`: the synthetic 3-D ViT of SURVEY 8-d (96^3, 8^3 patches -> 1729 tokens, dim 512, depth 4, 8 heads x 64), forward;
 its roofline object is the flash-attention kernel against the bf16 MFMA peak.
 
-For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU (RCCL).  The timed region is
-bracketed by barrier + synchronize on both sides; the reported time is the max over ranks.
+workload `gen128`: BASELINE config 4, the generator forward alone (main_gan_vit.py:69) on 2 volumes of 128^3.
+
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or `python bench.py --gpus N` alone does: with no
+WORLD_SIZE in the environment the process starts `torch.distributed.run` with N ranks as a CHILD process -- before this
+process has made any GPU call; it never re-executes itself -- and exits with the child's code.  The timed region is bracketed
+by barrier + synchronize on both sides; the reported time is the max over ranks.
 """
 import argparse
 import json
@@ -26,6 +31,46 @@ SRC = os.path.join(ROOT, "gfe-mamba_amd")
 for p in (ROOT, SRC):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+
+def launch_command(n_gpus, argv, port=None):
+    """The command `bench.py --gpus N` starts when nobody has started the ranks for it: torch.distributed.run, one rank per GPU
+    of this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(argv=None):
+    """`python bench.py --gpus N` (N > 1) without WORLD_SIZE: start the N ranks as a child process.  Nothing in this process has
+    touched the GPU at this point (torch is not even imported), and the child is a child -- no exec of a GPU-initialised process."""
+    argv = sys.argv[1:] if argv is None else argv
+    if "WORLD_SIZE" in os.environ:
+        return None
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return None
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(launch_command(n, argv), env=env)
+
+
+if __name__ == "__main__":
+    _rc = maybe_self_launch()
+    if _rc is not None:
+        sys.exit(_rc)
 
 import torch
 import torch.distributed as dist
@@ -209,18 +254,78 @@ class NormWorkload:
                 "sample": "oracle/ref_ops.adaptive_normal (torch CPU sort) on 2 volumes of 160x160x96"}
 
 
+class Gen128Workload:
+    """BASELINE config 4: the MRI->PET generator forward alone (main_gan_vit.py:69: `model(condition)`, output_vit_mid=False) on
+    volumes of 128^3 (ViT image (256,128), patch 32), batch 2, bf16 activations, deterministic random-init weights."""
+    name = "Residual_mid_UNet3D_vit forward (main_gan_vit generator), 128^3, batch 2, synthetic (config 4)"
+    GFLOP_PER_VOL = 3214.4          # SURVEY 8-d config 4: ~3.21 TFLOP per 128^3 volume (conv 96^3 figures x (128/96)^3 + ViT GEMMs)
+
+    def __init__(self, batch):
+        import gfe_hip.det_init as det
+        from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+        self.vol = (128, 128, 128)
+        gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(64, 128, 256), vol_size=self.vol)
+        gen.load_state_dict(det.det_state_dict(gen.state_dict(), seed=32, prefix="gen128."))
+        self.gen = gen.cuda().eval()
+        self.x = det.det_inputs(batch, self.vol, seed=6)[0].cuda()
+        self.batch = self.units = batch
+
+    def step(self):
+        with torch.no_grad():
+            return self.gen(self.x)
+
+    def roofline(self, iters=10):
+        """Dominant kernel: the GroupNorm-folded 27-tap 64->64 conv at 128^3 (three launches per forward)."""
+        from gfe_hip import nn_ops as K
+        blk = self.gen.encoders[0].basic_module
+        with torch.no_grad():
+            r = blk.lift(self.x)
+            conv = blk.conv2
+            w32 = K.pack_conv3(conv.conv.weight, torch.float32)
+            g, b = conv.groupnorm.weight.detach().float().contiguous(), conv.groupnorm.bias.detach().float().contiguous()
+            ss = K.groupnorm_scale_shift(r, g, b, 8)
+            w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, 64, 64)
+            out = K.conv_igemm(r, w, K.CONV3_TAPS, 64, bias_tab=tab, relu=True)
+            run = lambda: K.conv_igemm(r, w, K.CONV3_TAPS, 64, bias_tab=tab, relu=True, out=out)
+            for _ in range(3):
+                run()
+            ms = time_region(run, iters)
+        flops = 2.0 * 27 * 64 * 64 * self.batch * 128 ** 3
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": None, "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @128^3, ReLU)",
+                "launch_ms": round(ms, 4), "algorithmic_flops": flops}
+
+    def cpu_baseline(self):
+        """oracle.ref_ops.generator (torch CPU fp32 restatement of model.py:137-175) on ONE 128^3 volume."""
+        from oracle import ref_ops as O
+        sd = {k: v.detach().float().cpu() for k, v in self.gen.state_dict().items()}
+        x = self.x[:1].cpu()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.generator(x, sd)
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle.ref_ops.generator, 1 volume of 128^3, fp32, torch CPU"}
+
+    def extra(self):
+        return {"generator_gflop_per_volume": self.GFLOP_PER_VOL}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise"])
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (volumes for `step`, sequences for `scan`)")
+    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise", "gen128"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (volumes for `step`, sequences for `scan`; default 8, gen128: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph (experimental: for host-bound batches of 1-4 volumes; "
                          "whole-step replay hits an intermittent HSA exception on this ROCm, see DESIGN.md 6)")
     ap.add_argument("--no-pipeline", action="store_true", help="step workload: strictly serial step (generator, then head) on one stream")
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 2 if a.workload == "gen128" else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -231,8 +336,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n_gpus = world
+    assert a.gpus == n_gpus or "WORLD_SIZE" in os.environ, "internal: --gpus N > 1 without WORLD_SIZE is started by maybe_self_launch()"
+    # per-rank RNG stream for everything drawn on the device during the step (the GEGLU feed-forward's dropout mask,
+    # mamba_transformer.py:85): each rank must drop different units of its own shard
+    torch.manual_seed(1234 + rank)
+    torch.cuda.manual_seed(1234 + rank)
 
-    if a.workload == "scan":
+    if a.workload == "gen128":
+        wl = Gen128Workload(a.batch)
+        steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 3
+        metric, unit, dtype = "MRI volumes/sec (128^3 bf16) MRI->PET generator forward (main_gan_vit, config 4)", "volumes/s", "bf16"
+        cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "128x128x128",
+               "parallelism": f"replicas x{n_gpus}"}
+    elif a.workload == "scan":
         wl = ScanWorkload(a.batch)
         steps, warmup = a.steps or 50, a.warmup if a.warmup is not None else 10
         metric, unit, dtype = "selective-scan tokens/sec (L=4096 ED=1024 N=16 bf16) fwd+bwd", "tokens/s", "bf16"
@@ -278,6 +394,7 @@ def main():
         el = t.item()
 
     roof = wl.roofline()
+    comm = wl.allreduce_stats() if world > 1 and hasattr(wl, "allreduce_stats") else None
     cpu = None
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         cpu = wl.cpu_baseline()
@@ -289,6 +406,8 @@ def main():
         extra = getattr(wl, "extra", None)
         if extra:
             out["extra"] = extra() if callable(extra) else extra
+        if comm:
+            out["allreduce"] = comm
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -16,7 +16,7 @@ def measured_traffic(key):
     import os
     f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01", "traffic_v13.json")
     try:
-        return float(json.load(open(f))[key]["traffic_bytes"])
+        return float(json.load(open(f))[key]["traffic_bytes"])          # a committed rocprofv3 measurement, not this run's
     except (OSError, KeyError, ValueError):
         return None
 # generator conv FLOPs per 96^3 volume: 3x3x3 convs + transposed convs, multiply-add = 2 flop
@@ -99,6 +99,27 @@ class StepWorkload:
         dt = time.perf_counter() - t0
         return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": "oracle/ref_ops.py (torch CPU fp32): generator fwd + head fwd/bwd on 1 volume of 96^3 (no optimiser)"}
+
+    def allreduce_stats(self, iters=10):
+        """The step's only collective, timed alone on every rank (max over ranks): SUM all-reduce of the flat f32 gradient buffer.
+        bus GB/s = 2 (N-1)/N x bytes / time (the ring all-reduce's per-link traffic)."""
+        import torch.distributed as dist
+        g = self.step_obj.opt.flat_g
+        for _ in range(2):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        dt = torch.tensor([(time.perf_counter() - t0) / iters], device="cuda", dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        g.zero_()
+        n, nbytes = self.world, g.numel() * 4
+        return {"bytes": nbytes, "ms": round(dt.item() * 1e3, 4), "algbw_GBs": round(nbytes / dt.item() / 1e9, 1),
+                "busbw_GBs": round(2 * (n - 1) / n * nbytes / dt.item() / 1e9, 1), "collective": "all_reduce(SUM) of the flat f32 gradient buffer, RCCL"}
 
     def extra(self):
         return {"generator_gflop_per_volume": GEN_GFLOP_PER_VOL, "head_gflop_per_sample": HEAD_GFLOP_PER_SAMPLE}
