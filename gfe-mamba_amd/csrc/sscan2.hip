@@ -1,0 +1,730 @@
+// Fused selective scan (Mamba S6 recurrence), N = 16 states -- single-pass formulation for gfx950.
+//
+// Replaces, like sscan.hip (which stays for N = 4 / 8), the reference's
+//   cross_atten/mamba.py:265-286  MambaBlock.selective_scan  (deltaA/deltaB/BX -> pscan -> hs@C + D*x)
+//   cross_atten/mamba.py:243-259  softplus(delta + dt_proj.bias) and the y*silu(z) gate of the `selective_scan_fn` plug-in
+//   cross_atten/pscan.py:151-224  PScan.forward / backward (the recurrence and its adjoint)
+//
+// Why a second formulation (instruction prices from tools/probes/valu_rates.hip): the scan is VALU-issue bound --
+// one v_exp_f32 (8 cycles) and four f32 operations per state-step -- so the only lever is the number of instructions issued per
+// state-step.  sscan.hip keeps a channel's 16 states in one lane; filling the chip then needs chunks along L and TWO passes over
+// every chunk (local end state, then the real pass), i.e. two exp per state-step.  Here a lane owns one channel x one PAIR of
+// states: B*ED*8 lanes fill 1024 SIMDs from B = 8 up without cutting L, every state-step is computed once, the pair keeps the
+// arithmetic in v_pk_* form, and a segment's states fit in registers for the backward (no third exp, no LDS checkpoints).
+// L is cut into chunks (two passes + carry) only when B*ED/8 waves cannot fill the chip (B = 1).
+//
+// Work split: block = 4 waves = 32 channels of one (batch, chunk); wave = 8 channels x 8 state pairs:
+//     lane bits {2,3,4} = pair p   (the sum over states = over p runs on DPP row operations + v_permlane16_swap, no selects)
+//     lane bits {0,1,5} = channel c within the wave
+// u / delta / z rows reach the block as 64-B (bf16) or 128-B (f32) row segments, are turned ONCE per (t, channel) into
+// dt = softplus(delta + bias), dt*u, D*u and silu(z) and parked in LDS (double-buffered 32-step tiles, one barrier per tile);
+// B / C rows are parked as {B[2p], B[2p+1], C[2p], C[2p+1]} so that one ds_read_b128 feeds a step.  y goes back through LDS so
+// that global stores are whole row segments.
+#include "common.h"
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int TT = 32;       // steps per LDS tile == checkpoint interval: the backward recomputes one tile at a time with its states in registers
+constexpr int CB = 32;       // channels per block (4 waves x 8)
+constexpr int EPS = 36;      // row stride (floats) of the [step][channel] arrays: banks 4*p + c are distinct for the butterfly's owners
+constexpr int SEG = TT;
+
+// [channel][step] arrays (dt, dt*u): a lane reads 4 consecutive steps of its channel per ds_read_b128.  The 4-step groups of a row are
+// XOR-swizzled by the channel so that both the staging writes (32 lanes = 8 channel quads x 4 steps) and the reads (4 rows per
+// 16-lane group) are bank-conflict free without padding.
+__device__ __forceinline__ int dts_index(int ch, int t) { return ch * TT + ((((t >> 2) ^ (ch >> 2) ^ ((ch >> 1) & 1)) & 7) << 2) + (t & 3); }
+
+struct S2Fwd {
+    const void* u; const void* delta; const void* z; const float* Bm; const float* Cm;
+    const float* A; const float* D; const float* dbias;
+    void* y;
+    float* hstate;      // (B, nchunks, ED, 16): K1 writes local end states, K2 turns them into chunk-start states, K3 reads
+    float* sdelta;      // (B, nchunks, ED): sum of dt over the chunk (the chunk's decay is exp(A * sum dt): no products)
+    float* ckpt;        // (B, nseg, ED, 16) state at the START of every 32-step segment, or NULL (no backward wanted)
+    int B, L, ED, T, nchunks, softplus, nseg;
+};
+
+// Diagnostic build only (-DGFE_S2_STAMPS, tools/scan_stamps.py): wave 0 of block 0 accumulates s_memtime deltas per phase.
+#ifdef GFE_S2_STAMPS
+__device__ unsigned long long g_s2_stamps[48];
+#define S2_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define S2_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; }
+#define S2_STAMP_FLUSH(base) if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) g_s2_stamps[base + i_] = st_acc[i_]; }
+#else
+#define S2_STAMP_DECL
+#define S2_STAMP(i)
+#define S2_STAMP_FLUSH(base)
+#endif
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: behind a block's global stores and
+// (backward) float atomics -- which stay counted for 600-3000 cycles -- that stalls every wave once per tile for nothing: no global
+// data is exchanged between the waves of a block here, only LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Staging math, branch-free (the generic helpers in common.h compile to nested exec-masked branches around v_log / the series, which at
+// one wave per SIMD cost more than both paths together).  softplus(x) = max(x, 0) + log1p(e), e = exp(-|x|): series below 2^-7 (1 + e
+// would round e away; the reference's dt_proj.bias puts softplus outputs down to 1e-4), v_log above; for x > 20 the result equals x
+// after rounding, which is torch's threshold rule.  sig (optional) = d softplus / dx = sigmoid(x) from the same e.
+__device__ __forceinline__ float softplus_nb(float x, float* sig = nullptr) {
+    const float e = fast_exp2(-fabsf(x) * GFE_LOG2E);
+    const float w1 = 1.0f + e;
+    const float ser = e * fmaf(e, fmaf(e, 0.33333333f, -0.5f), 1.0f);
+    const float lg = __builtin_amdgcn_logf(w1) * GFE_LN2;
+    const float l = e < 0.0078125f ? ser : lg;
+    if (sig) { const float r = fast_rcp(w1); *sig = x >= 0.f ? r : e * r; }
+    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()) + l;
+}
+
+// Sum over the 8 pair-lanes (lane bits 2,3,4) of 8 per-lane values v[0..7]; the lane with pair index p returns the total of v[p].
+// Halving butterfly: bit 4 by v_permlane16_swap (rows of 16 lanes trade registers), bits 3 and 2 by pairs of bank-masked
+// v_add_f32_dpp (row_ror:8; row_shl:4 / row_shr:4): each pair writes the two halves of one result register, so a level costs two
+// instructions per result and needs neither v_cndmask nor copies -- 16 VALU instructions per 8 values.
+// (Inline asm because the masked v_add_dpp has no builtin; the leading s_nop 1 is the VALU-write -> DPP-read hazard, which hipcc does
+// not pad inside or in front of an asm statement.)
+__device__ __forceinline__ float reduce_pairs8(const float (&v)[8]) {
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
+        w[j] = __uint_as_float(x[0]) + __uint_as_float(x[1]);          // rows with bit4 = 0: total of v[j]; bit4 = 1: total of v[j+4]
+    }
+    float x0, x1, r;
+    // lanes 0-7 of a row (bit3 = 0): w[j] + w[j] of lane^8;  lanes 8-15: w[j+2] + w[j+2] of lane^8
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(x0), "=&v"(x1) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+    // banks 0,2 (bit2 = 0): x0 + x0 of lane+4;  banks 1,3 (bit2 = 1): x1 + x1 of lane-4
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    typedef f4 type;
+    static __device__ __forceinline__ void unpack(const type& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ type zero() { return type{0.f, 0.f, 0.f, 0.f}; }
+};
+template <> struct Vec4<bf16_t> {
+    typedef uint2 type;
+    static __device__ __forceinline__ void unpack(const type& v, float (&o)[4]) {
+        o[0] = bf16lo_to_f32(v.x); o[1] = bf16hi_to_f32(v.x); o[2] = bf16lo_to_f32(v.y); o[3] = bf16hi_to_f32(v.y);
+    }
+    static __device__ __forceinline__ type zero() { return make_uint2(0u, 0u); }
+};
+
+// LDS image of one 32-step tile
+struct Tile {
+    float dt[CB * TT];           // [channel][step]  softplus(delta + bias), 0 past the chunk end  (dts_index)
+    float dtu[CB * TT];          // [channel][step]  dt * u
+    float epu[TT * EPS];         // [step][channel]  D * u
+    float epg[TT * EPS];         // [step][channel]  silu(z) (1 without a gate)
+    f4 bc[TT * 8];               // [step][pair]     {B[2p], B[2p+1], C[2p], C[2p+1]}
+};
+
+// One block = 32 channels x one chunk.  STATE_ONLY (K1 of the chunked plan): end state from h = 0 and sum(dt), no output.
+template <typename T, bool STATE_ONLY>
+__global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
+    typedef typename Vec4<T>::type V4;
+    __shared__ __attribute__((aligned(16))) Tile tiles[2];
+    __shared__ __attribute__((aligned(16))) T ytile[2][TT * EPS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
+    const int cl = 8 * w + cw;                                   // channel within the block
+    const int e0 = blockIdx.x * CB, c = blockIdx.y, b = blockIdx.z;
+    const int e = e0 + cl;
+    const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
+    const T* __restrict__ u = (const T*)p.u;
+    const T* __restrict__ dl = (const T*)p.delta;
+    const T* __restrict__ z = (const T*)p.z;
+    T* __restrict__ y = (T*)p.y;
+    const bool has_z = !STATE_ONLY && z != nullptr;
+
+    // staging role of this thread: row sr of the tile, channels 4*sc .. 4*sc+3 of the block
+    const int sr = tid >> 3, sc = tid & 7;
+    float sbias[4], sD[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
+        sD[k] = (!STATE_ONLY && p.D) ? p.D[e0 + 4 * sc + k] : 0.f;
+    }
+    // B / C role: threads 0-127 fetch B, 128-255 fetch C: row (tid & 127) >> 2 of the tile, floats 4q .. 4q+3
+    const int br = (tid & 127) >> 2, bq = tid & 3;
+    const float* __restrict__ bcsrc = (tid < 128) ? p.Bm : p.Cm;
+
+    f2 A2 = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]} * GFE_LOG2E;
+    f2 h = f2{0.f, 0.f};
+    const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
+    if (!STATE_ONLY && p.nchunks > 1) h = *reinterpret_cast<const f2*>(p.hstate + sbase);
+    float sd = 0.f;
+
+    V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero();
+    f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
+    // 64-bit bases once; per tile only a 32-bit row offset (rows past the chunk end: clamped here, masked in park)
+    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;
+    const T* __restrict__ pu = u + rowbase;
+    const T* __restrict__ pd = dl + rowbase;
+    const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
+    const float* __restrict__ pbc = bcsrc + ((size_t)b * p.L + t0) * 16 + 4 * bq;
+    const int nrows = t1 - t0;
+    auto fetch = [&](int tb) {                                    // global -> registers, tile starting at step tb
+        const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
+        ru = *reinterpret_cast<const V4*>(pu + off);
+        rd = *reinterpret_cast<const V4*>(pd + off);
+        if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+        if (!STATE_ONLY || tid < 128) rbc = *reinterpret_cast<const f4*>(pbc + min(tb - t0 + br, nrows - 1) * 16);
+    };
+    auto park = [&](Tile& tl, int tb) {                           // registers -> LDS (the per-(t, channel) math happens once, here)
+        float fu[4], fd[4], fz[4];
+        Vec4<T>::unpack(ru, fu); Vec4<T>::unpack(rd, fd);
+        if (has_z) Vec4<T>::unpack(rz, fz);
+        const bool valid = tb + sr < t1;
+        f4 vu, vg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float raw = fd[k] + sbias[k];
+            float dt = p.softplus ? softplus_nb(raw) : raw;
+            if (!valid) dt = 0.f;                                 // a = exp2(0) = 1, dt*u = 0: steps past the end leave the state alone
+            tl.dt[dts_index(4 * sc + k, sr)] = dt;
+            tl.dtu[dts_index(4 * sc + k, sr)] = dt * fu[k];
+            vu[k] = sD[k] * fu[k];
+            vg[k] = has_z ? siluf_(fz[k]) : 1.f;
+        }
+        if (!STATE_ONLY) {
+            *reinterpret_cast<f4*>(&tl.epu[sr * EPS + 4 * sc]) = vu;
+            *reinterpret_cast<f4*>(&tl.epg[sr * EPS + 4 * sc]) = vg;
+        }
+        float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
+        if (!STATE_ONLY || tid < 128) {
+            const f4 v = (tb + br < t1) ? rbc : f4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
+            *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
+        }
+    };
+
+    fetch(t0);
+    park(tiles[0], t0);
+    lds_barrier();
+    int cur = 0;
+    S2_STAMP_DECL
+    for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
+        const bool more = tb + TT < t1;
+        S2_STAMP(0)
+        if (more) fetch(tb + TT);
+        V4 yrow = Vec4<T>::zero();
+        if (!STATE_ONLY && tb > t0) yrow = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);   // stored below, behind the first group's LDS reads
+        if (!STATE_ONLY && p.ckpt)                                // every tile starts a segment (t0 is a multiple of SEG)
+            *reinterpret_cast<f2*>(p.ckpt + ((((size_t)b * p.nseg + tb / SEG) * p.ED + e) * 16 + 2 * pr)) = h;
+        const Tile& tl = tiles[cur];
+        // One wave per SIMD at B = 8: nothing hides an LDS round trip but the wave's own instruction stream, so the 14 reads of the
+        // next 8-step group are issued before the current group's arithmetic (two register sets, pinned with sched_barrier).
+        struct Grp { f4 dt4[2], du4[2], bc[8]; float epu, epg; };
+        auto load_grp = [&](Grp& G, int g) {
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                G.dt4[j4] = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 8 * g + 4 * j4)]);
+                G.du4[j4] = *reinterpret_cast<const f4*>(&tl.dtu[dts_index(cl, 8 * g + 4 * j4)]);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) G.bc[s] = tl.bc[(8 * g + s) * 8 + pr];
+            if (!STATE_ONLY) { G.epu = tl.epu[(8 * g + pr) * EPS + cl]; G.epg = tl.epg[(8 * g + pr) * EPS + cl]; }
+        };
+        auto run_grp = [&](const Grp& G, int g) {
+            float yv[8];
+            f2 a[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {                          // the decays do not depend on h: all 16 exp first, so that none of the
+                const f2 x = A2 * G.dt4[s >> 2][s & 3];            // transcendental results is wanted right behind its instruction
+                a[s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
+                if (STATE_ONLY) sd += G.dt4[s >> 2][s & 3];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f4 bc = G.bc[s];
+                h = a[s] * h + f2{bc.x, bc.y} * G.du4[s >> 2][s & 3];
+                if (!STATE_ONLY) yv[s] = fmaf(h.y, bc.w, h.x * bc.z);
+            }
+            if (!STATE_ONLY) {
+                const float ys = reduce_pairs8(yv);                // this lane: step 8g + pr of channel cl
+                IO<T>::st(&ytile[cur][(8 * g + pr) * EPS + cl], (ys + G.epu) * G.epg);
+            }
+        };
+        Grp ga, gb;
+        S2_STAMP(1)
+        load_grp(ga, 0);
+        if (!STATE_ONLY && tb > t0)                               // the previous tile's outputs: whole row segments, 4 channels per lane
+            *reinterpret_cast<V4*>(y + rowbase + (size_t)(tb - TT - t0 + sr) * p.ED) = yrow;
+#pragma unroll
+        for (int g = 0; g < TT / 8; g += 2) {
+            load_grp(gb, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            run_grp(ga, g);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < TT / 8) load_grp(ga, g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            run_grp(gb, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        S2_STAMP(2)
+        if (more) park(tiles[cur ^ 1], tb + TT);
+        S2_STAMP(3)
+        lds_barrier();
+        S2_STAMP(4)
+    }
+    S2_STAMP_FLUSH(STATE_ONLY ? 36 : 0)
+    if (STATE_ONLY) {
+        *reinterpret_cast<f2*>(p.hstate + sbase) = h;
+        if (pr == 0) p.sdelta[((size_t)b * p.nchunks + c) * p.ED + e] = sd;
+    } else {
+        const int r = ((t1 - t0 - 1) / TT) * TT + sr;               // the last tile's outputs
+        if (r < nrows) *reinterpret_cast<V4*>(y + rowbase + (size_t)r * p.ED) = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);
+    }
+}
+
+// K2: hstate[b, c, e, n] (local end state of chunk c) -> state at the start of chunk c.  REVERSE: the adjoint carry (chunk c
+// receives from chunk c+1).  One lane per (e, n); loads of 8 chunks are batched ahead of the 8 dependent fma steps.
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void sscan2_carry_kernel(float* __restrict__ hstate, const float* __restrict__ sdelta,
+                                                           const float* __restrict__ A, int ED, int nchunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // e*16 + n
+    const int b = blockIdx.y;
+    if (i >= 16 * ED) return;
+    const int e = i >> 4;
+    const float A2 = A[i] * GFE_LOG2E;
+    float H = 0.f;
+    constexpr int G = 8;
+    for (int k0 = 0; k0 < nchunks; k0 += G) {
+        float loc[G], sdv[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int k = min(k0 + j, nchunks - 1);
+            const int c = REVERSE ? nchunks - 1 - k : k;
+            loc[j] = hstate[((size_t)b * nchunks + c) * ED * 16 + i];
+            sdv[j] = sdelta[((size_t)b * nchunks + c) * ED + e];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (k0 + j < nchunks) {
+                const int c = REVERSE ? nchunks - 1 - (k0 + j) : k0 + j;
+                hstate[((size_t)b * nchunks + c) * ED * 16 + i] = H;
+                H = fmaf(fast_exp2(A2 * sdv[j]), H, loc[j]);
+            }
+        }
+    }
+}
+
+template <typename T>
+int sscan2_fwd_launch(const S2Fwd& p, hipStream_t st) {
+    const dim3 blk(256), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
+    if (p.nchunks > 1) {
+        hipLaunchKernelGGL((sscan2_fwd_kernel<T, true>), grid, blk, 0, st, p);
+        hipLaunchKernelGGL((sscan2_carry_kernel<false>), dim3((unsigned)ceil_div((int64_t)16 * p.ED, 256), p.B), dim3(256), 0, st,
+                           p.hstate, p.sdelta, p.A, p.ED, p.nchunks);
+    }
+    hipLaunchKernelGGL((sscan2_fwd_kernel<T, false>), grid, blk, 0, st, p);
+    return gfe_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+struct S2Bwd {
+    const void* u; const void* delta; const void* z; const float* Bm; const float* Cm; const void* dy;
+    const float* A; const float* D; const float* dbias;
+    void* du; void* ddelta; void* dz;
+    float* dAws;                        // (ED, 16) f32, zeroed, accumulated atomically (once per lane and chunk)
+    float* dBws; float* dCws;           // (B, L, 16) f32, zeroed, accumulated atomically (one 64-lane atomic per two steps and block)
+    float* dDws; float* dbiasws;        // (ED) f32, zeroed
+    const float* ckpt;                  // (B, nseg, ED, 16) segment-start states left by the forward
+    float* qstate;                      // (B, nchunks, ED, 16) adjoint carry (chunked plan only)
+    const float* sdelta;                // (B, nchunks, ED)
+    int B, L, ED, T, nchunks, softplus, nseg;
+};
+
+constexpr int RSL = TT * 32 + 8;   // slab stride: + 8 floats so that the four (channel & 3) slabs of one ds_write_b64 fall on disjoint banks
+struct BTile {
+    float dt[CB * TT];           // [channel][step] (dts_index)  softplus(delta + bias), 0 past the end
+    float dtu[CB * TT];          //                              dt * u
+    float g[CB * TT];            //                              dL/dy_scan = dy * silu(z) (dy without a gate), 0 past the end
+    float eu[TT * EPS];          // [step][channel]: what the lane that owns (step, channel) after the pair butterflies needs
+    float edt[TT * EPS];
+    float esg[TT * EPS];         //   d softplus / d raw = sigmoid(raw) (1 without softplus), 0 past the end
+    float eg[TT * EPS];
+    float egz[TT * EPS];         //   dy * d silu(z)/dz
+    f4 bc[TT * 8];               // [step][pair] {B[2p], B[2p+1], C[2p], C[2p+1]}
+    float red[16 * RSL];         // [wave][channel & 3] slabs of [step][16 dB | 16 dC]: partial sums over the two channels of a wave that share (channel & 3)
+};
+
+// One block = 32 channels x one chunk, segments of 32 steps walked from the chunk's end to its start:
+//   recompute the segment forward from its checkpoint, keeping a_t = exp(dt_t A) and h_t of all 32 steps in registers (a lane owns two
+//   states: 128 registers), then run the adjoint over the same steps -- no exp beyond the recompute's.
+//   Sums over states (d(dt*u), d dt, and y for dz) go through the pair butterflies, sums over channels (dB, dC) through
+//   v_permlane32_swap + quad DPP adds into an LDS slab that the block folds over its waves and adds to memory two steps per atomic.
+// STATE_ONLY (K1' of the chunked plan): only the local adjoint carry q of the chunk from q = 0.
+template <typename T, bool STATE_ONLY>
+__global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
+    typedef typename Vec4<T>::type V4;
+    __shared__ __attribute__((aligned(16))) BTile tl;
+    __shared__ __attribute__((aligned(16))) T otile[3][TT * EPS];       // du, ddelta, dz rows on their way out
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
+    const int cl = 8 * w + cw;
+    const int e0 = blockIdx.x * CB, c = blockIdx.y, b = blockIdx.z;
+    const int e = e0 + cl;
+    const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
+    const T* __restrict__ u = (const T*)p.u;
+    const T* __restrict__ dl = (const T*)p.delta;
+    const T* __restrict__ z = (const T*)p.z;
+    const T* __restrict__ dy = (const T*)p.dy;
+    const bool has_z = z != nullptr;
+
+    const int sr = tid >> 3, sc = tid & 7;
+    float sbias[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
+    const int br = (tid & 127) >> 2, bq = tid & 3;
+    const float* __restrict__ bcsrc = (tid < 128) ? p.Bm : p.Cm;
+
+    const f2 An = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
+    const f2 A2 = An * GFE_LOG2E;
+    const float Dv = p.D ? p.D[e] : 0.f;
+    const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
+    f2 q = f2{0.f, 0.f};
+    if (!STATE_ONLY && p.nchunks > 1) q = *reinterpret_cast<const f2*>(p.qstate + sbase);
+    f2 dAacc = f2{0.f, 0.f};
+    float dDacc = 0.f, dbacc = 0.f;
+
+    V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero(), rg = Vec4<T>::zero();
+    f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
+    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;      // 64-bit bases once; per segment only a 32-bit row offset
+    const T* __restrict__ pu = u + rowbase;
+    const T* __restrict__ pd = dl + rowbase;
+    const T* __restrict__ pg = dy + rowbase;
+    const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
+    const float* __restrict__ pbc = bcsrc + ((size_t)b * p.L + t0) * 16 + 4 * bq;
+    const int nrows = t1 - t0;
+    auto fetch = [&](int tb) {                                    // rows past the end: clamped here, masked in park
+        const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
+        if (!STATE_ONLY) ru = *reinterpret_cast<const V4*>(pu + off);
+        rd = *reinterpret_cast<const V4*>(pd + off);
+        rg = *reinterpret_cast<const V4*>(pg + off);
+        if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+        if (!STATE_ONLY || tid >= 128) rbc = *reinterpret_cast<const f4*>(pbc + min(tb - t0 + br, nrows - 1) * 16);
+    };
+    auto park = [&](int tb) {
+        float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4];
+        if (!STATE_ONLY) Vec4<T>::unpack(ru, fu);
+        Vec4<T>::unpack(rd, fd); Vec4<T>::unpack(rg, fg);
+        if (has_z) Vec4<T>::unpack(rz, fz);
+        const bool valid = tb + sr < t1;
+        f4 vu, vdt, vsg, vg, vgz;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float raw = fd[k] + sbias[k];
+            float sg = 1.f;
+            float dt = softplus_nb(raw, &sg);
+            if (!p.softplus) { dt = raw; sg = 1.f; }
+            float gg = fg[k], gz = 0.f;
+            if (has_z) {
+                const float sz = sigmoidf_(fz[k]);
+                gz = fg[k] * sz * (1.f + fz[k] * (1.f - sz));          // dy * d/dz [z sigmoid(z)]
+                gg = fg[k] * fz[k] * sz;
+            }
+            if (!valid) { dt = 0.f; sg = 0.f; gg = 0.f; gz = 0.f; }
+            const int ix = dts_index(4 * sc + k, sr);
+            tl.dt[ix] = dt;
+            if (!STATE_ONLY) tl.dtu[ix] = dt * fu[k];
+            tl.g[ix] = gg;
+            vu[k] = fu[k]; vdt[k] = dt; vsg[k] = sg; vg[k] = gg; vgz[k] = gz;
+        }
+        if (!STATE_ONLY) {
+            *reinterpret_cast<f4*>(&tl.eu[sr * EPS + 4 * sc]) = vu;
+            *reinterpret_cast<f4*>(&tl.edt[sr * EPS + 4 * sc]) = vdt;
+            *reinterpret_cast<f4*>(&tl.esg[sr * EPS + 4 * sc]) = vsg;
+            *reinterpret_cast<f4*>(&tl.eg[sr * EPS + 4 * sc]) = vg;
+            if (has_z) *reinterpret_cast<f4*>(&tl.egz[sr * EPS + 4 * sc]) = vgz;
+        }
+        float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
+        if (!STATE_ONLY || tid >= 128) {
+            const f4 v = (tb + br < t1) ? rbc : f4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
+            *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
+        }
+    };
+
+    const int nsegc = (t1 - t0 + TT - 1) / TT;
+    fetch(t0 + (nsegc - 1) * TT);
+    // the segment's start state: fetched one segment ahead too (wanted by the very first instruction of phase 1: an HBM round trip there
+    // cost 1 300 cycles per segment)
+    const float* __restrict__ pck = STATE_ONLY ? nullptr : p.ckpt + (((size_t)b * p.nseg + t0 / SEG) * p.ED + e) * 16 + 2 * pr;
+    const size_t ckstride = (size_t)p.ED * 16;
+    f2 hck_next = f2{0.f, 0.f};
+    if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(nsegc - 1) * ckstride);
+    S2_STAMP_DECL
+    for (int k = nsegc - 1; k >= 0; --k) {
+        const int tb = t0 + k * TT;
+        S2_STAMP(0)
+        park(tb);
+        S2_STAMP(1)
+        lds_barrier();
+        S2_STAMP(2)
+        const f2 hck = hck_next;
+        if (k > 0) {
+            fetch(tb - TT);
+            if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(k - 1) * ckstride);
+        }
+        S2_STAMP(7)
+
+        if (STATE_ONLY) {
+#pragma unroll
+            for (int j4 = TT / 4 - 1; j4 >= 0; --j4) {
+                const f4 dt4 = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 4 * j4)]);
+                const f4 g4 = *reinterpret_cast<const f4*>(&tl.g[dts_index(cl, 4 * j4)]);
+#pragma unroll
+                for (int s = 3; s >= 0; --s) {
+                    const f4 bc = tl.bc[(4 * j4 + s) * 8 + pr];
+                    const f2 x = A2 * dt4[s];
+                    const f2 a = f2{fast_exp2(x.x), fast_exp2(x.y)};
+                    q = a * (f2{bc.z, bc.w} * g4[s] + q);
+                }
+            }
+            lds_barrier();
+            continue;
+        }
+
+        // ---- phase 1: the segment's states, forward from the checkpoint; phase 2: the adjoint, last step first.
+        // Work unit = 4 steps.  As in the forward, the LDS reads of the NEXT unit are issued ahead of the current unit's arithmetic (one
+        // wave per SIMD: nothing else hides the round trip): two register sets X / Y by unit parity, pinned with sched_barrier.
+        f2 av[TT], hs[TT];
+        float yred[TT / 8];
+        struct H4 { f4 dt4, du4, g4, bc[4]; };
+        auto load_u = [&](H4& H, int qd) {
+            H.dt4 = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 4 * qd)]);
+            H.du4 = *reinterpret_cast<const f4*>(&tl.dtu[dts_index(cl, 4 * qd)]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) H.bc[s] = tl.bc[(4 * qd + s) * 8 + pr];
+        };
+        auto load_g = [&](H4& H, int qd) { H.g4 = *reinterpret_cast<const f4*>(&tl.g[dts_index(cl, 4 * qd)]); };
+        f2 h = hck;
+        float yv[8];
+        auto fwd_u = [&](const H4& H, int qd) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int t = 4 * qd + s;
+                const f4 bc = H.bc[s];
+                const f2 x = A2 * H.dt4[s];
+                av[t] = f2{fast_exp2(x.x), fast_exp2(x.y)};
+                h = av[t] * h + f2{bc.x, bc.y} * H.du4[s];
+                hs[t] = h;
+                if (has_z) yv[4 * (qd & 1) + s] = fmaf(h.y, bc.w, h.x * bc.z);
+            }
+            if (qd & 1) yred[qd >> 1] = has_z ? reduce_pairs8(yv) : 0.f;     // owner: step 8*(qd/2) + pr of channel cl
+        };
+        struct Own { float u, dt, sg, g, gz; };
+        auto load_own = [&](Own& O, int g8) {
+            const int r = 8 * g8 + pr;
+            O.u = tl.eu[r * EPS + cl]; O.dt = tl.edt[r * EPS + cl]; O.sg = tl.esg[r * EPS + cl]; O.g = tl.eg[r * EPS + cl];
+            O.gz = has_z ? tl.egz[r * EPS + cl] : 0.f;
+        };
+        float ddtu_p[8], ddt_p[8];
+        auto bwd_u = [&](const H4& H, const Own& O, int qd) {
+#pragma unroll
+            for (int s = 3; s >= 0; --s) {
+                const int t = 4 * qd + s;
+                const f4 bc = H.bc[s];
+                const f2 Bv = f2{bc.x, bc.y}, Cv = f2{bc.z, bc.w};
+                const float gt = H.g4[s], dtv = H.dt4[s], dtu = H.du4[s];
+                const f2 dh = Cv * gt + q;
+                const f2 dC = hs[t] * gt;
+                const f2 dB = dh * dtu;
+                ddtu_p[4 * (qd & 1) + s] = fmaf(dh.y, Bv.y, dh.x * Bv.x);
+                const f2 hp = (t == 0) ? hck : hs[t == 0 ? 0 : t - 1];
+                q = av[t] * dh;
+                const f2 da = q * hp;                                      // dL/d(dt*A) of this (t, pair) = dh * a * h_{t-1}
+                dAacc += da * dtv;
+                ddt_p[4 * (qd & 1) + s] = fmaf(da.y, An.y, da.x * An.x);
+                // dB / dC sum over channels.  In the wave: v_permlane32_swap pairs dB with dC (lanes < 32 end up with the dB sum over lane
+                // bit 5, lanes >= 32 with the dC sum).  The remaining 4 (channel & 3) x 4 (wave) partials are folded by the block from LDS
+                // below: every lane stores, so there is no exec masking and no basic-block break inside the unrolled steps.
+                // (ds_add_f32 into one shared row instead was 15x slower: ~900 cycles per instruction with 4 lanes per address.)
+                const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.x), __float_as_uint(dC.x), false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.y), __float_as_uint(dC.y), false, false);
+                *reinterpret_cast<f2*>(&tl.red[(w * 4 + (lane & 3)) * RSL + t * 32 + (lane >> 5) * 16 + 2 * pr]) =
+                    f2{__uint_as_float(sx[0]) + __uint_as_float(sx[1]), __uint_as_float(sy[0]) + __uint_as_float(sy[1])};
+            }
+            if ((qd & 1) == 0) {                                           // group complete: the lane that owns (step r, channel cl) finishes it
+                const float ddtu = reduce_pairs8(ddtu_p);
+                const float ddtA = reduce_pairs8(ddt_p);
+                const int r = 4 * qd + pr;
+                const float dd = fmaf(ddtu, O.u, ddtA) * O.sg;
+                IO<T>::st(&otile[0][r * EPS + cl], fmaf(ddtu, O.dt, Dv * O.g));
+                IO<T>::st(&otile[1][r * EPS + cl], dd);
+                if (has_z) IO<T>::st(&otile[2][r * EPS + cl], O.gz * fmaf(Dv, O.u, yred[qd >> 1]));
+                dDacc = fmaf(O.g, O.u, dDacc);
+                dbacc += dd;
+            }
+        };
+#define SB __builtin_amdgcn_sched_barrier(0)
+        {
+            H4 X, Y;
+            Own oa, ob;
+            load_u(X, 0); SB;
+            load_u(Y, 1); SB; fwd_u(X, 0); SB;
+            load_u(X, 2); SB; fwd_u(Y, 1); SB;
+            load_u(Y, 3); SB; fwd_u(X, 2); SB;
+            load_u(X, 4); SB; fwd_u(Y, 3); SB;
+            S2_STAMP(8)
+            load_u(Y, 5); SB; fwd_u(X, 4); SB;
+            load_u(X, 6); SB; fwd_u(Y, 5); SB;
+            load_u(Y, 7); load_g(Y, 7); SB; fwd_u(X, 6); SB;
+            load_g(X, 6); load_own(oa, 3); SB; fwd_u(Y, 7); SB;
+            S2_STAMP(3)
+            bwd_u(Y, oa, 7); SB;
+            load_u(Y, 5); load_g(Y, 5); SB; bwd_u(X, oa, 6); SB;
+            load_u(X, 4); load_g(X, 4); load_own(ob, 2); SB; bwd_u(Y, ob, 5); SB;
+            load_u(Y, 3); load_g(Y, 3); SB; bwd_u(X, ob, 4); SB;
+            S2_STAMP(9)
+            load_u(X, 2); load_g(X, 2); load_own(oa, 1); SB; bwd_u(Y, oa, 3); SB;
+            load_u(Y, 1); load_g(Y, 1); SB; bwd_u(X, oa, 2); SB;
+            load_u(X, 0); load_g(X, 0); load_own(ob, 0); SB; bwd_u(Y, ob, 1); SB;
+            bwd_u(X, ob, 0);
+        }
+#undef SB
+        S2_STAMP(4)
+        lds_barrier();
+        S2_STAMP(5)
+        // ---- rows out, and the block's dB / dC rows.  Wave w folds the 16 partial slabs for steps 8w .. 8w+7 with ds_read_b128, writes
+        // the sums back as rows of 32 (its own rows: no barrier, only its own lgkmcnt) and adds them to memory as contiguous 64-lane
+        // atomics -- two steps x (16 dB | 16 dC) per instruction, the access shape float atomics run at full rate on.
+        {
+            const int r = tb - t0 + sr;
+            if (r < nrows) {
+                const size_t off = rowbase + (size_t)r * p.ED;
+                *reinterpret_cast<V4*>((T*)p.du + off) = *reinterpret_cast<const V4*>(&otile[0][sr * EPS + 4 * sc]);
+                *reinterpret_cast<V4*>((T*)p.ddelta + off) = *reinterpret_cast<const V4*>(&otile[1][sr * EPS + 4 * sc]);
+                if (has_z) *reinterpret_cast<V4*>((T*)p.dz + off) = *reinterpret_cast<const V4*>(&otile[2][sr * EPS + 4 * sc]);
+            }
+            const int ts = 8 * w + (lane >> 3), jq = (lane & 7) * 4;
+            f4 acc = *reinterpret_cast<const f4*>(&tl.red[ts * 32 + jq]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) acc += *reinterpret_cast<const f4*>(&tl.red[k * RSL + ts * 32 + jq]);
+            *reinterpret_cast<f4*>(&tl.red[ts * 32 + jq]) = acc;          // slab 0, this wave's rows only
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = lane + 64 * i, t2 = 8 * w + (v >> 5), j = v & 31;
+                const float sum = tl.red[t2 * 32 + j];
+                if (tb + t2 < t1) atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * 16 + (j & 15), sum);
+            }
+        }
+        // (the next park() only touches the staging arrays; its barrier orders these reads of otile / red before the next writes)
+        S2_STAMP(6)
+    }
+    S2_STAMP_FLUSH(16)
+    if (STATE_ONLY) {
+        *reinterpret_cast<f2*>(p.qstate + sbase) = q;
+        return;
+    }
+    atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr, dAacc.x);
+    atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr + 1, dAacc.y);
+    // dD / dbias: the 8 owner lanes of a channel (pair bits 2, 3, 4) hold partial sums over their steps
+    dDacc += __shfl_xor(dDacc, 4, 64); dbacc += __shfl_xor(dbacc, 4, 64);
+    dDacc += __shfl_xor(dDacc, 8, 64); dbacc += __shfl_xor(dbacc, 8, 64);
+    dDacc += __shfl_xor(dDacc, 16, 64); dbacc += __shfl_xor(dbacc, 16, 64);
+    if (pr == 0) {
+        if (p.dDws) atomicAdd(p.dDws + e, dDacc);
+        if (p.dbiasws) atomicAdd(p.dbiasws + e, dbacc);
+    }
+}
+
+template <typename T>
+int sscan2_bwd_launch(const S2Bwd& p, hipStream_t st) {
+    const dim3 blk(256), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
+    if (p.nchunks > 1) {
+        hipLaunchKernelGGL((sscan2_bwd_kernel<T, true>), grid, blk, 0, st, p);
+        hipLaunchKernelGGL((sscan2_carry_kernel<true>), dim3((unsigned)ceil_div((int64_t)16 * p.ED, 256), p.B), dim3(256), 0, st,
+                           p.qstate, p.sdelta, p.A, p.ED, p.nchunks);
+    }
+    hipLaunchKernelGGL((sscan2_bwd_kernel<T, false>), grid, blk, 0, st, p);
+    return gfe_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out, int* nchunks_out) {
+    GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && ED % CB == 0 && T_out && nchunks_out, GFE_ERR_SHAPE);
+    int64_t T = L;
+    if (chunk_req > 0) {
+        T = ceil_div(chunk_req, SEG) * SEG;                       // chunk starts must be checkpoint positions
+    } else {
+        const int64_t waves = B * (ED / 8);                       // one wave = 8 channels x 8 state pairs
+        if (waves < 768) {                                        // cannot fill 1024 SIMDs: cut L (two passes + carry)
+            const int64_t want = ceil_div(1024, waves);
+            T = ceil_div(ceil_div(L, want), SEG) * SEG;
+            if (T < 64) T = 64;
+        }
+    }
+    if (T > L) T = L;
+    *T_out = (int)T;
+    *nchunks_out = (int)ceil_div(L, T);
+    return GFE_OK;
+}
+
+int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
+                   const float* D, const void* z, const float* delta_bias, void* y,
+                   float* hstate, float* sdelta, float* ckpt,
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, void* stream) {
+    GFE_REQUIRE(u && delta && A && Bm && Cm && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
+    S2Fwd p;
+    p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y;
+    p.hstate = hstate; p.sdelta = sdelta; p.ckpt = ckpt;
+    p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
+    p.nseg = (int)ceil_div(L, SEG);
+    GFE_REQUIRE(p.nchunks <= 65535, GFE_ERR_SHAPE);
+    GFE_REQUIRE(p.nchunks == 1 || (hstate && sdelta && T % SEG == 0), GFE_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GFE_F32) return sscan2_fwd_launch<float>(p, st);
+    if (dtype == GFE_BF16) return sscan2_fwd_launch<bf16_t>(p, st);
+    return GFE_ERR_DTYPE;
+}
+
+int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
+                   const float* D, const void* z, const float* delta_bias, const void* dy,
+                   void* du, void* ddelta, void* dz,
+                   float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
+                   const float* ckpt, float* qstate, const float* sdelta,
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, void* stream) {
+    GFE_REQUIRE(u && delta && A && Bm && Cm && dy && du && ddelta && dA_ws && dB_ws && dC_ws && ckpt, GFE_ERR_NULL);
+    GFE_REQUIRE(!z || dz, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
+    S2Bwd p;
+    p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.dy = dy; p.A = A; p.D = D; p.dbias = delta_bias;
+    p.du = du; p.ddelta = ddelta; p.dz = dz; p.dAws = dA_ws; p.dBws = dB_ws; p.dCws = dC_ws; p.dDws = dD_ws; p.dbiasws = dbias_ws;
+    p.ckpt = ckpt; p.qstate = qstate; p.sdelta = sdelta;
+    p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
+    p.nseg = (int)ceil_div(L, SEG);
+    GFE_REQUIRE(p.nchunks <= 65535, GFE_ERR_SHAPE);
+    GFE_REQUIRE(p.nchunks == 1 || (qstate && sdelta && T % SEG == 0), GFE_ERR_SHAPE);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GFE_F32) return sscan2_bwd_launch<float>(p, st);
+    if (dtype == GFE_BF16) return sscan2_bwd_launch<bf16_t>(p, st);
+    return GFE_ERR_DTYPE;
+}
+
+#ifdef GFE_S2_STAMPS
+int gfe_dbg_s2_stamps(unsigned long long* host_out) { return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_s2_stamps), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -4; }
+#endif
+
+}  // extern "C"

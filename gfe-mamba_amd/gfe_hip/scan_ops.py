@@ -5,6 +5,7 @@
 `pscan`              : drop-in for cross_atten/pscan.py:226
 """
 import ctypes
+import os
 
 import torch
 
@@ -26,6 +27,70 @@ def _common_dtype(*ts):
 
 def _f32c(t):
     return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def sscan2_plan(B, L, ED, chunk=0):
+    T, nc = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib().gfe_sscan2_plan(B, L, ED, int(chunk), ctypes.byref(T), ctypes.byref(nc))
+    if rc != 0:
+        raise ValueError(f"gfe_sscan2_plan: unsupported shape B={B} L={L} ED={ED}")
+    return T.value, nc.value
+
+
+def _al16(t):
+    """The single-pass kernels move rows as 8/16-byte vectors: a contiguous view at an odd storage offset is copied once."""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
+
+
+class _SelectiveScan2(torch.autograd.Function):
+    """N = 16: csrc/sscan2.hip (a lane owns one channel x one pair of states; chunked along L only for small batches)."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk, need_grad):
+        Bsz, L, ED = u.shape
+        dt = _common_dtype(u, delta, Bm, Cm, z)
+        cast = lambda t: None if t is None else _al16(t.detach().to(dt).contiguous())
+        u_, d_, z_ = cast(u), cast(delta), cast(z)
+        B_, C_ = _al16(_f32c(Bm)), _al16(_f32c(Cm))
+        A_, D_, b_ = _f32c(A), _f32c(D), _f32c(delta_bias)
+        T, nc = sscan2_plan(Bsz, L, ED, chunk)
+        dev = u.device
+        hstate = sdelta = ckpt = None
+        if nc > 1:
+            hstate = torch.empty((Bsz, nc, ED, 16), device=dev, dtype=torch.float32)
+            sdelta = torch.empty((Bsz, nc, ED), device=dev, dtype=torch.float32)
+        if need_grad:
+            ckpt = torch.empty((Bsz, -(-L // 32), ED, 16), device=dev, dtype=torch.float32)
+        y = torch.empty((Bsz, L, ED), device=dev, dtype=dt)
+        call("gfe_sscan2_fwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(y),
+             ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, int(bool(delta_softplus)), dtype_code(dt), stream())
+        ctx.save_for_backward(u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta)
+        ctx.meta = (T, nc, bool(delta_softplus), dt,
+                    tuple(None if t is None else t.dtype for t in (u, delta, A, Bm, Cm, D, z, delta_bias)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta = ctx.saved_tensors
+        T, nc, softplus, dt, in_dtypes = ctx.meta
+        Bsz, L, ED = u_.shape
+        dev = u_.device
+        dy_ = _al16(dy.to(dt).contiguous())
+        du = torch.empty_like(u_)
+        dd = torch.empty_like(u_)
+        dz = torch.empty_like(u_) if z_ is not None else None
+        sizes = [ED * 16, Bsz * L * 16, Bsz * L * 16, ED, ED]                   # one zeroed f32 slab for every atomically accumulated gradient
+        slab = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        dA_ws, dB_ws, dC_ws, dD_ws, db_ws = torch.split(slab, sizes)
+        qstate = torch.empty((Bsz, nc, ED, 16), device=dev, dtype=torch.float32) if nc > 1 else None
+        call("gfe_sscan2_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_),
+             ptr(du), ptr(dd), ptr(dz), ptr(dA_ws), ptr(dB_ws), ptr(dC_ws),
+             ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
+             ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), stream())
+        to = lambda g, i: None if in_dtypes[i] is None else g.to(in_dtypes[i])
+        return (to(du, 0), to(dd, 1), to(dA_ws.view(ED, 16), 2), to(dB_ws.view(Bsz, L, 16), 3), to(dC_ws.view(Bsz, L, 16), 4),
+                to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,
+                to(db_ws, 7) if b_ is not None else None, None, None, None)
 
 
 class _SelectiveScanTM(torch.autograd.Function):
@@ -88,6 +153,8 @@ def selective_scan_tm(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delt
     # the backward needs chunk-start states every <= 32 steps (LDS checkpoints); a forward that autograd does not record
     # (inference, torch.no_grad) uses coarse chunks instead and saves the state traffic
     need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
+    if A.shape[1] == 16 and u.shape[2] % 32 == 0 and os.environ.get("GFE_SSCAN_LEGACY") != "1":
+        return _SelectiveScan2.apply(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk, need_grad)
     return _SelectiveScanTM.apply(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, chunk, need_grad)
 
 

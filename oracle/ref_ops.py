@@ -63,9 +63,10 @@ def selective_scan(x, delta, A, B, C, D):
     BX = delta.unsqueeze(-1) * B.unsqueeze(2) * x.unsqueeze(-1)      # mamba.py:276-278 / 301-303
     h = torch.zeros(x.shape[0], x.shape[2], A.shape[1], dtype=deltaA.dtype)
     ys = []
-    for t in range(x.shape[1]):                                      # mamba.py:308-310
-        h = deltaA[:, t] * h + BX[:, t]
-        ys.append((h * C[:, t].unsqueeze(1)).sum(-1))                # mamba.py:314 (hs @ C)
+    # (unbind instead of [:, t]: the same values, but autograd's backward of a per-step slice allocates a full-size zero tensor per step)
+    for a_t, bx_t, c_t in zip(deltaA.unbind(1), BX.unbind(1), C.unbind(1)):   # mamba.py:308-310
+        h = a_t * h + bx_t
+        ys.append((h * c_t.unsqueeze(1)).sum(-1))                    # mamba.py:314 (hs @ C)
     return torch.stack(ys, 1) + D * x                                # mamba.py:316
 
 

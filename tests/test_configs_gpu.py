@@ -1,0 +1,221 @@
+"""GPU parity at BASELINE.json's own configurations, and exact-integer checks of the index transforms the HIP path performs inside
+its kernels:
+
+  * config 2 (L=4096, ED=1024, N=16) BACKWARD of the fused selective scan against the oracle on a channel slab, f32 and bf16 I/O;
+  * config 4 (128^3, batch 2) generator forward against the oracle;
+  * config 3/5's per-GPU batch (8 volumes of 96^3): every sample equals its own batch-of-one run (tile ranges / GroupNorm slots);
+  * patchify / un-patchify inside `gfe_layernorm` and the nearest-resize duplicate plane inside the transposed conv as EXACT integer
+    maps against the reference-generated index fixtures."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, rel_err, tt
+from oracle import ref_ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# config 2: backward at the benchmark shape
+# ---------------------------------------------------------------------------------------------------------------------------
+def _config2_inputs(dtype, B=1, L=4096, ED=1024, N=16, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(B, L, ED, generator=g)
+    draw = torch.randn(B, L, ED, generator=g) * 0.1
+    dt = torch.exp(torch.rand(ED, generator=g) * (np.log(0.1) - np.log(0.001)) + np.log(0.001)).clamp(min=1e-4)
+    bias = dt + torch.log(-torch.expm1(-dt))                                      # mamba.py:150-155
+    A = -(torch.arange(1, N + 1, dtype=torch.float32)).repeat(ED, 1)              # mamba.py:160-161, 232
+    Bm, Cm = torch.randn(B, L, N, generator=g), torch.randn(B, L, N, generator=g)
+    D = torch.ones(ED)
+    z = torch.randn(B, L, ED, generator=g)
+    dy = torch.randn(B, L, ED, generator=g)
+    r = lambda t: t.to(dtype).float()                                              # what both sides see after the I/O rounding
+    return dict(u=r(u), draw=r(draw), A=A, Bm=r(Bm), Cm=r(Cm), D=D, z=r(z), bias=bias, dy=r(dy))
+
+
+def _gpu_scan_grads(i, dtype, sl=slice(None)):
+    from gfe_hip.scan_ops import selective_scan_tm
+    lp = lambda t: t[..., sl].to(dtype).to(DEV).requires_grad_(True)
+    u, draw, z = lp(i["u"]), lp(i["draw"]), lp(i["z"])
+    Bm, Cm = i["Bm"].to(dtype).to(DEV).requires_grad_(True), i["Cm"].to(dtype).to(DEV).requires_grad_(True)
+    A, D, bias = (i[k][sl].to(DEV).requires_grad_(True) for k in ("A", "D", "bias"))
+    y = selective_scan_tm(u, draw, A, Bm, Cm, D, z=z, delta_bias=bias, delta_softplus=True)
+    y.backward(i["dy"][..., sl].to(dtype).to(DEV))
+    return dict(y=y, u=u.grad, draw=draw.grad, z=z.grad, A=A.grad, D=D.grad, bias=bias.grad, Bm=Bm.grad, Cm=Cm.grad)
+
+
+def _oracle_scan_grads(i, sl):
+    d = lambda t: t.double().requires_grad_(True)
+    u, draw, z = d(i["u"][..., sl]), d(i["draw"][..., sl]), d(i["z"][..., sl])
+    A, D, bias, Bm, Cm = d(i["A"][sl]), d(i["D"][sl]), d(i["bias"][sl]), d(i["Bm"]), d(i["Cm"])
+    y = O.selective_scan(u, F.softplus(draw + bias), A, Bm, Cm, D) * F.silu(z)          # mamba.py:254-259 + 220-222
+    y.backward(i["dy"][..., sl].double())
+    return dict(y=y.detach(), u=u.grad, draw=draw.grad, z=z.grad, A=A.grad, D=D.grad, bias=bias.grad, Bm=Bm.grad, Cm=Cm.grad)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-2)])
+def test_config2_backward_vs_oracle_on_a_channel_slab(dtype, tol):
+    """The whole (1, 4096, 1024, 16) problem runs on the GPU (the auto-chunked kernels with their carries and checkpoints); the
+    oracle (sequential definition, fp64, autograd) runs on 64 of the channels.  Per-channel gradients (du, ddelta, dz, dA, dD,
+    dbias) of that slab are compared directly; dB / dC sum over channels, so they are compared on a GPU run restricted to the slab,
+    and the full run's dB / dC against the sum of the 16 slab runs (additivity over channels)."""
+    i = _config2_inputs(dtype)
+    sl = slice(448, 512)
+    full = _gpu_scan_grads(i, dtype)
+    ref = _oracle_scan_grads(i, sl)
+    errs = {"y": rel_err(full["y"][..., sl], ref["y"])}
+    for k in ("u", "draw", "z"):
+        errs[k] = rel_err(full[k][..., sl], ref[k])
+    for k in ("A", "D", "bias"):
+        errs[k] = rel_err(full[k][sl], ref[k])
+    slab = _gpu_scan_grads(i, dtype, sl)
+    for k in ("Bm", "Cm"):
+        errs[k + "_slab"] = rel_err(slab[k], ref[k])
+    acc = {k: torch.zeros_like(full[k], dtype=torch.float64) for k in ("Bm", "Cm")}
+    for s in range(0, 1024, 64):
+        part = slab if s == sl.start else _gpu_scan_grads(i, dtype, slice(s, s + 64))
+        for k in acc:
+            acc[k] += part[k].double()
+    for k in acc:
+        errs[k + "_additive"] = rel_err(full[k], acc[k])
+    print("config-2 backward rel errors (%s): %s" % (str(dtype).split(".")[-1], {k: "%.2e" % v for k, v in errs.items()}))
+    for k, v in errs.items():
+        assert v < tol, (k, v)
+
+
+def test_config2_batch8_matches_batch1_runs():
+    """B=8 at the benchmark shape (a different chunking plan than B=1): sample 3 of the batch against its own batch-of-one run."""
+    i = _config2_inputs(torch.bfloat16, B=8, seed=3)
+    full = _gpu_scan_grads(i, BF)
+    one = _gpu_scan_grads({k: (v[3:4] if v.dim() == 3 else v) for k, v in i.items()}, BF)
+    for k in ("y", "u", "draw", "z", "Bm", "Cm"):
+        assert rel_err(full[k][3:4], one[k]) < 1e-2, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# config 4 and the per-GPU batch of configs 3 / 5
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_config4_generator_128_cubed_batch2_vs_oracle():
+    """BASELINE config 4: Residual_mid_UNet3D_vit forward on 2 volumes of 128^3 (main_gan_vit.py:69) against the oracle (torch CPU
+    fp32) on the same deterministic weights."""
+    import gfe_hip.det_init as det
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    vol = (128, 128, 128)
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(64, 128, 256), vol_size=vol)
+    sd = det.det_state_dict(gen.state_dict(), seed=32, prefix="gen128.")
+    gen.load_state_dict(sd)
+    gen = gen.to(DEV).eval()
+    x = det.det_inputs(2, vol, seed=6)[0]
+    with torch.no_grad():
+        mi, mo, pet = gen(x.to(DEV), output_vit_mid=True)
+        pet_only = gen(x.to(DEV))                                                   # the call main_gan_vit.py makes
+        omi, omo, opet = O.generator(x, {k: v.float() for k, v in sd.items()})
+    e = (rel_err(mi, omi), rel_err(mo, omo), rel_err(pet, opet), rel_err(pet_only, opet))
+    print("config-4 rel errors (mid_input, mid_output, pet, pet via output_vit_mid=False): %.2e %.2e %.2e %.2e" % e)
+    assert tuple(pet.shape) == (2, 1, 128, 128, 128) and tuple(mi.shape) == (2, 256, 256, 128)
+    assert e[0] < 2e-2 and e[1] < 3e-2 and e[2] < 3e-2 and e[3] < 3e-2, e
+
+
+def test_batch8_at_96_cubed_equals_eight_batch1_runs():
+    """Config 3 / 5's per-GPU share: the persistent kernels' tile ranges and GroupNorm statistic slots depend on B.  Every sample of
+    a batch of 8 must come out as in a batch of one (bf16 rounding flips from the atomically accumulated fold only)."""
+    from gfe_hip.step import build_models
+    import gfe_hip.det_init as det
+    gen, head, ft = build_models(vol=(96, 96, 96), seed=0)
+    x, x_cat, x_num, _ = det.det_inputs(8, (96, 96, 96), seed=77)
+    x = x.to(DEV)
+    with torch.no_grad():
+        mi8, mo8, pet8 = gen(x, output_vit_mid=True)
+        mi8, mo8, pet8 = mi8.float().clone(), mo8.float().clone(), pet8.clone()
+        worst = [0.0, 0.0, 0.0]
+        for b in range(8):
+            mi, mo, pet = gen(x[b:b + 1], output_vit_mid=True)
+            for j, (a, r) in enumerate(((mi8[b:b + 1], mi), (mo8[b:b + 1], mo), (pet8[b:b + 1], pet))):
+                worst[j] = max(worst[j], rel_err(a, r))
+    print("batch-8 vs batch-1 rel differences (mid_input, mid_output, pet): %.2e %.2e %.2e" % tuple(worst))
+    assert worst[0] < 5e-3 and worst[1] < 1e-2 and worst[2] < 1e-2, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# index transforms inside the kernels, as exact integer maps
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ln_rows_to_ints(rows_out, expected_ints):
+    """LayerNorm(gamma=1, beta=0) is an increasing affine map of each row; undo it with the row's own mean / std (from the
+    expected integers) and round: the integers the kernel gathered, exactly."""
+    e = expected_ints.double()
+    mean, var = e.mean(-1, keepdim=True), e.var(-1, unbiased=False, keepdim=True)
+    return torch.round(rows_out.double().cpu() * torch.sqrt(var + 1e-5) + mean).long()
+
+
+def test_patchify_inside_layernorm_is_the_reference_index_map():
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:96) is folded into gfe_layernorm's addressing (nn_ops.patch_map): feed the
+    image whose voxel values ARE their NCHW linear indices (0..255: exact in bf16 and f32) and recover the gathered indices."""
+    from gfe_hip import nn_ops as K
+    fx = golden("t0_index_maps.npz")["patchify_c2_16x8_p4"]                          # (8 patches, 32) int64, made by the reference's rearrange
+    C, Hi, Wi, p = 2, 16, 8, 4
+    img = torch.arange(C * Hi * Wi, dtype=torch.float32).view(1, C, Hi, Wi)
+    cl = img.permute(0, 2, 3, 1).contiguous()                                        # channels-last, as the generator holds it
+    ones, zeros = torch.ones(p * p * C, device=DEV), torch.zeros(p * p * C, device=DEV)
+    for dt in (torch.float32, BF):
+        rows = K.layernorm(cl.to(dt).to(DEV), ones, zeros, 8, p * p * C, torch.float32, in_map=K.patch_map(Hi, Wi, C, p))
+        assert torch.equal(_ln_rows_to_ints(rows, tt(fx)), tt(fx)), dt
+    # un-patchify (vit.py:109): rows (h w) x (p1 p2 c) scattered back into the image through out_map
+    tok = tt(fx).float().to(DEV)                                                     # row r holds the indices patch r came from
+    back = K.layernorm(tok, ones, zeros, 8, p * p * C, torch.float32, out_map=K.patch_map(Hi, Wi, C, p), out_shape=(1, Hi, Wi, C))
+    mean = tt(fx).double().mean(-1)
+    std = torch.sqrt(tt(fx).double().var(-1, unbiased=False) + 1e-5)
+    # voxel with NCHW index v lies in patch r(v); its value must be (v - mean_r) / std_r
+    r_of = torch.empty(C * Hi * Wi, dtype=torch.long)
+    for r in range(8):
+        r_of[tt(fx)[r]] = r
+    v = torch.arange(C * Hi * Wi)
+    want = ((v.double() - mean[r_of]) / std[r_of]).view(1, C, Hi, Wi).permute(0, 2, 3, 1)
+    assert torch.equal(torch.round(back.double().cpu() * std[r_of].view(1, C, Hi, Wi).permute(0, 2, 3, 1)
+                                   + mean[r_of].view(1, C, Hi, Wi).permute(0, 2, 3, 1)).long(),
+                       v.view(1, C, Hi, Wi).permute(0, 2, 3, 1))
+    assert (back.double().cpu() - want).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 64), (32, 16)])
+def test_nearest_resize_duplicate_plane_inside_the_transposed_conv_is_exact(cin, cout, monkeypatch):
+    """ConvTranspose3d(k3 s2 p1) gives 2n-1 planes; F.interpolate(mode='nearest') to 2n duplicates the FIRST one: dst j <- src
+    max(j-1, 0) (buildingblocks.py:523-537; fixture nearest_idx_n generated by the reference's own call).  With a centre-tap
+    identity weight the transposed conv is up[2i] = x[i], up[odd] = 0, so the fused kernel's output must be exactly
+    x[idx[j] / 2] where idx[j] is even and 0 elsewhere -- checked per axis with the coordinate stored in its own channel."""
+    from pytorch3dunet.unet3d.buildingblocks import TransposeConvUpsampling
+    store = golden("t0_unet_ops.npz")                                                # nearest_idx_n: the reference's F.interpolate on arange(2n-1)
+    D, H, W = 3, 4, 12
+    up = TransposeConvUpsampling(cin, cout).to(DEV)
+    w = torch.zeros(cin, cout, 3, 3, 3)
+    for c in range(3):
+        w[c, c, 1, 1, 1] = 1.0
+    with torch.no_grad():
+        up.upsample.conv_transposed.weight.copy_(w)
+    x = torch.zeros(1, D, H, W, cin)
+    dd, hh, ww = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    x[0, ..., 0], x[0, ..., 1], x[0, ..., 2] = dd.float() + 1, hh.float() + 1, ww.float() + 1      # +1: distinguishes plane 0 from "no tap"
+    skip = torch.zeros(1, 2 * D, 2 * H, 2 * W, cout)
+    variants = [False, True] if cin == 128 else [False]
+    for streamed in variants:
+        if streamed:
+            monkeypatch.setenv("GFE_CONVT_STREAMED", "1")
+        with torch.no_grad():
+            y = up(skip.to(BF).to(DEV), x.to(BF).to(DEV)).float().cpu()
+        if streamed:
+            monkeypatch.delenv("GFE_CONVT_STREAMED")
+        for axis, n in ((0, D), (1, H), (2, W)):
+            idx = store[f"nearest_idx_{n}"]                                          # dst j <- src idx[j] of the (2n-1)-plane tensor
+            src_is_tap = (idx % 2 == 0)                                              # even planes carry x[idx/2], odd planes are 0
+            want_axis = torch.from_numpy(np.where(src_is_tap, idx // 2 + 1, 0)).float()
+            # a voxel is non-zero only if all three of its source planes are taps
+            taps = [torch.from_numpy(store[f"nearest_idx_{m}"] % 2 == 0) for m in (D, H, W)]
+            mask = taps[0].view(-1, 1, 1) & taps[1].view(1, -1, 1) & taps[2].view(1, 1, -1)
+            shape = [1, 1, 1]
+            shape[axis] = -1
+            want = want_axis.view(shape).expand(2 * D, 2 * H, 2 * W) * mask
+            assert torch.equal(y[0, ..., axis], want), (axis, streamed)
+        assert torch.count_nonzero(y[0, ..., 3:]) == 0
