@@ -140,7 +140,7 @@ class ScanWorkload:
         from gfe_hip.step_bench import measured_traffic
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": measured_traffic("sscan_fwd_bwd_step_b8") if self.B == 8 else None,
-                "kernel": "sscan_fwd+sscan_bwd (fused selective scan; 6 launches per step)",
+                "kernel": "sscan2_fwd + sscan2_bwd (fused selective scan, state-pair lanes; one launch each way from B = 8, three each way when L is chunked)",
                 "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                 "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),
                 "algorithmic_bytes": self.bytes_fwd + self.bytes_bwd}

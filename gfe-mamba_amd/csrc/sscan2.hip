@@ -38,13 +38,13 @@ constexpr int SEG = TT;
 __device__ __forceinline__ int dts_index(int ch, int t) { return ch * TT + ((((t >> 2) ^ (ch >> 2) ^ ((ch >> 1) & 1)) & 7) << 2) + (t & 3); }
 
 struct S2Fwd {
-    const void* u; const void* delta; const void* z; const float* Bm; const float* Cm;
+    const void* u; const void* delta; const void* z; const void* Bm; const void* Cm;      // Bm / Cm: f32 or bf16 rows (bc_bf16)
     const float* A; const float* D; const float* dbias;
     void* y;
     float* hstate;      // (B, nchunks, ED, 16): K1 writes local end states, K2 turns them into chunk-start states, K3 reads
     float* sdelta;      // (B, nchunks, ED): sum of dt over the chunk (the chunk's decay is exp(A * sum dt): no products)
     float* ckpt;        // (B, nseg, ED, 16) state at the START of every 32-step segment, or NULL (no backward wanted)
-    int B, L, ED, T, nchunks, softplus, nseg;
+    int B, L, ED, T, nchunks, softplus, nseg, bc_bf16;
 };
 
 // Diagnostic build only (-DGFE_S2_STAMPS, tools/scan_stamps.py): wave 0 of block 0 accumulates s_memtime deltas per phase.
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
     }
     // B / C role: threads 0-127 fetch B, 128-255 fetch C: row (tid & 127) >> 2 of the tile, floats 4q .. 4q+3
     const int br = (tid & 127) >> 2, bq = tid & 3;
-    const float* __restrict__ bcsrc = (tid < 128) ? p.Bm : p.Cm;
+    const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
 
     f2 A2 = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]} * GFE_LOG2E;
     f2 h = f2{0.f, 0.f};
@@ -173,14 +173,28 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
     const T* __restrict__ pu = u + rowbase;
     const T* __restrict__ pd = dl + rowbase;
     const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
-    const float* __restrict__ pbc = bcsrc + ((size_t)b * p.L + t0) * 16 + 4 * bq;
+    const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
+    const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
+    const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
     const int nrows = t1 - t0;
     auto fetch = [&](int tb) {                                    // global -> registers, tile starting at step tb
         const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
         ru = *reinterpret_cast<const V4*>(pu + off);
         rd = *reinterpret_cast<const V4*>(pd + off);
         if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
-        if (!STATE_ONLY || tid < 128) rbc = *reinterpret_cast<const f4*>(pbc + min(tb - t0 + br, nrows - 1) * 16);
+        if (!STATE_ONLY || tid < 128) {
+            const int boff = min(tb - t0 + br, nrows - 1) * 16;
+            if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
+            else rbc = *reinterpret_cast<const f4*>(pbc + boff);
+        }
+    };
+    auto bc_rows = [&](int tb) -> f4 {                            // the fetched B / C quarter-row as f32 (zero past the end)
+        f4 v = rbc;
+        if (p.bc_bf16) {
+            const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
+            v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
+        }
+        return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
     };
     auto park = [&](Tile& tl, int tb) {                           // registers -> LDS (the per-(t, channel) math happens once, here)
         float fu[4], fd[4], fz[4];
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
         }
         float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
         if (!STATE_ONLY || tid < 128) {
-            const f4 v = (tb + br < t1) ? rbc : f4{0.f, 0.f, 0.f, 0.f};
+            const f4 v = bc_rows(tb);
             *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
             *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
         }
@@ -338,7 +352,7 @@ int sscan2_fwd_launch(const S2Fwd& p, hipStream_t st) {
 // backward
 // ------------------------------------------------------------------------------------------------
 struct S2Bwd {
-    const void* u; const void* delta; const void* z; const float* Bm; const float* Cm; const void* dy;
+    const void* u; const void* delta; const void* z; const void* Bm; const void* Cm; const void* dy;
     const float* A; const float* D; const float* dbias;
     void* du; void* ddelta; void* dz;
     float* dAws;                        // (ED, 16) f32, zeroed, accumulated atomically (once per lane and chunk)
@@ -347,7 +361,7 @@ struct S2Bwd {
     const float* ckpt;                  // (B, nseg, ED, 16) segment-start states left by the forward
     float* qstate;                      // (B, nchunks, ED, 16) adjoint carry (chunked plan only)
     const float* sdelta;                // (B, nchunks, ED)
-    int B, L, ED, T, nchunks, softplus, nseg;
+    int B, L, ED, T, nchunks, softplus, nseg, bc_bf16;
 };
 
 constexpr int RSL = TT * 32 + 8;   // slab stride: + 8 floats so that the four (channel & 3) slabs of one ds_write_b64 fall on disjoint banks
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
     const int br = (tid & 127) >> 2, bq = tid & 3;
-    const float* __restrict__ bcsrc = (tid < 128) ? p.Bm : p.Cm;
+    const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
 
     const f2 An = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
     const f2 A2 = An * GFE_LOG2E;
@@ -410,7 +424,9 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
     const T* __restrict__ pd = dl + rowbase;
     const T* __restrict__ pg = dy + rowbase;
     const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
-    const float* __restrict__ pbc = bcsrc + ((size_t)b * p.L + t0) * 16 + 4 * bq;
+    const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
+    const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
+    const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
     const int nrows = t1 - t0;
     auto fetch = [&](int tb) {                                    // rows past the end: clamped here, masked in park
         const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
@@ -418,7 +434,19 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
         rd = *reinterpret_cast<const V4*>(pd + off);
         rg = *reinterpret_cast<const V4*>(pg + off);
         if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
-        if (!STATE_ONLY || tid >= 128) rbc = *reinterpret_cast<const f4*>(pbc + min(tb - t0 + br, nrows - 1) * 16);
+        if (!STATE_ONLY || tid >= 128) {
+            const int boff = min(tb - t0 + br, nrows - 1) * 16;
+            if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
+            else rbc = *reinterpret_cast<const f4*>(pbc + boff);
+        }
+    };
+    auto bc_rows = [&](int tb) -> f4 {
+        f4 v = rbc;
+        if (p.bc_bf16) {
+            const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
+            v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
+        }
+        return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
     };
     auto park = [&](int tb) {
         float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4];
@@ -455,7 +483,7 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
         }
         float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
         if (!STATE_ONLY || tid >= 128) {
-            const f4 v = (tb + br < t1) ? rbc : f4{0.f, 0.f, 0.f, 0.f};
+            const f4 v = bc_rows(tb);
             *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
             *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
         }
@@ -681,17 +709,18 @@ int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out,
     return GFE_OK;
 }
 
-int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
+int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, void* y,
                    float* hstate, float* sdelta, float* ckpt,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, void* stream) {
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream) {
+    GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && y, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
     S2Fwd p;
     p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y;
     p.hstate = hstate; p.sdelta = sdelta; p.ckpt = ckpt;
     p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
-    p.nseg = (int)ceil_div(L, SEG);
+    p.nseg = (int)ceil_div(L, SEG); p.bc_bf16 = bc_dtype == GFE_BF16;
     GFE_REQUIRE(p.nchunks <= 65535, GFE_ERR_SHAPE);
     GFE_REQUIRE(p.nchunks == 1 || (hstate && sdelta && T % SEG == 0), GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
@@ -700,12 +729,13 @@ int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const float
     return GFE_ERR_DTYPE;
 }
 
-int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
+int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, const void* dy,
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
                    const float* ckpt, float* qstate, const float* sdelta,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, void* stream) {
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream) {
+    GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && dy && du && ddelta && dA_ws && dB_ws && dC_ws && ckpt, GFE_ERR_NULL);
     GFE_REQUIRE(!z || dz, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
@@ -714,7 +744,7 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const float
     p.du = du; p.ddelta = ddelta; p.dz = dz; p.dAws = dA_ws; p.dBws = dB_ws; p.dCws = dC_ws; p.dDws = dD_ws; p.dbiasws = dbias_ws;
     p.ckpt = ckpt; p.qstate = qstate; p.sdelta = sdelta;
     p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
-    p.nseg = (int)ceil_div(L, SEG);
+    p.nseg = (int)ceil_div(L, SEG); p.bc_bf16 = bc_dtype == GFE_BF16;
     GFE_REQUIRE(p.nchunks <= 65535, GFE_ERR_SHAPE);
     GFE_REQUIRE(p.nchunks == 1 || (qstate && sdelta && T % SEG == 0), GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;

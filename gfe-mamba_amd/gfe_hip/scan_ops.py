@@ -51,19 +51,24 @@ class _SelectiveScan2(torch.autograd.Function):
         dt = _common_dtype(u, delta, Bm, Cm, z)
         cast = lambda t: None if t is None else _al16(t.detach().to(dt).contiguous())
         u_, d_, z_ = cast(u), cast(delta), cast(z)
-        B_, C_ = _al16(_f32c(Bm)), _al16(_f32c(Cm))
+        bcdt = torch.bfloat16 if Bm.dtype == torch.bfloat16 and Cm.dtype == torch.bfloat16 else torch.float32
+        B_, C_ = _al16(Bm.detach().to(bcdt).contiguous()), _al16(Cm.detach().to(bcdt).contiguous())     # rows are read in their own dtype: no cast kernels
         A_, D_, b_ = _f32c(A), _f32c(D), _f32c(delta_bias)
         T, nc = sscan2_plan(Bsz, L, ED, chunk)
         dev = u.device
         hstate = sdelta = ckpt = None
-        if nc > 1:
-            hstate = torch.empty((Bsz, nc, ED, 16), device=dev, dtype=torch.float32)
-            sdelta = torch.empty((Bsz, nc, ED), device=dev, dtype=torch.float32)
-        if need_grad:
-            ckpt = torch.empty((Bsz, -(-L // 32), ED, 16), device=dev, dtype=torch.float32)
+        # one allocation for every f32 workspace of this call (chunk states, chunk sums of dt, segment checkpoints)
+        sizes = [Bsz * nc * ED * 16 if nc > 1 else 0, Bsz * nc * ED if nc > 1 else 0, Bsz * (-(-L // 32)) * ED * 16 if need_grad else 0]
+        if sum(sizes):
+            ws = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            hs_, sd_, ck_ = torch.split(ws, sizes)
+            if nc > 1:
+                hstate, sdelta = hs_, sd_
+            if need_grad:
+                ckpt = ck_
         y = torch.empty((Bsz, L, ED), device=dev, dtype=dt)
         call("gfe_sscan2_fwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(y),
-             ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, int(bool(delta_softplus)), dtype_code(dt), stream())
+             ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, int(bool(delta_softplus)), dtype_code(dt), dtype_code(bcdt), stream())
         ctx.save_for_backward(u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta)
         ctx.meta = (T, nc, bool(delta_softplus), dt,
                     tuple(None if t is None else t.dtype for t in (u, delta, A, Bm, Cm, D, z, delta_bias)))
@@ -86,7 +91,7 @@ class _SelectiveScan2(torch.autograd.Function):
         call("gfe_sscan2_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_),
              ptr(du), ptr(dd), ptr(dz), ptr(dA_ws), ptr(dB_ws), ptr(dC_ws),
              ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
-             ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), stream())
+             ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), stream())
         to = lambda g, i: None if in_dtypes[i] is None else g.to(in_dtypes[i])
         return (to(du, 0), to(dd, 1), to(dA_ws.view(ED, 16), 2), to(dB_ws.view(Bsz, L, 16), 3), to(dC_ws.view(Bsz, L, 16), 4),
                 to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,

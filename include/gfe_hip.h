@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 21
+#define GFE_ABI_VERSION 22
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -73,23 +73,24 @@ int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, con
 /* The same operator for N = 16 in the single-pass formulation (csrc/sscan2.hip: a lane owns one channel x one PAIR of states, so
  * B*ED/8 waves fill the chip without cutting L; L is chunked -- two passes + carry -- only for small B).  Same reference lines as
  * gfe_selective_scan_fwd/_bwd (mamba.py:243-286, pscan.py:151-224); N = 16, ED % 32 == 0, u/delta/z/y 16-byte aligned.
+ *   Bm, Cm: (B, L, 16) rows in `bc_dtype` (GFE_F32 or GFE_BF16), 16-byte aligned.
  *   gfe_sscan2_plan: T = chunk length (a multiple of 32 when nchunks > 1; chunk_req <= 0: automatic), host only.
  *   hstate (B, nchunks, ED, 16), sdelta (B, nchunks, ED) f32: workspaces, required when nchunks > 1.
  *   ckpt (B, ceil(L/32), ED, 16) f32 or NULL: the forward leaves the state at the start of every 32-step segment there; the backward
  *   recomputes one segment at a time from it with the segment's states in registers. */
 int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out, int* nchunks_out);
-int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
+int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, void* y,
                    float* hstate, float* sdelta, float* ckpt,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, void* stream);
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream);
 /*   dA_ws (ED, 16), dB_ws / dC_ws (B, L, 16), dD_ws / dbias_ws (ED) f32: zeroed, accumulated atomically; qstate: workspace like hstate
  *   (nchunks > 1); ckpt, sdelta: as left by gfe_sscan2_fwd with the same T. */
-int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const float* Bm, const float* Cm,
+int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, const void* dy,
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
                    const float* ckpt, float* qstate, const float* sdelta,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, void* stream);
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream);
 
 /* Materialised scan H[t] = A[t]*H[t-1] + X[t] (H[-1] = 0) over dim 1 of (B, L, DN) tensors, DN = D*N flattened.
  * Drop-in for cross_atten/pscan.py:226 `pscan(A, X)` (PScan.forward, pscan.py:151-186); inputs are not modified.
