@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, bf16_t* __restrict__ p16, const Chunk* __restrict__ chunks,
-                                                        const float* __restrict__ norm2, float gscale, float max_norm, float lr, float b1, float b2,
-                                                        float eps, float bc1, float bc2) {
+                                                        const float* __restrict__ norm2, float gscale, float max_norm, float step_size, float b1, float b2,
+                                                        float eps, float rsqrt_bc2) {
     const Chunk ck = chunks[blockIdx.x];
     // torch.nn.utils.clip_grad_norm_ on ONE tensor: coef = max_norm / (norm + 1e-6), clamped to 1 (classify_mamba.py:106-107)
     const float coef = fminf(max_norm / (sqrtf(norm2[ck.tid]) + 1e-6f), 1.0f) * gscale;
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
         const float mi = fmaf(b1, m[k], (1.f - b1) * gi);
         const float vi = fmaf(b2, v[k], (1.f - b2) * gi * gi);
         m[k] = mi; v[k] = vi;
-        // torch.optim.Adam: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
-        const float pn = p[k] - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+        // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps); lr / bc1 and 1 / sqrt(bc2) come from the host in double
+        const float pn = p[k] - step_size * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
         p[k] = pn;
         if (p16) p16[k] = f32_to_bf16(pn);
     }
@@ -258,15 +258,16 @@ int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* d
 }
 
 int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
-                  float* norm2_zeroed, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                  float* norm2_zeroed, float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps,
                   int64_t step, void* stream) {
     GFE_REQUIRE(p && g && m && v && chunks && norm2_zeroed, GFE_ERR_NULL);
     GFE_REQUIRE(nchunks > 0 && nchunks <= 0x7fffffff && step >= 1, GFE_ERR_SHAPE);
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    // bias corrections as torch.optim.Adam computes them (Python doubles): 1 - 0.999^t in f32 loses ~1e-5 relative to cancellation
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const Chunk*)chunks, norm2_zeroed, grad_scale);
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_bf16, (const Chunk*)chunks,
-                       norm2_zeroed, grad_scale, max_norm, lr, beta1, beta2, eps, bc1, bc2);
+                       norm2_zeroed, grad_scale, max_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)eps, (float)(1.0 / sqrt(bc2)));
     return gfe_launch_status();
 }
 

@@ -367,6 +367,28 @@ def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1, accum
     return out
 
 
+def gemm_f32(a, a_t, b, b_t, bias=None, accum_into=None):
+    """Exact-f32 C (M, N) = op(a) op(b)^T (+ bias) on the f32 matrix cores (gfe_gemm_f32): a_t / b_t say that the operand is stored
+    reduction-major, i.e. a is (K, M) / b is (K, N) in memory.  accum_into: f32 (M, N) gradient buffer the product is ADDED to.
+    Any sizes and alignments (unit inner stride)."""
+    M, K = (a.shape[1], a.shape[0]) if a_t else a.shape
+    N = b.shape[1] if b_t else b.shape[0]
+    unit = lambda t: t.shape[1] == 1 or t.stride(1) == 1          # (a size-1 dimension may carry any stride)
+    ld = lambda t: t.stride(0) if t.shape[0] > 1 else t.shape[1]
+    assert (b.shape[0] if b_t else b.shape[1]) == K and unit(a) and unit(b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    blocks = -(-M // 64) * -(-N // 64)
+    split_k = 1 if blocks >= 128 or K < 256 else min(16, K // 128, max(1, 256 // blocks))     # few-block shapes (x_proj: 5 blocks x 1024 deep)
+    if accum_into is not None:
+        assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and unit(accum_into) and bias is None
+        out = accum_into
+    else:
+        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=torch.float32, device=a.device)
+    call("gfe_gemm_f32", ptr(a), ld(a), int(a_t), ptr(b), ld(b), int(b_t), ptr(out), ld(out), M, N, K,
+         ptr(bias), int(accum_into is not None), split_k, stream())
+    return out
+
+
 def _ex_ok(t):
     """operand usable in place by gemm_ex: 2-D, unit inner stride, 16-byte aligned rows"""
     al = 4 if t.dtype == torch.float32 else 8

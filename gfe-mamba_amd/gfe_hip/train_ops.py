@@ -1,7 +1,10 @@
-"""Autograd plumbing for the trainable head: Linear over the bf16 MFMA GEMM, the head Linear over channels-last mid
-features, the image condition buffers, and the flat-buffer per-parameter-clip + Adam step (with the DP all-reduce).
+"""Autograd plumbing for the trainable head: Linear over the MFMA GEMMs, the head Linear over channels-last mid features, the image
+condition buffers, and the flat-buffer per-parameter-clip + Adam step (with the DP all-reduce).
 
-Numerics: master weights, residual stream and reductions are f32; GEMM operands are rounded to bf16 (f32 accumulate).
+Numerics: master weights, residual stream and reductions are f32.  The head's small Linears (Mamba projections, q / out projections,
+GEGLU feed-forward, logits: launch-bound sizes) run on the exact-f32 MFMA GEMM, as the reference trains the head in fp32
+(classify_mamba.py:69-74); only Linears wider than F32_LINEAR_MAX_K inputs (the cross-attention K / V projections over d_cross =
+9 216 .. 25 600 image columns, which carry 94 % of the head's FLOPs) round their operands to bf16 (f32 accumulate).
 """
 import weakref
 
@@ -14,6 +17,7 @@ from . import call, nn_ops as K, ptr, stream
 from .nn_ops import BF16
 
 _SHADOW = {}        # id(parameter) -> bf16 view kept fresh by FlatAdam (avoids a cast per use)
+F32_LINEAR_MAX_K = 4096     # Linears with at most this many input features keep f32 operands (gfe_gemm_f32)
 
 
 def _w16(weight):
@@ -24,9 +28,13 @@ def _w16(weight):
 
 
 def _grad_slot(param):
-    """The parameter's gradient buffer if a backward may add into it directly (f32, dense, same shape): FlatAdam hands every
-    parameter a view of its flat gradient buffer, zeroed at the start of the step, so the wgrad kernels accumulate in place and
-    autograd's per-parameter AccumulateGrad add/copy launches (~90 per step) disappear.  None -> return the gradient to autograd."""
+    """The parameter's gradient buffer if a backward may add into it directly: ONLY for parameters FlatAdam owns (it sets
+    `_gfe_flat_grad` on them and hands each a view of its flat gradient buffer, zeroed at the start of the step), so the wgrad kernels
+    accumulate in place and autograd's per-parameter AccumulateGrad add/copy launches (~90 per step) disappear.  Any other parameter
+    -- whatever its .grad happens to hold -- gets its gradient returned to autograd (AccumulateGrad, hooks and torch.autograd.grad
+    behave as usual)."""
+    if not getattr(param, "_gfe_flat_grad", False):
+        return None
     g = param.grad
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != param.shape or not g.is_cuda:
         return None
@@ -57,6 +65,17 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, x16, xT16):
         N, Kd = weight.shape
         xs = x.shape
+        if Kd <= F32_LINEAR_MAX_K and x16 is None and weight.dtype == torch.float32:
+            # exact-f32 path (the reference's own precision for the head): 1 launch forward, 2-3 backward, no casts
+            x32 = x.detach().reshape(-1, Kd)
+            if x32.dtype != torch.float32 or x32.stride(-1) != 1:
+                x32 = x32.float().contiguous()
+            b32 = None if bias is None else bias.detach().float().contiguous()
+            y = K.gemm_f32(x32, False, weight.detach(), False, bias=b32)
+            ctx.save_for_backward(x32, None, weight)
+            ctx.meta = (xs, bias is not None, x.dtype, "f32")
+            ctx.bias_ref, ctx.w_ref = bias, weight
+            return y.reshape(xs[:-1] + (N,))
         w16 = _w16(weight)
         b32 = None if bias is None else bias.detach().float().contiguous()
         xin = x16 if x16 is not None else x.detach().reshape(-1, Kd)
@@ -83,7 +102,14 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N)
         dx = dw = db = None
         d32 = dy2 if (dy2.dtype == torch.float32 and dy2.stride(1) == 1) else dy2.float().contiguous()
-        if fast and K._ex_ok(d32):
+        if fast == "f32":
+            if ctx.needs_input_grad[0]:
+                dx = K.gemm_f32(d32, False, weight.detach(), True).reshape(xs).to(xdt)    # dy (M, N) . W (N, K) read reduction-major
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.w_ref)
+                dw = K.gemm_f32(d32, True, xin, True, accum_into=slot)                     # dy^T . x, both read reduction-major
+                dw = None if slot is not None else dw.to(weight.dtype)
+        elif fast and K._ex_ok(d32):
             if ctx.needs_input_grad[0]:
                 dx = K.gemm_ex(d32, False, _w16(weight), True).reshape(xs).to(xdt)        # dy (M, N) . W (N, K) read reduction-major
             if ctx.needs_input_grad[1]:
@@ -252,6 +278,7 @@ class FlatAdam:
             self.flat_p[o:o + s].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[o:o + s].view(p.shape)
             p.grad = self.flat_g[o:o + s].view(p.shape)
+            p._gfe_flat_grad = True          # opt-in for the in-place wgrad accumulation (_grad_slot)
             for c0 in range(0, s, chunk):
                 rec.append((o + c0, min(chunk, s - c0), tid))
         tab = np.zeros(len(rec), dtype=np.dtype([("off", "<i8"), ("len", "<i4"), ("tid", "<i4")]))

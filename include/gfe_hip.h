@@ -223,6 +223,16 @@ int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t l
                 int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
                 int act, int out_f32, int split_k, void* stream);
 
+/* Exact-f32 GEMM on the f32 matrix cores for the trainable head's small Linears (the reference trains the head in fp32:
+ * classify_mamba.py:69-74; Mamba projections mamba.py:204, 235-238, 223; q / out projections sd_cross_atten.py:42-45; GEGLU FF
+ * corss_ft_transformer.py:15-22; logits mamba_transformer.py:79-82).
+ *   C[M][N] (+)= op(A)[M][K] op(B)[N][K]^T (+ bias[n]), all f32, any sizes / alignments.
+ *   a_tr / b_tr != 0: the operand is stored reduction-major, element (row, k) at base[k * ld + row].
+ *   accumulate != 0: add to C (a gradient buffer).  split_k > 1: K ranges are added with f32 atomics -- C must be zeroed, or be the
+ *   buffer that is accumulated into. */
+int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, float* C, int64_t ldc,
+                 int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, void* stream);
+
 /* out[b][c][r] = in[b][r][c], bf16 (operand re-layout for dgrad / wgrad). */
 int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream);
 
@@ -281,9 +291,10 @@ int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* d
 /* Per-PARAMETER clip_grad_norm_(p, max_norm) followed by one Adam step (classify_mamba.py:64, 106-108) over flat f32
  * buffers holding every trainable tensor back to back.  chunks: device array of {int64 offset, int32 length, int32 tensor_id}
  * (16 B each), no chunk crossing a tensor boundary.  norm2_zeroed: (n_tensors) f32, zero on entry.  grad_scale multiplies g
- * first (1/world_size after an all-reduce SUM).  p_bf16: optional flat bf16 copy of p refreshed in the same pass. */
+ * first (1/world_size after an all-reduce SUM).  p_bf16: optional flat bf16 copy of p refreshed in the same pass.
+ * lr / betas / eps are doubles: the bias corrections 1 - beta^step are formed in double on the host, as torch.optim.Adam does. */
 int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
-                  float* norm2_zeroed, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                  float* norm2_zeroed, float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps,
                   int64_t step, void* stream);
 
 /* RMSNorm (cross_atten/mamba.py:408-418): y = x * rsqrt(mean(x^2, -1) + eps) * w over (rows, dim) f32; rstd (rows) is kept for

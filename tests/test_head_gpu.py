@@ -1,5 +1,7 @@
 """GPU parity of the trainable path (Mamba, cross-attention, GEGLU FF, head Linear, clip+Adam, whole step) against the
-reference-generated fixtures and the oracle.  GEMM operands are bf16 -> 1e-2-class tolerances (BASELINE.json north_star)."""
+reference-generated fixtures and the oracle.  The head's Linears keep f32 operands (exact-f32 MFMA GEMM, as the reference trains
+the head in fp32): op-level tolerance 1e-3 (BASELINE.json north_star, fp32); only the K / V projections over the image condition
+and the frozen generator are bf16 -> 1e-2-class tolerances for whatever includes them."""
 import numpy as np
 import pytest
 import torch
@@ -20,14 +22,17 @@ def test_mamba_stack_vs_reference_fixture():
     m.load_state_dict(sub_sd(fx, "sd."))
     m = m.to(DEV)
     x = tt(fx["x"], device=DEV).requires_grad_(True)
+    TOL = 1e-3                                      # fp32 tolerance of BASELINE.json: every GEMM of the block keeps f32 operands
     assert rel_err(m.layers[0].norm(x), tt(fx["y_norm0"])) < 1e-5
-    assert rel_err(m.layers[0].mixer(x), tt(fx["y_block0"])) < 2e-2
+    e_block = rel_err(m.layers[0].mixer(x), tt(fx["y_block0"]))
     y = m(x)
-    assert rel_err(y, tt(fx["y"])) < 2e-2
+    e_y = rel_err(y, tt(fx["y"]))
     (y * tt(fx["w"], device=DEV)).sum().backward()
-    assert rel_err(x.grad, tt(fx["gx"])) < 3e-2
-    for k, p in m.named_parameters():
-        assert rel_err(p.grad, tt(fx["g." + k])) < 4e-2, k
+    e_gx = rel_err(x.grad, tt(fx["gx"]))
+    e_g = {k: rel_err(p.grad, tt(fx["g." + k])) for k, p in m.named_parameters()}
+    kw = max(e_g, key=e_g.get)
+    print("Mamba stack vs reference: block %.2e, stack %.2e, dx %.2e, worst parameter gradient %.2e (%s)" % (e_block, e_y, e_gx, e_g[kw], kw))
+    assert e_block < TOL and e_y < TOL and e_gx < TOL and e_g[kw] < TOL
 
 
 def test_cross_attention_ff_embedder_vs_reference_fixture():
@@ -38,23 +43,24 @@ def test_cross_attention_ff_embedder_vs_reference_fixture():
     ca.load_state_dict(sub_sd(fx, "ca.sd."))
     ca = ca.to(DEV)
     x, y = tt(fx["ca.x"], device=DEV).requires_grad_(True), tt(fx["ca.y"], device=DEV).requires_grad_(True)
+    TOL = 1e-3
     o = ca(x, y)
-    assert rel_err(o, tt(fx["ca.out"])) < 2e-2
+    assert rel_err(o, tt(fx["ca.out"])) < TOL
     (o * tt(fx["ca.w"], device=DEV)).sum().backward()
-    assert rel_err(x.grad, tt(fx["ca.gx"])) < 3e-2 and rel_err(y.grad, tt(fx["ca.gy"])) < 3e-2
+    assert rel_err(x.grad, tt(fx["ca.gx"])) < TOL and rel_err(y.grad, tt(fx["ca.gy"])) < TOL
     for k, p in ca.named_parameters():
         if k == "k_proj.bias":
-            assert p.grad.abs().max() < 1e-3       # exactly zero in exact arithmetic
+            assert p.grad.abs().max() < 1e-5       # exactly zero in exact arithmetic
             continue
-        assert rel_err(p.grad, tt(fx["ca.g." + k])) < 4e-2, k
+        assert rel_err(p.grad, tt(fx["ca.g." + k])) < TOL, k
     ff = FeedForward(16, mult=2, dropout=0.1)
     ff.load_state_dict(sub_sd(fx, "ff.sd."))
     ff = ff.to(DEV).eval()
     xf = tt(fx["ff.x"], device=DEV).requires_grad_(True)
     of = ff(xf)
-    assert rel_err(of, tt(fx["ff.out"])) < 2e-2
+    assert rel_err(of, tt(fx["ff.out"])) < TOL
     (of * tt(fx["ca.w"], device=DEV)).sum().backward()
-    assert rel_err(xf.grad, tt(fx["ff.gx"])) < 3e-2
+    assert rel_err(xf.grad, tt(fx["ff.gx"])) < TOL
     ne = NumericalEmbedder(16, 5)
     ne.load_state_dict(sub_sd(fx, "ne.sd."))
     assert rel_err(ne.to(DEV)(tt(fx["ne.x"], device=DEV)), tt(fx["ne.out"])) < 1e-6
@@ -125,7 +131,51 @@ def test_flat_clip_adam_matches_per_parameter_reference():
     assert torch.equal(opt.flat_p16.float(), opt.flat_p.to(BF).float())
 
 
-def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad):
+def _slices(t, n=256):
+    """tools/make_golden.py::slices -- the strided sample the fixtures hold of every large tensor."""
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)][:n]
+
+
+def _grad_and_update_errors(fx, names, params, opt):
+    """Element-wise comparison of the parameter gradients (fixture `gslice.*`: 64 strided elements per tensor, from the reference's
+    autograd) and of one clipped Adam step (`dslice.*`), plus the norms.  Returns the worst relative errors (max |a-b| / max |b|)."""
+    worst = dict(gslice=(0.0, ""), gnorm=(0.0, ""), dslice=(0.0, ""), dnorm=(0.0, ""))
+    per_tensor = []
+    for k, p in zip(names, params):
+        ref = tt(fx["gslice." + k])
+        if float(fx["gnorm." + k]) < 1e-7:
+            continue                                   # exactly-zero gradients (k_proj.bias: softmax is shift-invariant)
+        e = rel_err(_slices(p.grad, 64), ref)
+        per_tensor.append((e, k))
+        if e > worst["gslice"][0]:
+            worst["gslice"] = (e, k)
+        e = abs(p.grad.double().norm().item() - float(fx["gnorm." + k])) / float(fx["gnorm." + k])
+        if e > worst["gnorm"][0]:
+            worst["gnorm"] = (e, k)
+    before = opt.flat_p.clone()
+    opt.step()
+    for k, p, o, s in zip(names, params, opt.offs[:-1], opt.sizes):
+        if float(fx["gnorm." + k]) < 1e-7:
+            continue                                   # Adam normalises pure round-off there
+        delta = opt.flat_p[int(o):int(o) + s] - before[int(o):int(o) + s]
+        ref, gref = tt(fx["dslice." + k]), tt(fx["gslice." + k])
+        # Adam's first step is lr * g / (|g| + eps) ~ lr * sign(g): compare where the reference gradient is not round-off
+        m = gref.abs() > 0.02 * gref.abs().max()
+        if m.any():
+            e = ((_slices(delta, 64).double().cpu() - ref)[m].abs().max() / ref.abs().max()).item()
+            if e > worst["dslice"][0]:
+                worst["dslice"] = (e, k)
+        e = abs(delta.double().norm().item() - float(fx["dnorm." + k])) / max(float(fx["dnorm." + k]), 1e-12)
+        if e > worst["dnorm"][0]:
+            worst["dnorm"] = (e, k)
+    per_tensor.sort(reverse=True)
+    worst["top"] = per_tensor[:6]
+    worst["median"] = per_tensor[len(per_tensor) // 2][0]
+    return worst
+
+
+def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag):
     from gfe_hip import det_init as det
     from gfe_hip.step import ClassifyStep, build_models
     gen, head, ft = build_models(vol=vol, dim=dim, depth=depth, heads=heads, seed=seed, **gen_kw)
@@ -134,47 +184,99 @@ def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_g
     head.eval(); ft.eval()                          # fixtures were generated with dropout off
     st.opt.zero_grad()
     pred, (mi, mo, pet) = st.forward(x.to(DEV), x_cat.to(DEV), x_num.to(DEV))
+    meas = {}
     for name, t in (("mid_input", mi), ("mid_output", mo), ("pet", pet)):
-        ref_sum, ref_abs = float(fx[name + "_sum"]), float(fx[name + "_abssum"])
-        assert abs(t.double().abs().sum().item() - ref_abs) / ref_abs < tol_fwd, name
-        f = t.contiguous().reshape(-1) if name == "pet" else t.contiguous().reshape(-1)
-        step = max(1, f.numel() // 256)
-        assert rel_err(f[::step][:256], tt(fx[name + "_slice"])) < 5 * tol_fwd, name
-    assert rel_err(pred, tt(fx["pred"])) < 5 * tol_fwd
+        ref_abs = float(fx[name + "_abssum"])
+        assert abs(t.double().abs().sum().item() - ref_abs) / ref_abs < 1e-2, name
+        meas[name] = rel_err(_slices(t.contiguous()), tt(fx[name + "_slice"]))
+        assert meas[name] < 2e-2, (name, meas[name])          # frozen generator: bf16 activations through 12 conv layers + the ViT
+    meas["pred"] = rel_err(pred, tt(fx["pred"]))
     loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.to(DEV).float())
-    assert abs(loss.item() - float(fx["loss"])) < 5 * tol_fwd * max(1.0, float(fx["loss"]))
+    meas["loss"] = abs(loss.item() - float(fx["loss"])) / max(1.0, float(fx["loss"]))
     loss.backward()
     names = ["head." + k for k, _ in head.named_parameters()] + ["ft." + k for k, _ in ft.named_parameters()]
-    bad = []
-    for k, p in zip(names, st.all_params):
-        ref = float(fx["gnorm." + k])
-        got = p.grad.double().norm().item()
-        if ref < 1e-7:
-            continue
-        if abs(got - ref) / ref > tol_grad:
-            bad.append((k, got, ref))
-    assert not bad, bad
-    before = st.opt.flat_p.clone()
-    st.opt.step()
-    for (k, p), o, s in zip(zip(names, st.all_params), st.opt.offs[:-1], st.opt.sizes):
-        if k.endswith("k_proj.bias"):     # gradient is exactly zero in exact arithmetic; Adam normalises pure round-off
-            continue
-        ref = float(fx["dnorm." + k])
-        got = (st.opt.flat_p[int(o):int(o) + s] - before[int(o):int(o) + s]).double().norm().item()
-        assert abs(got - ref) / max(ref, 1e-12) < 0.1, (k, got, ref)     # Adam's first step is ~lr*sign(g): robust to bf16 noise
+    worst = _grad_and_update_errors(fx, names, st.all_params, st.opt)
+    print("%s measured rel errors vs the reference (fp32 CPU): %s | worst gradient element %.2e (%s), gradient norm %.2e (%s), "
+          "Adam update element %.2e (%s), update norm %.2e (%s); gradient elements per tensor: median %.2e, six worst %s"
+          % (tag, {k: "%.2e" % v for k, v in meas.items()}, *worst["gslice"], *worst["gnorm"], *worst["dslice"], *worst["dnorm"], worst["median"],
+             [("%.1e" % e, k) for e, k in worst["top"]]))
+    assert meas["pred"] < tol_fwd and meas["loss"] < tol_fwd, meas
+    # Element-wise (64 strided elements per tensor, error / max |reference element| of the tensor).  The head itself is fp32-exact
+    # (test_head_alone_...: 5e-3); what is measured here is the frozen generator's bf16 error (pet / mid features ~1e-2, run-to-run
+    # different roundings from its atomically accumulated GroupNorm fold) carried through the head's backward: typical tensor 2-3e-3,
+    # tensors that are signed sums with heavy cancellation (the 4-element bias of the image-token Linear = 1024 feature gradients each,
+    # the 32-wide dt_proj, a feed-forward row) up to 6e-2 of their largest element, and WHICH tensor is worst changes from run to run.
+    assert worst["median"] < tol_grad / 2 and worst["gnorm"][0] < tol_grad, worst
+    for e, k in worst["top"]:
+        assert e < tol_sens, (k, e)
+    assert worst["dslice"][0] < tol_sens and worst["dnorm"][0] < tol_grad, worst
 
 
 def test_reduced_step_vs_reference_fixture():
-    """T1: reduced-width classify_mamba step (32^3) run by the reference on CPU vs the HIP path end to end."""
+    """T1: reduced-width classify_mamba step (32^3) run by the reference on CPU vs the HIP path end to end: logits, loss, every
+    parameter gradient ELEMENT-wise (fixture gslice.*), one clipped Adam step element-wise (dslice.*).  bf16 generator -> 2e-2."""
     fx = golden("t1_reduced_step.npz")
     _check_step_fixture(fx, dict(f_maps=(8, 16, 32), vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128)),
-                        (32, 32, 32), 64, 2, 8, 11, tol_fwd=2e-2, tol_grad=8e-2)
+                        (32, 32, 32), 64, 2, 8, 11, tol_fwd=1e-2, tol_grad=2e-2, tol_sens=8e-2, tag="T1 (reduced, 32^3)")
 
 
 def test_full_96_step_vs_reference_fixture():
     """T2 / BASELINE config 1: the full-size model on 2 volumes of 96^3 (reference run on CPU in the build container)."""
     fx = golden("t2_full96_step.npz")
-    _check_step_fixture(fx, dict(f_maps=(64, 128, 256)), (96, 96, 96), 512, 6, 8, 21, tol_fwd=2e-2, tol_grad=1e-1)
+    _check_step_fixture(fx, dict(f_maps=(64, 128, 256)), (96, 96, 96), 512, 6, 8, 21, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=8e-2, tag="T2 (config 1, 96^3)")
+
+
+def test_head_alone_on_the_references_generator_outputs_meets_fp32_tolerance():
+    """The trainable path in isolation: head + Cross_mamba_both fed with the REFERENCE's own generator outputs (T1 fixture holds them
+    in full), so that nothing of the bf16 generator is in the comparison.  The head's Linears run on the exact-f32 MFMA GEMM; what is
+    left is the bf16 rounding of the mid features / image condition on the way into the K / V projections."""
+    from gfe_hip import det_init as det
+    from gfe_hip.step import build_models
+    from gfe_hip.train_ops import Condition, FlatAdam
+    fx = golden("t1_reduced_step.npz")
+    vol = (32, 32, 32)
+    _, head, ft = build_models(vol=vol, f_maps=(8, 16, 32), dim=64, depth=2, heads=8, seed=11,
+                               vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128))
+    head.eval(); ft.eval()
+    x, x_cat, x_num, y = det.det_inputs(2, vol, seed=11)
+    params = list(head.parameters()) + list(ft.parameters())
+    opt = FlatAdam(params, lr=1e-4, max_norm=1.0)
+    opt.zero_grad()
+    mi, mo, pet = (tt(fx[k], device=DEV) for k in ("mid_input", "mid_output", "pet"))
+    feat = head(mi, mo)
+    pred = ft(x_cat.to(DEV), x_num.to(DEV), feat, Condition([x.to(DEV), pet]))
+    loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.to(DEV).float())
+    loss.backward()
+    names = ["head." + k for k, _ in head.named_parameters()] + ["ft." + k for k, _ in ft.named_parameters()]
+    e_feat, e_pred = rel_err(feat, tt(fx["feat"])), rel_err(pred, tt(fx["pred"]))
+    e_loss = abs(loss.item() - float(fx["loss"])) / max(1.0, float(fx["loss"]))
+    worst = _grad_and_update_errors(fx, names, params, opt)
+    print("head alone (reference generator outputs in): feat %.2e pred %.2e loss %.2e | worst gradient element %.2e (%s), norm %.2e (%s), "
+          "Adam update element %.2e (%s)" % (e_feat, e_pred, e_loss, *worst["gslice"], *worst["gnorm"], *worst["dslice"]))
+    # feat: a 512-term signed sum of bf16-rounded mid features (2^-9 each): 3.5e-3 of its maximum; everything behind it is f32
+    assert e_feat < 6e-3 and e_pred < 3e-3 and e_loss < 1e-3
+    assert worst["gslice"][0] < 1e-2 and worst["gnorm"][0] < 5e-3, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(296, 512, 512), (37, 2048, 512), (300, 64, 1024), (8, 1, 512), (37, 40, 25), (5, 8, 8), (2048, 512, 296)])
+def test_gemm_f32_exact_modes(M, N, K):
+    """gfe_gemm_f32 (f32 MFMA): every operand layout, bias, accumulation and split-K against an f64 matmul: f32-exact (<= 2e-6 of the
+    largest |sum|), any sizes / alignments (the 1-wide logit layer, the 25/37-wide test models)."""
+    from gfe_hip import nn_ops as K_
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a, b, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ref = a.double() @ b.double().t()
+    scale = (a.double().abs() @ b.double().abs().t()).max().item()
+    for a_t in (False, True):
+        for b_t in (False, True):
+            aa = (a.t().contiguous() if a_t else a).to(DEV)
+            bb = (b.t().contiguous() if b_t else b).to(DEV)
+            out = K_.gemm_f32(aa, a_t, bb, b_t, bias=bias.to(DEV))
+            assert (out.double().cpu() - ref - bias.double()).abs().max().item() <= 2e-6 * scale, (a_t, b_t)
+            acc = torch.full((M, N), 0.5, device=DEV)
+            K_.gemm_f32(aa, a_t, bb, b_t, accum_into=acc)
+            assert (acc.double().cpu() - ref - 0.5).abs().max().item() <= 2e-6 * scale, (a_t, b_t, "accumulate")
 
 
 @pytest.mark.gpu
