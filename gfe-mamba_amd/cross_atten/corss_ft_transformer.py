@@ -6,17 +6,31 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from gfe_hip.head_ops import LayerNorm, geglu_dropout
 from gfe_hip.train_ops import Linear
 
 
 class GEGLU(nn.Module):
     def forward(self, x):
+        if x.is_cuda:
+            return geglu_dropout(x)                   # one kernel each way (gfe_geglu_fwd / _bwd)
         x, gates = x.chunk(2, dim=-1)
         return x * F.gelu(gates)
 
 
+class _FeedForward(nn.Sequential):
+    """LayerNorm -> Linear -> GEGLU -> Dropout -> Linear with the reference's Sequential indices (parameters at .0, .1, .4).  GEGLU and
+    the dropout behind it run as ONE kernel each way (the mask is regenerated in the backward from a seed, never stored)."""
+
+    def forward(self, x):
+        ln, lin1, _, drop, lin2 = self
+        h = lin1(ln(x))
+        h = geglu_dropout(h, drop.p, self.training and drop.training)
+        return lin2(h)
+
+
 def FeedForward(dim, mult=4, dropout=0.):
-    return nn.Sequential(nn.LayerNorm(dim), Linear(dim, dim * mult * 2), GEGLU(), nn.Dropout(dropout), Linear(dim * mult, dim))
+    return _FeedForward(LayerNorm(dim), Linear(dim, dim * mult * 2), GEGLU(), nn.Dropout(dropout), Linear(dim * mult, dim))
 
 
 class NumericalEmbedder(nn.Module):

@@ -9,6 +9,7 @@ from torch import nn
 from cross_atten.corss_ft_transformer import FeedForward, GEGLU, NumericalEmbedder  # noqa: F401
 from cross_atten.mamba import Mamba, MambaConfig
 from cross_atten.sd_cross_atten import CrossAttention
+from gfe_hip.head_ops import LayerNorm, embed_tokens, mean_tokens
 from gfe_hip.train_ops import Condition, Linear
 
 
@@ -31,7 +32,7 @@ class Cross_mamba_both(nn.Module):
             self.numerical_embedder = NumericalEmbedder(dim, self.num_continuous)
         self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
         self.transformer = Mamba(MambaConfig(d_model=dim, n_layers=depth, use_cuda=True))        # :64-65
-        self.to_logits = nn.Sequential(nn.LayerNorm(dim), Linear(dim, dim_out))
+        self.to_logits = nn.Sequential(LayerNorm(dim), Linear(dim, dim_out))
         self.final_cross = CrossAttention(n_heads=heads, d_embed=dim, d_cross=d_cross)           # :84
         self.final_feed = FeedForward(dim, mult=cross_ff_multi, dropout=cross_ff_dropout)        # :85
 
@@ -40,19 +41,25 @@ class Cross_mamba_both(nn.Module):
         if image_condition is None:
             raise ValueError("Cross_mamba_both needs image_condition=[mri, pet] (the reference fails with NameError at :124)")
         whole_condition = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))   # :89-94
-        xs = []
-        if self.num_unique_categories > 0:
-            xs.append(self.categorical_embeds(x_categ + self.categories_offset))                  # :98-100
-        if self.num_continuous > 0:
-            xs.append(self.numerical_embedder(x_numer))
-        x = torch.cat(xs, dim=1)
-        cls_tokens = self.cls_token.expand(x.shape[0], -1, -1)
-        x = torch.cat((cls_tokens, x, feature_img), dim=1)                                        # :117
+        x = self._tokens(x_categ, x_numer, feature_img)                                           # :97-117, one kernel each way
         x = self.transformer(x)
-        x = torch.mean(x, dim=1, keepdims=True)                                                   # :122
+        x = mean_tokens(x)                                                                        # :122
         x = self.final_cross(x, whole_condition) + x                                              # :124
         x = self.final_feed(x) + x                                                                # :125
         return self.to_logits(x.squeeze(1))                                                       # :127-131
+
+
+def _tokens(self, x_categ, x_numer, feature_img, table=True):
+    """[cls | categorical embeddings (offset add + gather) | numerical embeddings | image tokens] (mamba_transformer.py:97-117)."""
+    cat = table and self.num_unique_categories > 0
+    num = table and self.num_continuous > 0
+    ne = self.numerical_embedder if num else None
+    assert ne is None or not hasattr(ne, 'linear'), "shrink_dim embedder is not on the classify path"
+    return embed_tokens(x_categ if cat else None, self.categories_offset if cat else None, self.categorical_embeds.weight if cat else None,
+                        x_numer if num else None, ne.weights if num else None, ne.biases if num else None, self.cls_token, feature_img)
+
+
+Cross_mamba_both._tokens = _tokens
 
 
 class Cross_mamba_ablation(Cross_mamba_both):
@@ -62,21 +69,9 @@ class Cross_mamba_ablation(Cross_mamba_both):
 
     def forward(self, x_categ, x_numer, feature_img=None, image_condition=None, no_table=False):
         assert x_categ.shape[-1] == self.num_categories, f'you must pass in {self.num_categories} values for your categories input'
-        xs = []
-        if self.num_unique_categories > 0:
-            xs.append(self.categorical_embeds(x_categ + self.categories_offset))                  # :339-343
-        if self.num_continuous > 0:
-            xs.append(self.numerical_embedder(x_numer))
-        x = torch.cat(xs, dim=1)
-        cls_tokens = self.cls_token.expand(x.shape[0], -1, -1)
-        if no_table:
-            x = torch.cat((cls_tokens, feature_img), dim=1)                                       # :359
-        elif feature_img is not None:
-            x = torch.cat((cls_tokens, x, feature_img), dim=1)                                    # :362
-        else:
-            x = torch.cat((cls_tokens, x), dim=1)                                                 # :364
+        x = self._tokens(x_categ, x_numer, feature_img, table=not no_table)                       # :339-364
         x = self.transformer(x)
-        x = torch.mean(x, dim=1, keepdims=True)                                                   # :371
+        x = mean_tokens(x)                                                                        # :371
         if image_condition is not None:
             cond = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))
             x = self.final_cross(x, cond) + x                                                     # :374

@@ -1,14 +1,15 @@
 """CrossAttention / SelfAttention -- MI355X build of the reference's cross_atten/sd_cross_atten.py (:7-37, :39-70).
 Same constructor arguments and state-dict keys (q_proj, k_proj, v_proj, out_proj / in_proj, out_proj).  The four
-projections run on the bf16 MFMA GEMM; the K/V projections of the image condition (94 % of the trainable FLOPs) take the
-bf16 condition buffers of gfe_hip.train_ops.Condition in both GEMM layouts so neither forward nor weight gradient
-re-casts or transposes the 28 MB condition."""
+q / out projections run on the exact-f32 MFMA GEMM; the K/V projections of the image condition (94 % of the trainable FLOPs) on the
+bf16 one, reading the bf16 condition buffers of gfe_hip.train_ops.Condition in both GEMM layouts so neither forward nor weight
+gradient re-casts or transposes the 28 MB condition; the one-query softmax attention between them is gfe_cross_attn_q1."""
 import math
 
 import torch
 from torch import nn
 from torch.nn import functional as F
 
+from gfe_hip.head_ops import cross_attn_q1
 from gfe_hip.train_ops import Condition, Linear, linear
 
 
@@ -51,6 +52,8 @@ class CrossAttention(nn.Module):
             v = linear(a16, self.v_proj.weight, self.v_proj.bias, x16=a16, xT16=aT16).view(b, y.keys, d)
         else:
             k, v = self.k_proj(y), self.v_proj(y)
+        if lq == 1 and q.is_cuda:
+            return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))          # the classify path: one query per sample, one kernel each way
         q = q.view(b, -1, self.n_heads, self.d_head).transpose(1, 2)
         k = k.view(b, -1, self.n_heads, self.d_head).transpose(1, 2)
         v = v.view(b, -1, self.n_heads, self.d_head).transpose(1, 2)

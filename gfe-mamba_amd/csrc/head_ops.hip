@@ -1,0 +1,366 @@
+// The small operators of the trainable head (Cross_mamba_both), forward and backward, f32: everything between the Mamba stack's
+// GEMMs that the reference runs as strings of elementwise / softmax / LayerNorm torch ops.  All launch-bound sizes (B rows of 512):
+// one launch per operator and direction instead of 5-20 ATen launches.
+//
+//   embed_tokens   cross_atten/mamba_transformer.py:97-117   offset add + Embedding gather + NumericalEmbedder + cls + concat
+//   mean_tokens    mamba_transformer.py:122                  mean over the token axis
+//   cross_attn_q1  cross_atten/sd_cross_atten.py:58-68       one query per sample against Lkv keys, H heads: q k^T / sqrt(dh), softmax, @ v
+//   layernorm      mamba_transformer.py:79-82, corss_ft_transformer.py:16   nn.LayerNorm(dim) over (rows, dim)
+//   geglu          corss_ft_transformer.py:10-13, 19         x * gelu(gates) (exact erf GELU) followed by Dropout(p)
+//   bce_sigmoid    classify_mamba.py:104                     BCELoss(sigmoid(logit), y), mean over the batch, log clamped at -100
+#include "common.h"
+
+namespace {
+
+// ---- embed_tokens --------------------------------------------------------------------------------------------------------
+// out[b] = [cls | emb[x_cat[b, j] + offset[j]] (j < ncat) | x_num[b, j] * w[j] + bias[j] (j < ncont) | feat[b] (nf rows)]
+__global__ __launch_bounds__(256) void embed_tokens_fwd_kernel(const int64_t* __restrict__ x_cat, const int64_t* __restrict__ offsets,
+                                                               const float* __restrict__ emb, const float* __restrict__ x_num,
+                                                               const float* __restrict__ num_w, const float* __restrict__ num_b,
+                                                               const float* __restrict__ cls, const float* __restrict__ feat, float* __restrict__ out,
+                                                               int ncat, int ncont, int nf, int dim, int ntok) {
+    const int L = 1 + ncat + ncont + nf;
+    const int b = blockIdx.y, t = blockIdx.x;
+    float* o = out + ((size_t)b * L + t) * dim;
+    if (t == 0) {
+        for (int d = threadIdx.x; d < dim; d += 256) o[d] = cls[d];
+    } else if (t <= ncat) {
+        const int j = t - 1;
+        int64_t idx = x_cat[(size_t)b * ncat + j] + offsets[j];
+        idx = idx < 0 ? 0 : (idx >= ntok ? ntok - 1 : idx);              // (torch raises on an out-of-range index; never on valid tables)
+        for (int d = threadIdx.x; d < dim; d += 256) o[d] = emb[(size_t)idx * dim + d];
+    } else if (t <= ncat + ncont) {
+        const int j = t - 1 - ncat;
+        const float xv = x_num[(size_t)b * ncont + j];
+        for (int d = threadIdx.x; d < dim; d += 256) o[d] = fmaf(xv, num_w[(size_t)j * dim + d], num_b[(size_t)j * dim + d]);
+    } else {
+        const int j = t - 1 - ncat - ncont;
+        for (int d = threadIdx.x; d < dim; d += 256) o[d] = feat[((size_t)b * nf + j) * dim + d];
+    }
+}
+
+// gradients: one block per token slot t, threads over dim, loop over the batch (deterministic sums; atomics only for the embedding rows,
+// which different (b, j) may share)
+__global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ x_cat,
+                                                               const int64_t* __restrict__ offsets, const float* __restrict__ x_num,
+                                                               float* __restrict__ d_emb, float* __restrict__ d_num_w, float* __restrict__ d_num_b,
+                                                               float* __restrict__ d_cls, float* __restrict__ d_feat,
+                                                               int B, int ncat, int ncont, int nf, int dim, int ntok) {
+    const int L = 1 + ncat + ncont + nf;
+    const int t = blockIdx.x;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        if (t == 0) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += dout[((size_t)b * L) * dim + d];
+            d_cls[d] += s;
+        } else if (t <= ncat) {
+            const int j = t - 1;
+            for (int b = 0; b < B; ++b) {
+                int64_t idx = x_cat[(size_t)b * ncat + j] + offsets[j];
+                idx = idx < 0 ? 0 : (idx >= ntok ? ntok - 1 : idx);
+                atomicAdd(d_emb + (size_t)idx * dim + d, dout[((size_t)b * L + t) * dim + d]);
+            }
+        } else if (t <= ncat + ncont) {
+            const int j = t - 1 - ncat;
+            float sw = 0.f, sb = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float g = dout[((size_t)b * L + t) * dim + d];
+                sw = fmaf(g, x_num[(size_t)b * ncont + j], sw);
+                sb += g;
+            }
+            d_num_w[(size_t)j * dim + d] += sw;
+            d_num_b[(size_t)j * dim + d] += sb;
+        } else if (d_feat) {
+            const int j = t - 1 - ncat - ncont;
+            for (int b = 0; b < B; ++b) d_feat[((size_t)b * nf + j) * dim + d] = dout[((size_t)b * L + t) * dim + d];
+        }
+    }
+}
+
+// ---- mean over tokens ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_tokens_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int L, int dim) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        float s = 0.f;
+        for (int t = 0; t < L; ++t) s += x[((size_t)b * L + t) * dim + d];
+        y[(size_t)b * dim + d] = s / (float)L;
+    }
+}
+__global__ __launch_bounds__(256) void mean_tokens_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int L, int dim) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    for (int d = threadIdx.x; d < dim; d += 256) dx[((size_t)b * L + t) * dim + d] = dy[(size_t)b * dim + d] / (float)L;
+}
+
+// ---- cross attention with ONE query per sample -------------------------------------------------------------------------------
+// block = (head, sample), 256 threads.  scores over nk keys, softmax, out = sum_k p_k v_k.  probs (B, H, nk) kept for the backward.
+__global__ __launch_bounds__(256) void cross_attn_q1_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                float* __restrict__ out, float* __restrict__ probs, int H, int nk, int dh, float scale) {
+    extern __shared__ float sm[];                 // [nk] scores / probabilities, [16] reduction scratch
+    float* sp = sm;
+    float* scratch = sm + nk;
+    const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
+    const float* qp = q + (size_t)b * dim + h * dh;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < nk; j += 256) {
+        const float* kp = k + ((size_t)b * nk + j) * dim + h * dh;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(qp[d], kp[d], s);
+        s *= scale;
+        sp[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < nk; j += 256) {
+        const float e = __expf(sp[j] - mx);
+        sp[j] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, scratch + 4);
+    const float inv = 1.0f / sum;
+    for (int j = threadIdx.x; j < nk; j += 256) {
+        const float pj = sp[j] * inv;
+        sp[j] = pj;
+        probs[((size_t)b * H + h) * nk + j] = pj;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < dh; d += 256) {
+        float o = 0.f;
+        for (int j = 0; j < nk; ++j) o = fmaf(sp[j], v[((size_t)b * nk + j) * dim + h * dh + d], o);
+        out[(size_t)b * dim + h * dh + d] = o;
+    }
+}
+
+// dv = p dout^T, dp = dout . v, ds = p (dp - sum p dp), dq = scale * sum ds k, dk = scale * ds q
+__global__ __launch_bounds__(256) void cross_attn_q1_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                const float* __restrict__ probs, const float* __restrict__ dout,
+                                                                float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                                int H, int nk, int dh, float scale) {
+    extern __shared__ float sm[];                 // [nk] ds, [16] scratch
+    float* sds = sm;
+    float* scratch = sm + nk;
+    const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
+    const float* qp = q + (size_t)b * dim + h * dh;
+    const float* dop = dout + (size_t)b * dim + h * dh;
+    const float* pp = probs + ((size_t)b * H + h) * nk;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < nk; j += 256) {
+        const float* vp = v + ((size_t)b * nk + j) * dim + h * dh;
+        float dp = 0.f;
+        for (int d = 0; d < dh; ++d) dp = fmaf(dop[d], vp[d], dp);
+        sds[j] = dp;
+        acc = fmaf(pp[j], dp, acc);
+    }
+    acc = block_sum(acc, scratch);
+    for (int j = threadIdx.x; j < nk; j += 256) sds[j] = pp[j] * (sds[j] - acc) * scale;
+    __syncthreads();
+    // dk, dv rows (each thread: one (key, d) element at a time, coalesced over d)
+    for (int i = threadIdx.x; i < nk * dh; i += 256) {
+        const int j = i / dh, d = i - j * dh;
+        const size_t o = ((size_t)b * nk + j) * dim + h * dh + d;
+        dk[o] = sds[j] * qp[d];
+        dv[o] = pp[j] * dop[d];
+    }
+    for (int d = threadIdx.x; d < dh; d += 256) {
+        float s = 0.f;
+        for (int j = 0; j < nk; ++j) s = fmaf(sds[j], k[((size_t)b * nk + j) * dim + h * dh + d], s);
+        dq[(size_t)b * dim + h * dh + d] = s;
+    }
+}
+
+// ---- LayerNorm over (rows, dim): one block per row ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int dim, float eps) {
+    __shared__ float scratch[32];
+    const int r = blockIdx.x;
+    const float* xp = x + (size_t)r * dim;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < dim; d += 256) s += xp[d];
+    const float mu = block_sum(s, scratch) / (float)dim;
+    float v = 0.f;
+    for (int d = threadIdx.x; d < dim; d += 256) { const float c = xp[d] - mu; v = fmaf(c, c, v); }
+    const float var = block_sum(v, scratch + 16) / (float)dim;            // biased variance (torch.nn.LayerNorm)
+    const float rs = rsqrtf(var + eps);
+    for (int d = threadIdx.x; d < dim; d += 256) y[(size_t)r * dim + d] = fmaf((xp[d] - mu) * rs, gamma[d], beta[d]);
+    if (threadIdx.x == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum_rows dy * xhat, dbeta += sum_rows dy (f32 atomics: rows <= batch)
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int dim) {
+    __shared__ float scratch[32];
+    const int r = blockIdx.x;
+    const float mu = mean[r], rs = rstd[r];
+    const float* xp = x + (size_t)r * dim;
+    const float* gp = dy + (size_t)r * dim;
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        const float xh = (xp[d] - mu) * rs, g = gp[d] * gamma[d];
+        s1 += g; s2 = fmaf(g, xh, s2);
+    }
+    s1 = block_sum(s1, scratch) / (float)dim;
+    s2 = block_sum(s2, scratch + 16) / (float)dim;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        const float xh = (xp[d] - mu) * rs, g = gp[d] * gamma[d];
+        dx[(size_t)r * dim + d] = rs * (g - s1 - xh * s2);
+        atomicAdd(dgamma + d, gp[d] * xh);
+        atomicAdd(dbeta + d, gp[d]);
+    }
+}
+
+// ---- GEGLU + dropout ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+// counter-based uniform in [0, 1): one 32-bit hash of (seed, element index) -- reproducible from (seed, index) alone, so the backward
+// needs no stored mask and every rank / step draws its own stream by changing the seed
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int F, float p_drop, uint64_t seed) {
+    const float keep = 1.0f / (1.0f - p_drop);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * F; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / F; const int f = (int)(i - r * F);
+        const float a = x[r * 2 * F + f], g = x[r * 2 * F + F + f];
+        float o = a * gelu_erf_(g);
+        if (p_drop > 0.f) o = hash_uniform(seed, (uint32_t)i) < p_drop ? 0.f : o * keep;
+        y[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                        int64_t rows, int F, float p_drop, uint64_t seed) {
+    const float keep = 1.0f / (1.0f - p_drop);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * F; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / F; const int f = (int)(i - r * F);
+        const float a = x[r * 2 * F + f], g = x[r * 2 * F + F + f];
+        float d = dy[i];
+        if (p_drop > 0.f) d = hash_uniform(seed, (uint32_t)i) < p_drop ? 0.f : d * keep;
+        dx[r * 2 * F + f] = d * gelu_erf_(g);
+        dx[r * 2 * F + F + f] = d * a * gelu_erf_grad_(g);
+    }
+}
+
+// ---- BCELoss(sigmoid(z), y), mean over the batch ---------------------------------------------------------------------------
+// torch.nn.BCELoss clamps both logs at -100 in the forward; its backward is (p - y) / max(p (1 - p), 1e-12) (ATen
+// binary_cross_entropy_backward), which autograd then multiplies by the sigmoid's p (1 - p): (p - y) / n unless p (1 - p) < 1e-12,
+// where the quotient shrinks the gradient (z = -30, y = 1: -0.094 / n, not -1 / n) -- reproduced as the reference computes it.
+__global__ __launch_bounds__(256) void bce_sigmoid_fwd_kernel(const float* __restrict__ z, const float* __restrict__ y, float* __restrict__ loss,
+                                                              float* __restrict__ dz, int n) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float p = 1.0f / (1.0f + expf(-z[i]));
+        const float lp = fmaxf(logf(p), -100.0f), lq = fmaxf(logf(1.0f - p), -100.0f);
+        s -= y[i] * lp + (1.0f - y[i]) * lq;
+        if (dz) {
+            const float pq = p * (1.0f - p);
+            dz[i] = (p - y[i]) / fmaxf(pq, 1e-12f) * pq / (float)n;
+        }
+    }
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfe_embed_tokens_fwd(const int64_t* x_cat, const int64_t* offsets, const float* emb, const float* x_num, const float* num_w,
+                         const float* num_b, const float* cls, const float* feat, float* out,
+                         int64_t B, int64_t ncat, int64_t ncont, int64_t nf, int64_t dim, int64_t ntok, void* stream) {
+    GFE_REQUIRE(cls && out && (ncat == 0 || (x_cat && offsets && emb)) && (ncont == 0 || (x_num && num_w && num_b)) && (nf == 0 || feat), GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && ncat >= 0 && ncont >= 0 && nf >= 0 && dim > 0, GFE_ERR_SHAPE);
+    const int64_t L = 1 + ncat + ncont + nf;
+    hipLaunchKernelGGL(embed_tokens_fwd_kernel, dim3((unsigned)L, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x_cat, offsets, emb, x_num, num_w, num_b,
+                       cls, feat, out, (int)ncat, (int)ncont, (int)nf, (int)dim, (int)ntok);
+    return gfe_launch_status();
+}
+
+int gfe_embed_tokens_bwd(const float* dout, const int64_t* x_cat, const int64_t* offsets, const float* x_num,
+                         float* d_emb, float* d_num_w, float* d_num_b, float* d_cls, float* d_feat,
+                         int64_t B, int64_t ncat, int64_t ncont, int64_t nf, int64_t dim, int64_t ntok, void* stream) {
+    GFE_REQUIRE(dout && d_cls && (ncat == 0 || (x_cat && offsets && d_emb)) && (ncont == 0 || (x_num && d_num_w && d_num_b)), GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && dim > 0, GFE_ERR_SHAPE);
+    const int64_t L = 1 + ncat + ncont + nf;
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3((unsigned)L), dim3(256), 0, (hipStream_t)stream, dout, x_cat, offsets, x_num, d_emb, d_num_w, d_num_b,
+                       d_cls, d_feat, (int)B, (int)ncat, (int)ncont, (int)nf, (int)dim, (int)ntok);
+    return gfe_launch_status();
+}
+
+int gfe_mean_tokens_fwd(const float* x, float* y, int64_t B, int64_t L, int64_t dim, void* stream) {
+    GFE_REQUIRE(x && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && L > 0 && dim > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(mean_tokens_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, y, (int)L, (int)dim);
+    return gfe_launch_status();
+}
+int gfe_mean_tokens_bwd(const float* dy, float* dx, int64_t B, int64_t L, int64_t dim, void* stream) {
+    GFE_REQUIRE(dy && dx, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && dim > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(mean_tokens_bwd_kernel, dim3((unsigned)L, (unsigned)B), dim3(256), 0, (hipStream_t)stream, dy, dx, (int)L, (int)dim);
+    return gfe_launch_status();
+}
+
+int gfe_cross_attn_q1_fwd(const float* q, const float* k, const float* v, float* out, float* probs,
+                          int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream) {
+    GFE_REQUIRE(q && k && v && out && probs, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && nk > 0 && nk <= 8192 && dh > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(cross_attn_q1_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 32) * sizeof(float), (hipStream_t)stream,
+                       q, k, v, out, probs, (int)H, (int)nk, (int)dh, scale);
+    return gfe_launch_status();
+}
+int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                          float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream) {
+    GFE_REQUIRE(q && k && v && probs && dout && dq && dk && dv, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && nk > 0 && nk <= 8192 && dh > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(cross_attn_q1_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 32) * sizeof(float), (hipStream_t)stream,
+                       q, k, v, probs, dout, dq, dk, dv, (int)H, (int)nk, (int)dh, scale);
+    return gfe_launch_status();
+}
+
+int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                           int64_t rows, int64_t dim, float eps, void* stream) {
+    GFE_REQUIRE(x && gamma && beta && y && mean && rstd, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (int)dim, eps);
+    return gfe_launch_status();
+}
+int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                           float* dgamma, float* dbeta, int64_t rows, int64_t dim, void* stream) {
+    GFE_REQUIRE(x && gamma && mean && rstd && dy && dx && dgamma && dbeta, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, (int)dim);
+    return gfe_launch_status();
+}
+
+int gfe_geglu_fwd(const float* x, float* y, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream) {
+    GFE_REQUIRE(x && y, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && F > 0 && rows * F <= 0x7fffffff && p_drop >= 0.f && p_drop < 1.f, GFE_ERR_SHAPE);
+    int64_t g = ceil_div(rows * F, 256); if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, rows, (int)F, p_drop, (uint64_t)seed);
+    return gfe_launch_status();
+}
+int gfe_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream) {
+    GFE_REQUIRE(x && dy && dx, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && F > 0 && rows * F <= 0x7fffffff && p_drop >= 0.f && p_drop < 1.f, GFE_ERR_SHAPE);
+    int64_t g = ceil_div(rows * F, 256); if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, (int)F, p_drop, (uint64_t)seed);
+    return gfe_launch_status();
+}
+
+int gfe_bce_sigmoid(const float* logits, const float* y, float* loss, float* dlogits, int64_t n, void* stream) {
+    GFE_REQUIRE(logits && y && loss, GFE_ERR_NULL);
+    GFE_REQUIRE(n > 0 && n <= 0x7fffffff, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(bce_sigmoid_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, y, loss, dlogits, (int)n);
+    return gfe_launch_status();
+}
+
+}  // extern "C"

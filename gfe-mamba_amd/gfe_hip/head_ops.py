@@ -1,0 +1,217 @@
+"""Autograd wrappers of the head's small operators (include/gfe_hip.h, csrc/head_ops.hip): token embedding + concat, mean over tokens,
+one-query cross attention, LayerNorm over rows, GEGLU + dropout, BCE(sigmoid).  f32, one launch per operator and direction."""
+import torch
+
+from . import call, ptr, stream
+from .train_ops import _grad_slot
+
+
+def _f(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"gfe_hip {what} needs CUDA/HIP tensors (no CPU fallback)")
+
+
+def _acc_target(param):
+    """(buffer to accumulate into, True if it is the parameter's own gradient slot)."""
+    slot = _grad_slot(param)
+    if slot is not None:
+        return slot, True
+    return torch.zeros(param.shape, dtype=torch.float32, device=param.device), False
+
+
+class _EmbedTokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cat, offsets, emb, x_num, num_w, num_b, cls, feat):
+        B = next(t.shape[0] for t in (x_cat, x_num, feat) if t is not None)
+        ncat = 0 if x_cat is None else x_cat.shape[1]
+        ncont = 0 if x_num is None else x_num.shape[1]
+        nf = 0 if feat is None else feat.shape[1]
+        dim = cls.shape[-1]
+        xc = None if x_cat is None else x_cat.detach().to(torch.int64).contiguous()
+        off = None if offsets is None else offsets.detach().to(torch.int64).contiguous()
+        xn, ft = _f(x_num), _f(feat)
+        out = torch.empty((B, 1 + ncat + ncont + nf, dim), dtype=torch.float32, device=cls.device)
+        call("gfe_embed_tokens_fwd", ptr(xc), ptr(off), ptr(_f(emb)), ptr(xn), ptr(_f(num_w)), ptr(_f(num_b)), ptr(_f(cls)), ptr(ft), ptr(out),
+             B, ncat, ncont, nf, dim, 0 if emb is None else emb.shape[0], stream())
+        ctx.save_for_backward(xc, off, xn)
+        ctx.refs = (emb, num_w, num_b, cls)
+        ctx.meta = (B, ncat, ncont, nf, dim, feat is not None and feat.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, off, xn = ctx.saved_tensors
+        emb, num_w, num_b, cls = ctx.refs
+        B, ncat, ncont, nf, dim, want_feat = ctx.meta
+        d = dout.float().contiguous()
+        tg = [(_acc_target(p) if p is not None else (None, True)) for p in (emb, num_w, num_b, cls)]
+        dfeat = torch.empty((B, nf, dim), dtype=torch.float32, device=d.device) if (nf and want_feat) else None
+        call("gfe_embed_tokens_bwd", ptr(d), ptr(xc), ptr(off), ptr(xn), ptr(tg[0][0]), ptr(tg[1][0]), ptr(tg[2][0]), ptr(tg[3][0]), ptr(dfeat),
+             B, ncat, ncont, nf, dim, 0 if emb is None else emb.shape[0], stream())
+        g = [None if own else buf.view(p.shape) for (buf, own), p in zip(tg, (emb, num_w, num_b, cls))]
+        return None, None, g[0], None, g[1], g[2], g[3], dfeat
+
+
+def embed_tokens(x_cat, offsets, emb, x_num, num_w, num_b, cls, feat):
+    """[cls | Embedding(x_cat + offsets) | x_num * w + b | feat] as one (B, L, dim) f32 tensor (mamba_transformer.py:97-117)."""
+    _need_cuda(cls, "embed_tokens")
+    return _EmbedTokens.apply(x_cat, offsets, emb, x_num, num_w, num_b, cls, feat)
+
+
+class _MeanTokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, L, dim = x.shape
+        x_ = _f(x)
+        y = torch.empty((B, 1, dim), dtype=torch.float32, device=x.device)
+        call("gfe_mean_tokens_fwd", ptr(x_), ptr(y), B, L, dim, stream())
+        ctx.shape = (B, L, dim)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, dim = ctx.shape
+        dx = torch.empty((B, L, dim), dtype=torch.float32, device=dy.device)
+        call("gfe_mean_tokens_bwd", ptr(dy.float().contiguous()), ptr(dx), B, L, dim, stream())
+        return dx
+
+
+def mean_tokens(x):
+    """torch.mean(x, dim=1, keepdims=True) (mamba_transformer.py:122)."""
+    _need_cuda(x, "mean_tokens")
+    return _MeanTokens.apply(x)
+
+
+class _CrossAttnQ1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, n_heads):
+        B, nk, dim = k.shape
+        dh = dim // n_heads
+        q_, k_, v_ = _f(q).view(B, dim), _f(k), _f(v)
+        out = torch.empty((B, dim), dtype=torch.float32, device=q.device)
+        probs = torch.empty((B, n_heads, nk), dtype=torch.float32, device=q.device)
+        scale = dh ** -0.5
+        call("gfe_cross_attn_q1_fwd", ptr(q_), ptr(k_), ptr(v_), ptr(out), ptr(probs), B, n_heads, nk, dh, scale, stream())
+        ctx.save_for_backward(q_, k_, v_, probs)
+        ctx.meta = (B, n_heads, nk, dh, scale, q.shape)
+        return out.view(q.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_, k_, v_, probs = ctx.saved_tensors
+        B, H, nk, dh, scale, qshape = ctx.meta
+        d = dout.float().contiguous()
+        dq, dk, dv = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
+        call("gfe_cross_attn_q1_bwd", ptr(q_), ptr(k_), ptr(v_), ptr(probs), ptr(d), ptr(dq), ptr(dk), ptr(dv), B, H, nk, dh, scale, stream())
+        return dq.view(qshape), dk, dv, None
+
+
+def cross_attn_q1(q, k, v, n_heads):
+    """softmax(q k^T / sqrt(d_head)) v per head with ONE query per sample: q (B, 1, dim), k / v (B, nk, dim) -> (B, 1, dim)
+    (sd_cross_atten.py:58-68 between the projections)."""
+    _need_cuda(q, "cross_attn_q1")
+    assert q.shape[1] == 1
+    return _CrossAttnQ1.apply(q, k, v, n_heads)
+
+
+class _LayerNormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xs = x.shape
+        x2 = _f(x).reshape(-1, xs[-1])
+        g_, b_ = _f(gamma), _f(beta)
+        rows, dim = x2.shape
+        y = torch.empty_like(x2)
+        st = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        call("gfe_layernorm_rows_fwd", ptr(x2), ptr(g_), ptr(b_), ptr(y), ptr(st[0]), ptr(st[1]), rows, dim, float(eps), stream())
+        ctx.save_for_backward(x2, g_, st)
+        ctx.refs = (gamma, beta)
+        ctx.xs = xs
+        return y.view(xs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g_, st = ctx.saved_tensors
+        gamma, beta = ctx.refs
+        rows, dim = x2.shape
+        d = dy.float().reshape(rows, dim).contiguous()
+        dx = torch.empty_like(x2)
+        (dg, own_g), (db, own_b) = _acc_target(gamma), _acc_target(beta)
+        call("gfe_layernorm_rows_bwd", ptr(x2), ptr(g_), ptr(st[0]), ptr(st[1]), ptr(d), ptr(dx), ptr(dg), ptr(db), rows, dim, stream())
+        return dx.view(ctx.xs), (None if own_g else dg), (None if own_b else db), None
+
+
+def layernorm_rows(x, gamma, beta, eps=1e-5):
+    _need_cuda(x, "layernorm_rows")
+    return _LayerNormRows.apply(x, gamma, beta, eps)
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm over the last dimension (same parameters / state-dict keys), one launch each way."""
+
+    def forward(self, x):
+        return layernorm_rows(x, self.weight, self.bias, self.eps)
+
+
+class _Geglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p_drop, seed):
+        xs = x.shape
+        F2 = xs[-1]
+        x2 = _f(x).reshape(-1, F2)
+        y = torch.empty((x2.shape[0], F2 // 2), dtype=torch.float32, device=x.device)
+        call("gfe_geglu_fwd", ptr(x2), ptr(y), x2.shape[0], F2 // 2, float(p_drop), int(seed), stream())
+        ctx.save_for_backward(x2)
+        ctx.meta = (xs, float(p_drop), int(seed))
+        return y.view(xs[:-1] + (F2 // 2,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        xs, p_drop, seed = ctx.meta
+        d = dy.float().reshape(x2.shape[0], -1).contiguous()
+        dx = torch.empty_like(x2)
+        call("gfe_geglu_bwd", ptr(x2), ptr(d), ptr(dx), x2.shape[0], x2.shape[1] // 2, p_drop, seed, stream())
+        return dx.view(xs), None, None
+
+
+_DROP_CALLS = [0]
+
+
+def geglu_dropout(x, p_drop=0.0, training=False):
+    """x, gates = chunk(2, -1); dropout(x * gelu(gates), p) (corss_ft_transformer.py:10-13, 19).  The dropout mask comes from a
+    counter-based hash seeded from torch's generator state (torch.initial_seed(): per-rank seeds give per-rank masks) and a call counter."""
+    _need_cuda(x, "geglu")
+    p = float(p_drop) if training else 0.0
+    seed = 0
+    if p > 0.0:
+        _DROP_CALLS[0] += 1
+        seed = (torch.initial_seed() * 1000003 + _DROP_CALLS[0]) & 0x7FFFFFFFFFFFFFFF
+    return _Geglu.apply(x, p, seed)
+
+
+class _BceSigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y):
+        z, t = _f(logits).reshape(-1), _f(y).reshape(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        call("gfe_bce_sigmoid", ptr(z), ptr(t), ptr(loss), ptr(dz), z.numel(), stream())
+        ctx.save_for_backward(dz)
+        ctx.shape = logits.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dz,) = ctx.saved_tensors
+        return (dz * dloss).view(ctx.shape), None
+
+
+def bce_sigmoid(logits, y):
+    """nn.BCELoss()(sigmoid(logits), y.float()) (classify_mamba.py:67, 104): value and gradient from one launch."""
+    _need_cuda(logits, "bce_sigmoid")
+    return _BceSigmoid.apply(logits, y)

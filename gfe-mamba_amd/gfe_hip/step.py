@@ -7,6 +7,7 @@ global batch (BCELoss is a batch mean).
 import torch
 import torch.nn.functional as F
 
+from .head_ops import bce_sigmoid
 from .train_ops import Condition, FlatAdam
 
 
@@ -55,12 +56,12 @@ class ClassifyStep:
     # gaps of the generator's persistent conv kernels instead of having the chip to themselves.  Same arithmetic, same order of
     # updates, one generator forward and one head step per call -- measured 15.9 -> 13.8 ms/step at 8 volumes (tools/pipeline_probe.py).
     def _generate_async(self, x):
-        """Generator forward on the current stream; returns (x, outputs, event recorded behind them)."""
+        """Generator forward on the current stream; returns (x, outputs, event recorded behind them, (version, address) of x)."""
         with torch.no_grad():
             outs = self.gen(x, output_vit_mid=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        return x, outs, ev
+        return x, outs, ev, (x._version, x.data_ptr())
 
     def join(self):
         """Make the current stream wait for a head step that train_step_pipelined left running on the head stream."""
@@ -77,11 +78,19 @@ class ClassifyStep:
         if getattr(self, "_head_stream", None) is None:
             self._head_stream = torch.cuda.Stream()
         H = self._head_stream
+        # Whatever the caller enqueues on its stream from here on (refilling the previous call's input buffers, the usual
+        # double-buffered loader) is ordered behind the previous head step, which still read them.  Inputs of THIS call must stay
+        # unmodified until the next call returns, or join().
+        prev = getattr(self, "_head_done", None)
+        if prev is not None:
+            G.wait_event(prev)
         pf = getattr(self, "_prefetched", None)
-        if pf is None or pf[0] is not x:
+        # the announced batch is recognised by identity AND content version AND address: a loader that refills the same tensor in place
+        # (or a new tensor at a recycled address) gets a fresh generator forward, never the previous batch's outputs
+        if pf is None or pf[0] is not x or pf[3] != (x._version, x.data_ptr()):
             pf = self._generate_async(x)                      # pipeline prologue (or a batch nobody announced)
         self._prefetched = None
-        _, (mid_input, mid_output, pet), ev = pf
+        _, (mid_input, mid_output, pet), ev, _ = pf
         H.wait_stream(G)                                      # inputs, and everything else the caller queued before this call
         H.wait_event(ev)
         with torch.cuda.stream(H):
@@ -91,7 +100,7 @@ class ClassifyStep:
             self.opt.zero_grad()
             mid_feature = self.head(mid_input, mid_output)
             pred = self.ft(x_cat, x_num, mid_feature, Condition([x, pet]))
-            loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.float())
+            loss = bce_sigmoid(pred.squeeze(1), y)                       # classify_mamba.py:104, value + gradient in one launch
             loss.backward()
             self.opt.step(self.world_size, self.group)
             self._head_done = torch.cuda.Event()
@@ -114,7 +123,7 @@ class ClassifyStep:
     def train_step(self, x, x_cat, x_num, y):
         self.head.train(); self.ft.train()
         pred, _ = self.forward(x, x_cat, x_num, _before_head=self.opt.zero_grad)   # optimizer.zero_grad() (:109), moved behind the frozen generator
-        loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.float())  # :104
+        loss = bce_sigmoid(pred.squeeze(1), y)                                     # :104
         loss.backward()                                                            # :105
         self.opt.step(self.world_size, self.group, overlap=self.overlap_update)   # all-reduce, clip (:106-107), Adam (:108)
         return loss.detach()
@@ -131,7 +140,7 @@ class ClassifyStep:
             def fwd_bwd():
                 self.opt.zero_grad()
                 pred, _ = self.forward(self._gin[0], self._gin[1], self._gin[2])
-                loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), self._gin[3].float())
+                loss = bce_sigmoid(pred.squeeze(1), self._gin[3])
                 loss.backward()
                 return loss.detach()
 

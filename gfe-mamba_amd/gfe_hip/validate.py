@@ -96,10 +96,17 @@ def save_checkpoint(step, run_dir, kind="current"):
 
 
 def load_checkpoint(step, run_dir, kind="current"):
-    """Inverse of save_checkpoint; parameters are copied INTO the flat buffers (the views stay valid) and the bf16 shadows follow."""
+    """Inverse of save_checkpoint; parameters are copied INTO the flat buffers (the views stay valid) and the bf16 shadows follow.
+    Ordered against a head step still running on the pipeline's head stream and against an overlapped update (as save_checkpoint is);
+    the head stream in turn waits for the load before its next step."""
+    step.join()
+    step.opt.wait_updated()
     for f, module in zip(_FILES[kind], (step.head, step.ft)):
         sd = torch.load(os.path.join(run_dir, f), map_location="cpu")
         missing, unexpected = module.load_state_dict(sd, strict=True)
         assert not missing and not unexpected
     step.opt.flat_p16.copy_(step.opt.flat_p)
     step.opt._register_shadows()                    # load_state_dict bumped the parameters' versions
+    hs = getattr(step, "_head_stream", None)
+    if hs is not None:
+        hs.wait_stream(torch.cuda.current_stream())

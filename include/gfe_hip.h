@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 22
+#define GFE_ABI_VERSION 23
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -287,6 +287,47 @@ int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt,
 /* Weight gradient of the above: dW[s][hw] = sum_{b,c} dout[b][c][s] * mid[b][hw][c]; dout: (B, 2C, S) f32; dW: (S, HW) f32. */
 int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* dout, float* dW,
                          int64_t B, int64_t HW, int64_t C, int64_t S, void* stream);
+
+/* ---- small operators of the trainable head, f32, one launch per operator and direction (csrc/head_ops.hip) ----------------- */
+
+/* Token sequence of Cross_mamba_both (cross_atten/mamba_transformer.py:97-117): out (B, L, dim), L = 1 + ncat + ncont + nf,
+ *   out[b] = [cls | emb[x_cat[b,j] + offsets[j]] | x_num[b,j] * num_w[j] + num_b[j] (NumericalEmbedder, corss_ft_transformer.py:159-163) | feat[b]].
+ *   x_cat (B, ncat) int64, offsets (ncat) int64 (the categories_offset buffer), emb (ntok, dim), feat (B, nf, dim) or NULL when nf = 0.
+ * bwd: d_emb / d_num_w / d_num_b / d_cls are ACCUMULATED into (gradient buffers), d_feat (B, nf, dim) is written (NULL: not wanted). */
+int gfe_embed_tokens_fwd(const int64_t* x_cat, const int64_t* offsets, const float* emb, const float* x_num, const float* num_w,
+                         const float* num_b, const float* cls, const float* feat, float* out,
+                         int64_t B, int64_t ncat, int64_t ncont, int64_t nf, int64_t dim, int64_t ntok, void* stream);
+int gfe_embed_tokens_bwd(const float* dout, const int64_t* x_cat, const int64_t* offsets, const float* x_num,
+                         float* d_emb, float* d_num_w, float* d_num_b, float* d_cls, float* d_feat,
+                         int64_t B, int64_t ncat, int64_t ncont, int64_t nf, int64_t dim, int64_t ntok, void* stream);
+
+/* torch.mean(x, dim=1) over (B, L, dim) (mamba_transformer.py:122) and its adjoint. */
+int gfe_mean_tokens_fwd(const float* x, float* y, int64_t B, int64_t L, int64_t dim, void* stream);
+int gfe_mean_tokens_bwd(const float* dy, float* dx, int64_t B, int64_t L, int64_t dim, void* stream);
+
+/* Core of CrossAttention with one query per sample (cross_atten/sd_cross_atten.py:58-68): q (B, H*dh), k / v (B, nk, H*dh),
+ * out (B, H*dh) = softmax(q k^T * scale) v per head; probs (B, H, nk) is kept for the backward.  bwd writes dq, dk, dv. */
+int gfe_cross_attn_q1_fwd(const float* q, const float* k, const float* v, float* out, float* probs,
+                          int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
+int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                          float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
+
+/* nn.LayerNorm(dim) over (rows, dim) f32 (mamba_transformer.py:79-82, corss_ft_transformer.py:16); mean / rstd (rows) kept for the
+ * backward, which ACCUMULATES dgamma / dbeta (f32 atomics) and writes dx. */
+int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                           int64_t rows, int64_t dim, float eps, void* stream);
+int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                           float* dgamma, float* dbeta, int64_t rows, int64_t dim, void* stream);
+
+/* GEGLU (corss_ft_transformer.py:10-13: x, gates = chunk(2); x * gelu(gates), exact erf) followed by Dropout(p_drop) (:19):
+ * x (rows, 2F) -> y (rows, F).  The mask is a counter-based hash of (seed, element index): the backward regenerates it from the
+ * same seed; p_drop = 0 in eval mode. */
+int gfe_geglu_fwd(const float* x, float* y, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream);
+int gfe_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream);
+
+/* BCELoss(sigmoid(logits), y), mean over n samples (classify_mamba.py:67, 104), logs clamped at -100 as torch does: loss[0], and
+ * (dlogits != NULL) the gradient of that mean loss w.r.t. the logits in the same launch. */
+int gfe_bce_sigmoid(const float* logits, const float* y, float* loss, float* dlogits, int64_t n, void* stream);
 
 /* Per-PARAMETER clip_grad_norm_(p, max_norm) followed by one Adam step (classify_mamba.py:64, 106-108) over flat f32
  * buffers holding every trainable tensor back to back.  chunks: device array of {int64 offset, int32 length, int32 tensor_id}

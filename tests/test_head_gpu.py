@@ -429,3 +429,88 @@ def test_pipelined_step_matches_serial_step():
         assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
         assert (p0 - p1).abs().max().item() < 4e-4
         assert abs(e0 - e1) < 1e-3
+
+
+def test_head_small_ops_vs_torch_and_reference_fixture():
+    """gfe_embed_tokens / mean_tokens / cross_attn_q1 / layernorm_rows / geglu / bce_sigmoid (include/gfe_hip.h): forward and every
+    gradient against the same arithmetic in torch fp64 autograd, and the CrossAttention / FeedForward fixtures of the reference for the
+    one-query geometry (the op-level fixture test above goes through them with 6 keys x 3 queries)."""
+    from gfe_hip import head_ops as Hd
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g)
+    dd = lambda t: t.detach().double().cpu().requires_grad_(True)
+    # --- embed_tokens: offsets of the synthetic table (11,2,2,4,4,3,3 with 2 special tokens -> [2,13,15,17,21,25,28])
+    cards = (11, 2, 2, 4, 4, 3, 3)
+    B, dim, ncont, nf = 3, 40, 5, 4
+    off = torch.tensor([2, 13, 15, 17, 21, 25, 28])
+    x_cat = torch.stack([torch.randint(0, c, (B,), generator=g) for c in cards], 1)
+    x_cat[1, 0] = x_cat[0, 0]                                             # a shared embedding row: gradients must add
+    emb, x_num, nw, nb, cls, feat = r(sum(cards) + 2, dim), r(B, ncont), r(ncont, dim), r(ncont, dim), r(1, 1, dim), r(B, nf, dim)
+    w = r(B, 1 + len(cards) + ncont + nf, dim)
+    gp = [t.to(DEV).requires_grad_(True) for t in (emb, nw, nb, cls, feat)]
+    out = Hd.embed_tokens(x_cat.to(DEV), off.to(DEV), gp[0], x_num.to(DEV), gp[1], gp[2], gp[3], gp[4])
+    cp = [dd(t) for t in (emb, nw, nb, cls, feat)]
+    ref = torch.cat([cp[3].expand(B, -1, -1), cp[0][x_cat + off], x_num.double().unsqueeze(-1) * cp[1] + cp[2], cp[4]], 1)
+    assert torch.equal(out.cpu().double()[:, :8], ref.detach()[:, :8])                      # gather and cls rows: exact copies
+    assert rel_err(out, ref) < 1e-6
+    (out * w.to(DEV)).sum().backward(); (ref * w.double()).sum().backward()
+    for a, b in zip(gp, cp):
+        assert rel_err(a.grad, b.grad) < 1e-5
+    # without the table / without image tokens (Cross_mamba_ablation's switches)
+    o2 = Hd.embed_tokens(None, None, None, None, None, None, gp[3], gp[4])
+    assert torch.equal(o2.cpu(), torch.cat([cls.expand(B, -1, -1), feat], 1))
+    # --- mean over tokens
+    x = r(3, 37, 64)
+    xg, xc = x.to(DEV).requires_grad_(True), dd(x)
+    m, mr = Hd.mean_tokens(xg), xc.mean(1, keepdim=True)
+    assert rel_err(m, mr) < 1e-6
+    m.sum().backward(); mr.sum().backward()
+    assert rel_err(xg.grad, xc.grad) < 1e-6
+    # --- one-query cross attention, 8 heads x 64, 192 keys (the real geometry) and a ragged one
+    for (B, H, nk, dh) in ((2, 8, 192, 64), (3, 2, 7, 8)):
+        q, k, v, w = r(B, 1, H * dh), r(B, nk, H * dh), r(B, nk, H * dh), r(B, 1, H * dh)
+        gq, gk, gv = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        cq, ck, cv = dd(q), dd(k), dd(v)
+        o = Hd.cross_attn_q1(gq, gk, gv, H)
+        sp = lambda t: t.view(B, -1, H, dh).transpose(1, 2)
+        ro = (torch.softmax(sp(cq) @ sp(ck).transpose(-1, -2) / dh ** 0.5, -1) @ sp(cv)).transpose(1, 2).reshape(B, 1, H * dh)   # sd_cross_atten.py:58-68
+        assert rel_err(o, ro) < 1e-5
+        (o * w.to(DEV)).sum().backward(); (ro * w.double()).sum().backward()
+        for a, b in ((gq, cq), (gk, ck), (gv, cv)):
+            assert rel_err(a.grad, b.grad) < 1e-5
+    # --- LayerNorm over rows
+    x, ga, be, w = r(5, 512) * 3 + 1, r(512), r(512), r(5, 512)
+    gx, gg, gb = (t.to(DEV).requires_grad_(True) for t in (x, ga, be))
+    cx, cg, cb = dd(x), dd(ga), dd(be)
+    y, yr = Hd.layernorm_rows(gx, gg, gb), F.layer_norm(cx, (512,), cg, cb)
+    assert rel_err(y, yr) < 1e-5
+    (y * w.to(DEV)).sum().backward(); (yr * w.double()).sum().backward()
+    for a, b in ((gx, cx), (gg, cg), (gb, cb)):
+        assert rel_err(a.grad, b.grad) < 1e-5
+    # --- GEGLU (no dropout: exact), then the dropout statistics and mask consistency between forward and backward
+    x, w = r(6, 2048), r(6, 1024)
+    gx, cx = x.to(DEV).requires_grad_(True), dd(x)
+    y = Hd.geglu_dropout(gx)
+    a_, g_ = cx.chunk(2, -1)
+    yr = a_ * F.gelu(g_)
+    assert rel_err(y, yr) < 1e-6
+    (y * w.to(DEV)).sum().backward(); (yr * w.double()).sum().backward()
+    assert rel_err(gx.grad, cx.grad) < 1e-5
+    gx2 = x.to(DEV).requires_grad_(True)
+    yd = Hd.geglu_dropout(gx2, 0.1, training=True)
+    kept = (yd != 0).float().mean().item()
+    assert 0.86 < kept < 0.94                                                         # Dropout(0.1)
+    assert rel_err(yd[yd != 0], (y.detach() / 0.9)[yd != 0]) < 1e-6                   # survivors scaled by 1 / (1 - p)
+    yd.sum().backward()
+    assert torch.equal(gx2.grad[:, :1024] == 0, yd == 0)                              # the backward regenerates the same mask
+    yd2 = Hd.geglu_dropout(x.to(DEV), 0.1, training=True)
+    assert not torch.equal(yd2 == 0, yd == 0)                                         # a new mask on every call
+    # --- BCE(sigmoid): value and gradient, saturated logits included (torch clamps the logs at -100)
+    z = torch.tensor([0.3, -2.0, 5.0, -30.0, 30.0, 120.0, -120.0, 0.0])
+    t = torch.tensor([1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0])
+    gz = z.to(DEV).requires_grad_(True)
+    cz = z.clone().requires_grad_(True)
+    loss, lref = Hd.bce_sigmoid(gz, t.to(DEV)), F.binary_cross_entropy(torch.sigmoid(cz), t)
+    assert abs(loss.item() - lref.item()) < 1e-5 * max(1.0, lref.item())
+    loss.backward(); lref.backward()
+    assert (gz.grad.cpu() - cz.grad).abs().max() < 1e-6
