@@ -227,8 +227,21 @@ def conv_c1_k3_tables(w32_oct, scale, shift, w1, b1):
         m = _C1_MASK[str(dev)] = torch.tensor(rows, dtype=torch.float32, device=dev)
     sw = scale * w1                                                   # (B, Cin)
     sh = scale * b1 + shift
-    both = torch.einsum('oct,nbc->nbto', w32_oct, torch.stack([sw, sh]))      # (2, B, 27, Cout)
-    return both[0].contiguous(), torch.matmul(m, both[1]).contiguous()
+    # weight-only factors, cached: Wt[(t, o)][c] = W[o][c][t] and Wm[(cls, o)][c] = sum_t mask[cls][t] W[o][c][t]; the per-sample tables
+    # are then two small f32 MFMA GEMMs (gfe_gemm_f32), no library GEMM on the path
+    key = (w32_oct.data_ptr(), w32_oct._version)
+    ent = _C1_WT.get(str(dev))
+    if ent is None or ent[0] != key:
+        cout, cin = w32_oct.shape[0], w32_oct.shape[1]
+        wt = w32_oct.permute(2, 0, 1).reshape(27 * cout, cin).contiguous()
+        wm = gemm_f32(m, False, w32_oct.permute(2, 0, 1).reshape(27, cout * cin).contiguous(), True).reshape(64 * cout, cin)
+        ent = _C1_WT[str(dev)] = (key, wt, wm)
+    _, wt, wm = ent
+    B, cout = scale.shape[0], w32_oct.shape[0]
+    return gemm_f32(sw, False, wt, False).view(B, 27, cout), gemm_f32(sh, False, wm, False).view(B, 64, cout)
+
+
+_C1_WT = {}
 
 
 def lift_groupnorm_affine(x, w1, b1, gamma, beta, groups, eps=1e-5):
@@ -378,7 +391,9 @@ def gemm_f32(a, a_t, b, b_t, bias=None, accum_into=None):
     assert (b.shape[0] if b_t else b.shape[1]) == K and unit(a) and unit(b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32
     blocks = -(-M // 64) * -(-N // 64)
-    split_k = 1 if blocks >= 128 or K < 256 else min(16, K // 128, max(1, 256 // blocks))     # few-block shapes (x_proj: 5 blocks x 1024 deep)
+    # launch-bound sizes (a launch costs ~5 us whatever it does; the atomics of a split add 5-10 us): split only the few-block deep
+    # shapes (x_proj: 5 blocks x 1024 deep) so that ~64 blocks are in flight with >= 8 k-steps each
+    split_k = 1 if blocks >= 32 or K < 512 else max(1, min(8, K // 256, 64 // blocks))
     if accum_into is not None:
         assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and unit(accum_into) and bias is None
         out = accum_into
