@@ -148,6 +148,27 @@ __global__ __launch_bounds__(256) void an_apply_kernel(const float* __restrict__
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) yb[i] = f(xb[i]);
 }
 
+
+// ---- Resized(spatial_size) of the loader (dataloader/pic_table_loader.py:58: monai Resized, default mode "area" = torch
+// F.interpolate(mode="area") = adaptive average pooling): out[i] = mean of in[floor(i D/d) .. ceil((i+1) D/d)) per axis. --------
+__global__ __launch_bounds__(256) void resize_area_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W, int d, int h, int w) {
+    const int64_t n = (int64_t)d * h * w;
+    const float* xb = x + (size_t)blockIdx.y * D * H * W;
+    float* yb = y + (size_t)blockIdx.y * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int ow = (int)(i % w), oh = (int)((i / w) % h), od = (int)(i / ((int64_t)w * h));
+        // start = floor(o * in / out), end = ceil((o + 1) * in / out)   (ATen adaptive pooling index rule)
+        const int d0 = (int)(((int64_t)od * D) / d), d1 = (int)((((int64_t)od + 1) * D + d - 1) / d);
+        const int h0 = (int)(((int64_t)oh * H) / h), h1 = (int)((((int64_t)oh + 1) * H + h - 1) / h);
+        const int w0 = (int)(((int64_t)ow * W) / w), w1 = (int)((((int64_t)ow + 1) * W + w - 1) / w);
+        float s = 0.f;
+        for (int a = d0; a < d1; ++a)
+            for (int b = h0; b < h1; ++b)
+                for (int c = w0; c < w1; ++c) s += xb[((size_t)a * H + b) * W + c];
+        yb[i] = s / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -169,6 +190,15 @@ int gfe_adaptive_normal(const float* x, float* y, uint32_t* ws, int64_t B, int64
     hipLaunchKernelGGL(an_hist_kernel<2>, grid, dim3(HIST_THREADS), 0, st, x, ws, n);
     hipLaunchKernelGGL(an_select_kernel<2>, dim3((unsigned)B), dim3(256), 0, st, ws);
     hipLaunchKernelGGL(an_apply_kernel, grid, dim3(256), 0, st, x, y, ws, n);
+    return gfe_launch_status();
+}
+
+/* Area (adaptive-average) resize of B single-channel volumes (B, D, H, W) -> (B, d, h, w), f32. */
+int gfe_resize_area(const float* x, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t d, int64_t h, int64_t w, void* stream) {
+    GFE_REQUIRE(x && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0 && D * H * W < (1LL << 31) && d * h * w < (1LL << 31), GFE_ERR_SHAPE);
+    int64_t g = ceil_div(d * h * w, 256); if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(resize_area_kernel, dim3((unsigned)g, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, y, (int)D, (int)H, (int)W, (int)d, (int)h, (int)w);
     return gfe_launch_status();
 }
 

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 23
+#define GFE_ABI_VERSION 24
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -397,6 +397,11 @@ int gfe_conv3d_k3_out1(const void* x, const void* w_packed, int64_t w_batch_stri
  * without a voxel >= 0 (the reference raises IndexError) leaves m = 0 and an unspecified y: callers check ws[0]. */
 int gfe_adaptive_normal_ws_words(void);
 int gfe_adaptive_normal(const float* x, float* y, uint32_t* ws, int64_t B, int64_t n, void* stream);
+
+/* The loader's Resized(keys=['image'], spatial_size=desired_shape) (dataloader/pic_table_loader.py:58; monai's default mode "area" =
+ * torch F.interpolate(mode="area") = adaptive average pooling): B single-channel f32 volumes (B, D, H, W) -> (B, d, h, w);
+ * out[i] = mean of in[floor(i D / d) .. ceil((i + 1) D / d)) along every axis. */
+int gfe_resize_area(const float* x, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t d, int64_t h, int64_t w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,3 +59,30 @@ def test_adaptive_normal_empty_selection_raises_like_the_reference():
         adaptive_normal(torch.full((4, 4, 4), -1.0).cuda())
     with pytest.raises(TypeError):
         adaptive_normal(torch.zeros(4, 4, 4))                         # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("shape,size", [((2, 40, 48, 36), (32, 32, 24)), ((1, 256, 256, 166), (160, 160, 96)), ((3, 7, 5, 9), (7, 5, 9)),
+                                         ((1, 10, 10, 10), (13, 4, 20)), ((2, 1, 1, 1), (3, 2, 1))])
+def test_resize_area_matches_torch_area_interpolation(shape, size):
+    """The loader's Resized(spatial_size) (pic_table_loader.py:58; monai's default mode "area" IS F.interpolate(mode="area")): down-,
+    up- and mixed resizing, identity, native size 256x256x166 -> 160x160x96.  monai is not in the image: parity is pinned to the torch
+    operator monai's Resize calls, on the host."""
+    from utils.data_normalization import resize_area
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 100 + 30
+    ref = torch.nn.functional.interpolate(x.unsqueeze(0).double(), size=size, mode="area")[0]
+    got = resize_area(x.cuda(), size)
+    assert tuple(got.shape) == shape[:1] + tuple(size)
+    assert (got.double().cpu() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    if tuple(shape[1:]) == tuple(size):
+        assert torch.equal(got.cpu(), x)                        # boxes of one voxel: a copy
+
+
+def test_load_transform_is_normalise_then_resize():
+    from utils.data_normalization import adaptive_normal, load_transform, resize_area
+    g = torch.Generator().manual_seed(9)
+    v = (torch.randn(64, 72, 40, generator=g).abs() * 300).cuda()
+    out = load_transform(v, (32, 32, 24))
+    assert tuple(out.shape) == (1, 32, 32, 24)
+    assert torch.equal(out, resize_area(adaptive_normal(v).unsqueeze(0), (32, 32, 24)))
+    assert out.min() >= -1 and out.max() <= 1

@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -368,6 +368,38 @@ def t4(R, out):
     np.savez_compressed(os.path.join(out, "t4_adaptive_normal.npz"), **fx)
 
 
+def t5(R, out):
+    """table/deal_table.py:28-61 `prepare_table` on a synthetic TADPOLE-like frame: bookkeeping and baseline columns to drop, string
+    categoricals (with missing values and a numeric-looking string column that contains letters), numeric columns with missing and
+    unparsable entries, a constant column.  The input travels as a CSV data file, the reference's outputs as arrays."""
+    import importlib
+    import pandas as pd
+    dt = importlib.import_module("table.deal_table")
+    g = np.random.default_rng(5)
+    n = 40
+    df = pd.DataFrame({
+        "RID": np.arange(n), "PTID": [f"0{i % 7:02d}_S_{1000 + i % 7}" for i in range(n)],
+        "EXAMDATE": [f"20{10 + i % 5}-0{1 + i % 9}-1{i % 9}" for i in range(n)], "LABEL": g.integers(0, 2, n).astype(float),
+        "D2": 0, "SITE": g.integers(1, 60, n), "DX": g.choice(["CN", "MCI", "Dementia"], n), "COLPROT": "ADNI2", "ORIGPROT": "ADNI1",
+        "Month": g.integers(0, 60, n), "M": g.integers(0, 60, n), "FDG": g.normal(1.2, 0.1, n), "PIB": np.nan, "AV45": g.normal(1.1, 0.2, n),
+        "AGE": g.normal(72, 6, n).round(1), "PTGENDER": g.choice(["Male", "Female"], n), "PTEDUCAT": g.integers(8, 21, n),
+        "PTETHCAT": g.choice(["Not Hisp/Latino", "Hisp/Latino", "Unknown"], n), "PTMARRY": g.choice(["Married", "Widowed", "Divorced", None], n),
+        "APOE4": g.choice([0.0, 1.0, 2.0, np.nan], n), "ABETA": g.choice([">1700", "912.3", "1200", None], n),
+        "TAU": g.choice(["210.5", "<80", "300", "155.1"], n), "MMSE": g.integers(18, 31, n).astype(float), "CDRSB": g.choice([0.0, 0.5, 1.0, 2.5], n),
+        "Hippocampus": g.normal(7000, 900, n).round(0), "ICV": 1.5e6, "AGE_bl": 70.0, "MMSE_bl": 28.0, "Years_bl": g.random(n),
+    })
+    df.loc[3, "MMSE"] = np.nan
+    df.loc[5, "Hippocampus"] = np.nan
+    csv = os.path.join(out, "t5_table_input.csv")
+    df.to_csv(csv, index=False)
+    ref = dt.prepare_table(pd.read_csv(csv))                   # (the reference reads the table from a CSV too: pic_table_loader.py:64)
+    fx = dict(cate_x=ref["cate_x"].to_numpy(dtype=np.int64), conti_x=ref["conti_x"].to_numpy(dtype=np.float64),
+              num_cat=np.asarray(ref["num_cat"], dtype=np.int64), num_cont=np.asarray(ref["num_cont"]),
+              cate_cols=np.asarray(list(ref["cate_x"].columns)), conti_cols=np.asarray(list(ref["conti_x"].columns)),
+              info_cols=np.asarray(list(ref["info"].columns)))
+    np.savez_compressed(os.path.join(out, "t5_table.npz"), **fx)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -376,7 +408,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
