@@ -1,0 +1,208 @@
+"""Jamba backbone (Mamba + attention + sparse mixture-of-experts MLPs) -- MI355X build of the reference's cross_atten/jamba.py
+(JambaLMConfig :37-95, Jamba :258-306, AttentionLayer :308-340, AttentionSDPA :342-398, MambaLayer :400-439, SparseMoEBlock :441-517,
+MLP :519-535, load_balancing_loss :537-556), the backbone of Cross_jamba_both (cross_atten/mamba_transformer.py:135-251).
+Same class names, constructor arguments and state-dict keys.
+
+Every projection runs on the exact-f32 MFMA GEMM (gfe_hip.train_ops.Linear), the Mamba mixers on the fused selective-scan kernels
+(with the inner RMSNorms of Jamba, mamba.py:171-178), the causal attention on gfe_sdpa_small (37 tokens x 8 heads x 64), RMSNorm on
+gfe_rmsnorm.  The expert routing itself (softmax, top-2, gather / scatter-add of the selected tokens) stays on torch's indexing ops --
+it is bookkeeping on (B*37) x 16 numbers, written exactly as the reference writes it so that ties and orders agree.
+Not built: the language-model wrapper JambaLM / from_pretrained (never used by the GFE-Mamba scripts) and the KV-cache decode path."""
+import math
+from dataclasses import dataclass
+from typing import Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from cross_atten.mamba import MambaBlock, MambaConfig, RMSNorm
+from gfe_hip.head_ops import sdpa_small
+from gfe_hip.train_ops import Linear
+
+
+@dataclass
+class JambaLMConfig:
+    d_model: int
+    n_layers: int
+    mlp_size: int
+    initializer_range: float = 0.02
+    rms_norm_eps: float = 1e-5
+    # mamba related
+    d_state: int = 16
+    expand_factor: int = 2
+    d_conv: int = 4
+    dt_rank: Union[int, str] = 'auto'
+    dt_min: float = 0.001
+    dt_max: float = 0.1
+    dt_init: str = "random"
+    dt_scale: float = 1.0
+    dt_init_floor = 1e-4
+    bias: bool = False
+    conv_bias: bool = True
+    inner_layernorms: bool = True
+    use_cuda: bool = False
+    pscan: bool = True
+    # attention related
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    attention_dropout: float = 0.
+    # MoE related
+    num_experts: int = 16
+    num_experts_per_tok: int = 2
+    # structure
+    attn_layer_offset: int = 4
+    attn_layer_period: int = 8
+    expert_layer_offset: int = 1
+    expert_layer_period: int = 2
+    # language modeling
+    vocab_size: int = 65536
+    pad_token_id: int = 0
+    tie_lm_weights: bool = True
+
+    def __post_init__(self):
+        self.d_inner = self.expand_factor * self.d_model
+        if self.dt_rank == 'auto':
+            self.dt_rank = math.ceil(self.d_model / 16)
+        self.mamba_config = MambaConfig(d_model=self.d_model, n_layers=0, dt_rank=self.dt_rank, d_state=self.d_state,
+                                        expand_factor=self.expand_factor, d_conv=self.d_conv, dt_min=self.dt_min, dt_max=self.dt_max,
+                                        dt_init=self.dt_init, dt_scale=self.dt_scale, rms_norm_eps=self.rms_norm_eps,
+                                        bias=self.bias, conv_bias=self.conv_bias, inner_layernorms=self.inner_layernorms,
+                                        pscan=self.pscan, use_cuda=self.use_cuda)
+
+
+class Jamba(nn.Module):
+    def __init__(self, config: JambaLMConfig):
+        super().__init__()
+        self.config = config
+        layers = []
+        for i in range(config.n_layers):                                        # jamba.py:266-276
+            is_attn = (i - config.attn_layer_offset) % config.attn_layer_period == 0
+            is_expert = (i - config.expert_layer_offset) % config.expert_layer_period == 0
+            num_experts = config.num_experts if is_expert else 1
+            layers.append((AttentionLayer if is_attn else MambaLayer)(config, num_experts=num_experts))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x):
+        """x: (B, L, D) -> (x, [router logits of every layer])   (jamba.py:282-296)."""
+        router_logits = []
+        for layer in self.layers:
+            (x, rl), _ = layer(x)
+            router_logits.append(rl)
+        return x, router_logits
+
+
+class AttentionLayer(nn.Module):
+    def __init__(self, config: JambaLMConfig, num_experts: int):
+        super().__init__()
+        self.self_attn = AttentionSDPA(config)
+        num_experts_per_tok = config.num_experts_per_tok if num_experts > 1 else 1
+        self.moe = SparseMoEBlock(config, num_experts=num_experts, num_experts_per_tok=num_experts_per_tok)
+        self.input_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
+        self.pre_moe_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
+
+    def forward(self, x, cache=None):
+        assert cache is None, "KV-cache decoding is not part of the classification path"
+        x = x + self.self_attn(self.input_layernorm(x))[0]                       # jamba.py:325-329
+        h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # :332-335
+        return (x + h, router_logits), None
+
+
+class AttentionSDPA(nn.Module):
+    def __init__(self, config: JambaLMConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.d_model
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.attention_dropout = config.attention_dropout
+        self.q_proj = Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.k_proj = Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=False)
+        self.v_proj = Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=False)
+        self.o_proj = Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+
+    def forward(self, x, cache=None):
+        assert cache is None, "KV-cache decoding is not part of the classification path"
+        if self.training and self.attention_dropout > 0:
+            raise NotImplementedError("attention dropout (Cross_jamba_both passes attn_dropout = 0)")
+        B, L, _ = x.shape
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        if self.num_key_value_groups > 1:                                        # GQA: repeat_kv (jamba.py:558-567) on the projection layout
+            rep = lambda t: t.view(B, L, self.num_key_value_heads, 1, self.head_dim).expand(-1, -1, -1, self.num_key_value_groups, -1).reshape(B, L, -1)
+            k, v = rep(k), rep(v)
+        o = sdpa_small(q, k, v, self.num_heads, causal=True)                     # F.scaled_dot_product_attention(..., is_causal=True) (:390-392)
+        return self.o_proj(o), None
+
+
+class MambaLayer(nn.Module):
+    def __init__(self, config: JambaLMConfig, num_experts: int):
+        super().__init__()
+        self.config = config
+        self.mamba = MambaBlock(config=config.mamba_config)
+        num_experts_per_tok = config.num_experts_per_tok if num_experts > 1 else 1
+        self.moe = SparseMoEBlock(config, num_experts=num_experts, num_experts_per_tok=num_experts_per_tok)
+        self.input_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
+        self.pre_moe_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
+
+    def forward(self, x, cache=None):
+        assert cache is None, "single-token decoding is not part of the classification path"
+        x = x + self.mamba(self.input_layernorm(x))                              # jamba.py:418-425
+        h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # :428-431
+        return (x + h, router_logits), None
+
+
+class SparseMoEBlock(nn.Module):
+    def __init__(self, config: JambaLMConfig, num_experts: int, num_experts_per_tok: int):
+        super().__init__()
+        self.hidden_dim = config.d_model
+        self.ffn_dim = config.mlp_size
+        self.num_experts = num_experts
+        self.top_k = num_experts_per_tok
+        self.router = Linear(self.hidden_dim, self.num_experts, bias=False) if num_experts > 1 else None
+        self.experts = nn.ModuleList([MLP(config) for _ in range(self.num_experts)])
+
+    def forward(self, x):
+        B, L, D = x.shape
+        if self.num_experts == 1:                                                # no routing (jamba.py:470-478)
+            return self.experts[0](x), torch.ones((B * L, 1), device=x.device, dtype=x.dtype, requires_grad=x.requires_grad)
+        x = x.reshape(-1, D)
+        router_logits = self.router(x)                                           # (B*L, n_experts)
+        routing_weights = F.softmax(router_logits, dim=1, dtype=torch.float)
+        routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
+        routing_weights = routing_weights.to(x.dtype)
+        out = torch.zeros((B * L, D), dtype=x.dtype, device=x.device)
+        expert_mask = F.one_hot(selected_experts, num_classes=self.num_experts).permute(2, 1, 0)      # :493
+        hit = expert_mask.sum((1, 2)).tolist()                                   # one host read for all experts (the reference reads per expert)
+        for e in range(self.num_experts):
+            if hit[e] == 0:
+                continue
+            idx, top_x = torch.where(expert_mask[e])
+            cur = self.experts[e](x[top_x]) * routing_weights[top_x, idx, None]  # :508-509
+            out.index_add_(0, top_x, cur.to(x.dtype))                            # :513
+        return out.reshape(B, L, D), router_logits
+
+
+class MLP(nn.Module):
+    def __init__(self, config: JambaLMConfig):
+        super().__init__()
+        self.hidden_dim = config.d_model
+        self.ffn_dim = config.mlp_size
+        self.gate_proj = Linear(self.hidden_dim, self.ffn_dim, bias=False)
+        self.down_proj = Linear(self.ffn_dim, self.hidden_dim, bias=False)
+        self.up_proj = Linear(self.hidden_dim, self.ffn_dim, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))      # jamba.py:535
+
+
+def load_balancing_loss(router_logits, num_experts, num_experts_per_tok):
+    """jamba.py:537-556 (not used by the classification scripts; kept for API completeness)."""
+    router_logits = torch.cat([r for r in router_logits if r.shape[1] > 1], dim=0)
+    routing_weights = F.softmax(router_logits, dim=-1)
+    _, selected_experts = torch.topk(routing_weights, num_experts_per_tok, dim=-1)
+    expert_mask = F.one_hot(selected_experts, num_experts)
+    tokens_per_expert = torch.mean(expert_mask.float(), dim=0)
+    router_prob_per_expert = torch.mean(routing_weights, dim=0)
+    return torch.sum(tokens_per_expert * router_prob_per_expert.unsqueeze(0)) * num_experts

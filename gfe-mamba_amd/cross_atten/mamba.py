@@ -80,7 +80,6 @@ class MambaBlock(nn.Module):
     def __init__(self, config: MambaConfig):
         super().__init__()
         self.config = config
-        assert not config.inner_layernorms, "inner_layernorms (Jamba) is outside the classify_mamba hot path"
         self.in_proj = Linear(config.d_model, 2 * config.d_inner, bias=config.bias)
         self.conv1d = nn.Conv1d(in_channels=config.d_inner, out_channels=config.d_inner, kernel_size=config.d_conv,
                                 bias=config.conv_bias, groups=config.d_inner, padding=config.d_conv - 1)
@@ -104,7 +103,12 @@ class MambaBlock(nn.Module):
         self.D = nn.Parameter(torch.ones(config.d_inner))        # mamba.py:164-165
         self.D._no_weight_decay = True
         self.out_proj = Linear(config.d_inner, config.d_model, bias=config.bias)
-        self.dt_layernorm = self.B_layernorm = self.C_layernorm = None
+        if config.inner_layernorms:                              # used in Jamba (mamba.py:171-178)
+            self.dt_layernorm = RMSNorm(config.dt_rank, config.rms_norm_eps)
+            self.B_layernorm = RMSNorm(config.d_state, config.rms_norm_eps)
+            self.C_layernorm = RMSNorm(config.d_state, config.rms_norm_eps)
+        else:
+            self.dt_layernorm = self.B_layernorm = self.C_layernorm = None
         # the reference's plug-in slot (mamba.py:180-186); here it is always populated, never a silent fallback
         self.selective_scan_cuda = selective_scan_fn
 
@@ -136,8 +140,19 @@ class MambaBlock(nn.Module):
         A = -torch.exp(self.A_log.float())
         deltaBC = self.x_proj(x)
         delta, B, C = torch.split(deltaBC, [cfg.dt_rank, cfg.d_state, cfg.d_state], dim=-1)
+        delta, B, C = self._apply_layernorms(delta, B, C)       # mamba.py:237 (identity unless inner_layernorms)
         delta = _dt_linear(delta, self.dt_proj)
         return selective_scan_tm(x, delta, A, B, C, self.D.float(), z=z, delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+
+    def _apply_layernorms(self, dt, B, C):
+        """mamba.py:188-195: RMSNorm over the dt_rank / d_state axes of the x_proj outputs (Jamba's inner_layernorms)."""
+        if self.dt_layernorm is not None:
+            dt = self.dt_layernorm(dt)
+        if self.B_layernorm is not None:
+            B = self.B_layernorm(B)
+        if self.C_layernorm is not None:
+            C = self.C_layernorm(C)
+        return dt, B, C
 
     def selective_scan(self, x, delta, A, B, C, D):
         """The reference's parallel-scan form (mamba.py:265-286): y = (pscan(exp(delta (x) A), delta B x) @ C) + D x with delta already
@@ -167,6 +182,7 @@ class MambaBlock(nn.Module):
         D = self.D.float()
         deltaBC = F.linear(x, self.x_proj.weight)
         delta, B, C = torch.split(deltaBC, [self.config.dt_rank, self.config.d_state, self.config.d_state], dim=-1)
+        delta, B, C = self._apply_layernorms(delta, B, C)
         delta = F.softplus(F.linear(delta, self.dt_proj.weight, self.dt_proj.bias))
         deltaA = torch.exp(delta.unsqueeze(-1) * A)
         BX = delta.unsqueeze(-1) * B.unsqueeze(1) * x.unsqueeze(-1)

@@ -1,12 +1,13 @@
 """Cross_mamba_both -- MI355X build of the classifier used by classify_mamba.py (reference:
 cross_atten/mamba_transformer.py:11-133) -- and its ablation twin Cross_mamba_ablation (:254-385).  Same keyword-only
 constructors, forward contracts and state-dict keys.  Additive: `d_cross` (default 160*160, the reference's hard-coded value at
-:84 / :325) so that 96^3 / 128^3 volumes are constructible.  Cross_jamba_both is next-round scope."""
+:84 / :325) so that 96^3 / 128^3 volumes are constructible.  Cross_jamba_both (:135-251) swaps the Mamba stack for the Jamba backbone."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from cross_atten.corss_ft_transformer import FeedForward, GEGLU, NumericalEmbedder  # noqa: F401
+from cross_atten.jamba import Jamba, JambaLMConfig
 from cross_atten.mamba import Mamba, MambaConfig
 from cross_atten.sd_cross_atten import CrossAttention
 from gfe_hip.head_ops import LayerNorm, embed_tokens, mean_tokens
@@ -77,3 +78,30 @@ class Cross_mamba_ablation(Cross_mamba_both):
             x = self.final_cross(x, cond) + x                                                     # :374
             x = self.final_feed(x) + x                                                            # :375
         return self.to_logits(x.squeeze(1))                                                       # :377-381
+
+
+class Cross_jamba_both(Cross_mamba_both):
+    """Reference: cross_atten/mamba_transformer.py:135-251 -- Cross_mamba_both with the Jamba backbone (2*depth layers: Mamba mixers with
+    inner RMSNorms, one causal-attention layer at index 4, 16-expert top-2 MoE MLPs on the odd layers) instead of the Mamba stack; same
+    embedding, cross-attention, feed-forward and logit modules and state-dict keys."""
+
+    def __init__(self, *, categories, num_continuous, dim, depth, heads, dim_head=16, dim_out=1, num_special_tokens=2,
+                 attn_dropout=0., ff_dropout=0., cross_ff_multi=2, cross_ff_dropout=0.1, d_cross=160 * 160):
+        super().__init__(categories=categories, num_continuous=num_continuous, dim=dim, depth=1, heads=heads, dim_head=dim_head,
+                         dim_out=dim_out, num_special_tokens=num_special_tokens, attn_dropout=attn_dropout, ff_dropout=ff_dropout,
+                         cross_ff_multi=cross_ff_multi, cross_ff_dropout=cross_ff_dropout, d_cross=d_cross)
+        config = JambaLMConfig(d_model=dim, n_layers=depth * 2, use_cuda=True, mlp_size=dim * 2, attention_dropout=attn_dropout,
+                               num_attention_heads=heads)                                     # :189-191
+        self.transformer = Jamba(config)
+
+    def forward(self, x_categ, x_numer, feature_img, image_condition=None):
+        assert x_categ.shape[-1] == self.num_categories, f'you must pass in {self.num_categories} values for your categories input'
+        if image_condition is None:
+            raise ValueError("Cross_jamba_both needs image_condition=[mri, pet] (the reference fails with NameError at :242)")
+        whole_condition = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))   # :205-210
+        x = self._tokens(x_categ, x_numer, feature_img)                                           # :212-235
+        x = self.transformer(x)                                                                   # :239
+        x = mean_tokens(x[0])                                                                     # :240
+        x = self.final_cross(x, whole_condition) + x                                              # :242
+        x = self.final_feed(x) + x                                                                # :243
+        return self.to_logits(x.squeeze(1))                                                       # :245-251

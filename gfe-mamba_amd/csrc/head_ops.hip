@@ -172,6 +172,87 @@ __global__ __launch_bounds__(256) void cross_attn_q1_bwd_kernel(const float* __r
     }
 }
 
+
+// ---- small self-attention (Jamba's AttentionSDPA, cross_atten/jamba.py:342-398: F.scaled_dot_product_attention, is_causal) ---------
+// block = (head, sample); q, k, v rows of one head staged in LDS (L <= 64, dh <= 64); probs (B, H, L, L) kept for the backward.
+__global__ __launch_bounds__(256) void sdpa_small_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             float* __restrict__ out, float* __restrict__ probs, int H, int L, int dh, float scale, int causal) {
+    extern __shared__ float sm[];
+    float* sq = sm; float* sk = sq + L * dh; float* sv = sk + L * dh; float* sp = sv + L * dh;      // sp: [L][L]
+    const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
+    for (int i = threadIdx.x; i < L * dh; i += 256) {
+        const int t = i / dh, d = i - t * dh;
+        const size_t o = ((size_t)b * L + t) * dim + h * dh + d;
+        sq[i] = q[o]; sk[i] = k[o]; sv[i] = v[o];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * L; i += 256) {
+        const int r = i / L, c = i - r * L;
+        float s = -INFINITY;
+        if (!causal || c <= r) {
+            s = 0.f;
+            for (int d = 0; d < dh; ++d) s = fmaf(sq[r * dh + d], sk[c * dh + d], s);
+            s *= scale;
+        }
+        sp[i] = s;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < L; r += 256) {                    // one row per thread (L <= 64)
+        float mx = -INFINITY;
+        for (int c = 0; c < L; ++c) mx = fmaxf(mx, sp[r * L + c]);
+        float sum = 0.f;
+        for (int c = 0; c < L; ++c) { const float e = __expf(sp[r * L + c] - mx); sp[r * L + c] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int c = 0; c < L; ++c) { const float pv = sp[r * L + c] * inv; sp[r * L + c] = pv; probs[(((size_t)b * H + h) * L + r) * L + c] = pv; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * dh; i += 256) {
+        const int r = i / dh, d = i - r * dh;
+        float o = 0.f;
+        for (int c = 0; c < L; ++c) o = fmaf(sp[r * L + c], sv[c * dh + d], o);
+        out[((size_t)b * L + r) * dim + h * dh + d] = o;
+    }
+}
+__global__ __launch_bounds__(256) void sdpa_small_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             const float* __restrict__ probs, const float* __restrict__ dout,
+                                                             float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                             int H, int L, int dh, float scale) {
+    extern __shared__ float sm[];
+    float* sq = sm; float* sk = sq + L * dh; float* sv = sk + L * dh; float* so = sv + L * dh; float* sp = so + L * dh; float* sd = sp + L * L;
+    const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
+    for (int i = threadIdx.x; i < L * dh; i += 256) {
+        const int t = i / dh, d = i - t * dh;
+        const size_t o = ((size_t)b * L + t) * dim + h * dh + d;
+        sq[i] = q[o]; sk[i] = k[o]; sv[i] = v[o]; so[i] = dout[o];
+    }
+    for (int i = threadIdx.x; i < L * L; i += 256) sp[i] = probs[((size_t)b * H + h) * L * L + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * L; i += 256) {                 // dP = dO V^T
+        const int r = i / L, c = i - r * L;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(so[r * dh + d], sv[c * dh + d], s);
+        sd[i] = s;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < L; r += 256) {                     // dS = P (dP - sum_c P dP) * scale
+        float acc = 0.f;
+        for (int c = 0; c < L; ++c) acc = fmaf(sp[r * L + c], sd[r * L + c], acc);
+        for (int c = 0; c < L; ++c) sd[r * L + c] = sp[r * L + c] * (sd[r * L + c] - acc) * scale;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * dh; i += 256) {
+        const int t = i / dh, d = i - t * dh;
+        float gq = 0.f, gk = 0.f, gv = 0.f;
+        for (int c = 0; c < L; ++c) {
+            gq = fmaf(sd[t * L + c], sk[c * dh + d], gq);            // dQ_t = sum_c dS[t][c] K_c
+            gk = fmaf(sd[c * L + t], sq[c * dh + d], gk);            // dK_t = sum_r dS[r][t] Q_r
+            gv = fmaf(sp[c * L + t], so[c * dh + d], gv);            // dV_t = sum_r P[r][t] dO_r
+        }
+        const size_t o = ((size_t)b * L + t) * dim + h * dh + d;
+        dq[o] = gq; dk[o] = gk; dv[o] = gv;
+    }
+}
+
 // ---- LayerNorm over (rows, dim): one block per row ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int dim, float eps) {
@@ -323,6 +404,25 @@ int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const 
     GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && nk > 0 && nk <= 8192 && dh > 0, GFE_ERR_SHAPE);
     hipLaunchKernelGGL(cross_attn_q1_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 32) * sizeof(float), (hipStream_t)stream,
                        q, k, v, probs, dout, dq, dk, dv, (int)H, (int)nk, (int)dh, scale);
+    return gfe_launch_status();
+}
+
+int gfe_sdpa_small_fwd(const float* q, const float* k, const float* v, float* out, float* probs,
+                       int64_t B, int64_t H, int64_t L, int64_t dh, float scale, int causal, void* stream) {
+    GFE_REQUIRE(q && k && v && out && probs, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && L > 0 && L <= 64 && dh > 0 && dh <= 64, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(sdpa_small_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(3 * L * dh + L * L) * sizeof(float), (hipStream_t)stream,
+                       q, k, v, out, probs, (int)H, (int)L, (int)dh, scale, causal);
+    return gfe_launch_status();
+}
+int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                       float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, void* stream) {
+    GFE_REQUIRE(q && k && v && probs && dout && dq && dk && dv, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && L > 0 && L <= 64 && dh > 0 && dh <= 64, GFE_ERR_SHAPE);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)sdpa_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304); attr = true; }
+    hipLaunchKernelGGL(sdpa_small_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(4 * L * dh + 2 * L * L) * sizeof(float), (hipStream_t)stream,
+                       q, k, v, probs, dout, dq, dk, dv, (int)H, (int)L, (int)dh, scale);
     return gfe_launch_status();
 }
 

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 24
+#define GFE_ABI_VERSION 25
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -311,6 +311,13 @@ int gfe_cross_attn_q1_fwd(const float* q, const float* k, const float* v, float*
                           int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
 int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                           float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
+
+/* Small multi-head self-attention for Jamba's AttentionSDPA (cross_atten/jamba.py:342-398: F.scaled_dot_product_attention, is_causal
+ * when no cache is passed): q, k, v, out (B, L, H*dh) f32, L <= 64, dh <= 64; probs (B, H, L, L) kept for the backward. */
+int gfe_sdpa_small_fwd(const float* q, const float* k, const float* v, float* out, float* probs,
+                       int64_t B, int64_t H, int64_t L, int64_t dh, float scale, int causal, void* stream);
+int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                       float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, void* stream);
 
 /* nn.LayerNorm(dim) over (rows, dim) f32 (mamba_transformer.py:79-82, corss_ft_transformer.py:16); mean / rstd (rows) kept for the
  * backward, which ACCUMULATES dgamma / dbeta (f32 atomics) and writes dx. */

@@ -105,6 +105,10 @@ def mamba_block(x, sd, pre, d_state=16, d_conv=4):
     D = sd[pre + "D"].float()                                        # :233
     dbc = xc @ sd[pre + "x_proj.weight"].t()                         # :235
     delta, B, C = torch.split(dbc, [dt_rank, d_state, d_state], dim=-1)   # :236
+    if (pre + "dt_layernorm.weight") in sd:                          # Jamba's inner_layernorms (:171-178, 188-195, 237)
+        delta = rmsnorm(delta, sd[pre + "dt_layernorm.weight"])
+        B = rmsnorm(B, sd[pre + "B_layernorm.weight"])
+        C = rmsnorm(C, sd[pre + "C_layernorm.weight"])
     delta = (sd[pre + "dt_proj.weight"] @ delta.transpose(1, 2)).transpose(1, 2)   # :238, :255
     delta = F.softplus(delta + sd[pre + "dt_proj.bias"])             # :256
     y = selective_scan(xc, delta, A, B, C, D)                        # :259
@@ -116,6 +120,61 @@ def mamba(x, sd, pre, n_layers):
     for l in range(n_layers):
         p = f"{pre}layers.{l}."
         x = mamba_block(rmsnorm(x, sd[p + "norm.weight"]), sd, p + "mixer.") + x
+    return x
+
+
+def jamba_mlp(x, sd, pre):
+    """MLP (cross_atten/jamba.py:519-535): down(silu(gate(x)) * up(x)), no biases."""
+    return (F.silu(x @ sd[pre + "gate_proj.weight"].t()) * (x @ sd[pre + "up_proj.weight"].t())) @ sd[pre + "down_proj.weight"].t()
+
+
+def jamba_moe(x, sd, pre, top_k=2):
+    """SparseMoEBlock.forward (cross_atten/jamba.py:459-517): one expert when there is no router; otherwise softmax over the router
+    logits, top-k (NOT renormalised), every selected expert's output times its routing weight, summed per token."""
+    B, L, D = x.shape
+    if (pre + "router.weight") not in sd:
+        return jamba_mlp(x, sd, pre + "experts.0.")                   # :470-478
+    xf = x.reshape(-1, D)
+    w = F.softmax(xf @ sd[pre + "router.weight"].t(), dim=1)         # :483-485
+    w, sel = torch.topk(w, top_k, dim=-1)                            # :486
+    out = torch.zeros_like(xf)
+    n_exp = sd[pre + "router.weight"].shape[0]
+    for e in range(n_exp):                                           # :496-513 (per expert: gather, MLP, scale, index_add)
+        for j in range(top_k):
+            m = sel[:, j] == e
+            if m.any():
+                out[m] = out[m] + jamba_mlp(xf[m], sd, f"{pre}experts.{e}.") * w[m, j, None]
+    return out.reshape(B, L, D)
+
+
+def jamba_attention(x, sd, pre, n_heads, n_kv_heads):
+    """AttentionSDPA.forward without a cache (cross_atten/jamba.py:362-398): q/k/v projections (no bias), GQA repeat, causal
+    scaled-dot-product attention, output projection."""
+    B, L, D = x.shape
+    dh = D // n_heads
+    q = (x @ sd[pre + "q_proj.weight"].t()).view(B, L, n_heads, dh).transpose(1, 2)
+    k = (x @ sd[pre + "k_proj.weight"].t()).view(B, L, n_kv_heads, dh).transpose(1, 2)
+    v = (x @ sd[pre + "v_proj.weight"].t()).view(B, L, n_kv_heads, dh).transpose(1, 2)
+    rep = n_heads // n_kv_heads
+    if rep > 1:                                                      # repeat_kv (:558-567)
+        k, v = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    s = s.masked_fill(torch.ones(L, L, dtype=torch.bool).triu(1), float("-inf"))      # is_causal=True (:390-392)
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, D)
+    return o @ sd[pre + "o_proj.weight"].t()
+
+
+def jamba(x, sd, pre, n_layers, n_heads, n_kv_heads=8, attn_offset=4, attn_period=8):
+    """Jamba.forward (cross_atten/jamba.py:258-296) with AttentionLayer / MambaLayer (:308-340, 400-439): pre-norm residual mixer, then
+    pre-norm residual MoE; attention at layers (i - 4) % 8 == 0, Mamba (with inner layernorms) elsewhere."""
+    for i in range(n_layers):
+        p = f"{pre}layers.{i}."
+        h = rmsnorm(x, sd[p + "input_layernorm.weight"])
+        if (i - attn_offset) % attn_period == 0:
+            x = x + jamba_attention(h, sd, p + "self_attn.", n_heads, n_kv_heads)
+        else:
+            x = x + mamba_block(h, sd, p + "mamba.")
+        x = x + jamba_moe(rmsnorm(x, sd[p + "pre_moe_layernorm.weight"]), sd, p + "moe.")
     return x
 
 
@@ -183,6 +242,26 @@ def cross_mamba_both(x_categ, x_numer, feature_img, image_condition, sd, depth, 
     x = x.squeeze(1)                                                 # :127
     x = F.layer_norm(x, x.shape[-1:], sd[pre + "to_logits.0.weight"], sd[pre + "to_logits.0.bias"])
     return x @ sd[pre + "to_logits.1.weight"].t() + sd[pre + "to_logits.1.bias"]   # :131
+
+
+def cross_jamba_both(x_categ, x_numer, feature_img, image_condition, sd, depth, heads, pre="", drop_mask=None):
+    """Cross_jamba_both.forward (cross_atten/mamba_transformer.py:203-251): Cross_mamba_both with the Jamba backbone (2*depth layers)."""
+    cond = build_condition(image_condition)                          # :205-210
+    xs = []
+    if (pre + "categorical_embeds.weight") in sd:
+        xs.append(sd[pre + "categorical_embeds.weight"][x_categ + sd[pre + "categories_offset"]])      # :214-218
+    if (pre + "numerical_embedder.weights") in sd:
+        xs.append(x_numer.unsqueeze(-1) * sd[pre + "numerical_embedder.weights"] + sd[pre + "numerical_embedder.biases"])
+    x = torch.cat(xs, dim=1)
+    cls = sd[pre + "cls_token"].expand(x.shape[0], -1, -1)
+    x = torch.cat((cls, x, feature_img), dim=1)                      # :235
+    x = jamba(x, sd, pre + "transformer.", 2 * depth, heads)         # :239 (num_key_value_heads keeps its default 8)
+    x = x.mean(dim=1, keepdim=True)                                  # :240
+    x = cross_attention(x, cond, sd, pre + "final_cross.", heads) + x   # :242
+    x = geglu_ff(x, sd, pre + "final_feed.", drop_mask) + x          # :243
+    x = x.squeeze(1)
+    x = F.layer_norm(x, x.shape[-1:], sd[pre + "to_logits.0.weight"], sd[pre + "to_logits.0.bias"])
+    return x @ sd[pre + "to_logits.1.weight"].t() + sd[pre + "to_logits.1.bias"]   # :249
 
 
 def cross_mamba_ablation(x_categ, x_numer, feature_img, image_condition, sd, depth, heads, pre="", no_table=False, drop_mask=None):

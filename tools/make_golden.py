@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -368,6 +368,30 @@ def t4(R, out):
     np.savez_compressed(os.path.join(out, "t4_adaptive_normal.npz"), **fx)
 
 
+def t6(R, out):
+    """Cross_jamba_both (cross_atten/mamba_transformer.py:135-251) on the Jamba backbone (jamba.py:258-535): depth 3 -> 6 layers (attention
+    at layer 4, 16-expert top-2 MoE on layers 1, 3, 5, Mamba mixers with inner layernorms elsewhere): logits, loss, per-parameter
+    gradient norms and slices.  Weights are committed (257 small tensors): the router's top-2 choice must be reproduced exactly."""
+    cards, n_cont, dim, depth, heads, vol, Bn = (5, 3, 2), 6, 64, 3, 8, (8, 12, 6), 3
+    ft = R.mt.Cross_jamba_both(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads)
+    ft.final_cross = R.xattn.CrossAttention(n_heads=heads, d_embed=dim, d_cross=vol[0] * vol[1])      # :200 hard-codes 160*160
+    load_det(ft, 41, "jam.")
+    ft.eval()
+    x, x_cat, x_num, y = det.det_inputs(Bn, vol, cards, n_cont, seed=41)
+    pet = rnd_det("jam.pet", (Bn, 1) + vol)
+    feat = rnd_det("jam.feat", (Bn, 4, dim))
+    pred = ft(x_cat, x_num, feat, [x, pet])
+    loss = torch.nn.BCELoss()(torch.sigmoid(pred.squeeze(1)), y.float())
+    loss.backward()
+    fx = dict(meta=np.array(list(cards) + [n_cont, dim, depth, heads] + list(vol) + [Bn]), pet=npy(pet), feat=npy(feat),
+              pred=npy(pred.double()), loss=npy(loss.double()))
+    for k, p in ft.named_parameters():
+        fx["gnorm." + k] = npy(p.grad.double().norm()) if p.grad is not None else np.array(-1.0)
+        if p.grad is not None:
+            fx["gslice." + k] = slices(p.grad, 64)
+    np.savez_compressed(os.path.join(out, "t6_jamba.npz"), **fx)
+
+
 def t5(R, out):
     """table/deal_table.py:28-61 `prepare_table` on a synthetic TADPOLE-like frame: bookkeeping and baseline columns to drop, string
     categoricals (with missing values and a numeric-looking string column that contains letters), numeric columns with missing and
@@ -408,7 +432,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
