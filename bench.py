@@ -139,7 +139,7 @@ class ScanWorkload:
         gbs = (self.bytes_fwd + self.bytes_bwd) / (t_s * 1e-3) / 1e9
         from gfe_hip.step_bench import measured_traffic
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("sscan_fwd_bwd_step_b8") if self.B == 8 else None,
+                "traffic": None, "traffic_source": None,
                 "kernel": "sscan2_fwd + sscan2_bwd (fused selective scan, state-pair lanes; one launch each way from B = 8, three each way when L is chunked)",
                 "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                 "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),
@@ -195,7 +195,9 @@ class Vit3dWorkload:
         flops = 4.0 * B * H * n * n * dh                 # attention FLOPs per layer = 4 B h n^2 d
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": self._traffic(), "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)",
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": self._traffic(),
+                "traffic_source": "profiles/r01/traffic_v13.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.B == 8 else None,
+                "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)",
                 "launch_ms": round(ms, 4), "algorithmic_flops": flops}
 
     def _traffic(self):

@@ -12,17 +12,18 @@
 //   Linear without a transpose pass:  forward y = x W^T: (x, W);  dgrad dx = dy W: (dy, W reduction-major);
 //   wgrad dW = dy^T x: (dy reduction-major, x reduction-major, accumulate into the gradient buffer).
 //
-// Tile 64 x 64 x 32, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of 16 x 16; both operands live in LDS as [k][row] (row stride 80
-// floats: the two k values a 32-lane half reads sit on disjoint bank halves), next tile register-prefetched under the MFMAs
-// (16-byte loads when base, ld and the extent allow).  split_k > 1: blockIdx.z takes a K range and adds with f32 atomics (for the
-// few-block shapes: x_proj is 5 blocks x 1024 deep).
+// Tile T x T x 32 (T = 64 or 32), 4 waves as 2 x 2, each wave (T/32)^2 MFMA tiles of 16 x 16; both operands live in LDS as [k][row]
+// (row stride T + 16 floats: the two k values a 32-lane half reads sit on disjoint bank halves), next tile register-prefetched under
+// the MFMAs (16-byte loads when base, ld and the extent allow).  The f32 MFMA is 32 cycles per instruction and a k-step costs one
+// exposed memory round trip (one tile of prefetch), so these launch-bound shapes (<= 300 rows) want MANY SMALL blocks with DEEP
+// k-steps: T = 32 with 128-deep tiles unless 64 x 64 x 32 tiles already fill the chip.  split_k > 1: blockIdx.z takes a K range and adds with f32 atomics (atomics cost more than they save
+// beyond a few splits: 2.4 MB of output x 8 splits is 15 us of atomic traffic).
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-constexpr int FBM = 64, FBN = 64, FBK = 32, FLD = 80;
 
 struct GemmF32Params {
     const float* A; const float* B; float* C; const float* bias;
@@ -30,82 +31,92 @@ struct GemmF32Params {
     int M, N, K, a_tr, b_tr, accumulate, a_vec, b_vec, ksplit;
 };
 
-// 8 elements of a 64-row x 32-k operand tile per thread.  K-major source: row = t >> 2, k = 8 (t & 3) + i.
-// Reduction-major source: k = t >> 3, row = 8 (t & 7) + i.  vec: 16-byte loads are legal for this operand (host-checked alignment).
-__device__ __forceinline__ void f32_tile_load(const float* __restrict__ base, int64_t ld, int tr, int vec, int row0, int nrows, int k0, int kend, int t, float (&v)[8]) {
+// E = T * BK / 256 elements of a T-row x BK-deep operand tile per thread (256 threads).  K-major source: row = t / (BK / E),
+// k = E (t % (BK / E)) + i.  Reduction-major source: k = t / (T / E), row = E (t % (T / E)) + i.  vec: 16-byte loads are legal for this
+// operand (host-checked alignment).
+template <int T, int BK>
+__device__ __forceinline__ void f32_tile_load(const float* __restrict__ base, int64_t ld, int tr, int vec, int row0, int nrows, int k0, int kend, int t, float (&v)[T * BK / 256]) {
+    constexpr int E = T * BK / 256;
     int outer, inner, outer_n, inner_n;                      // element i of this thread: base[outer * ld + inner + i]
-    if (!tr) { outer = row0 + (t >> 2); inner = k0 + 8 * (t & 3); outer_n = nrows; inner_n = kend; }
-    else { outer = k0 + (t >> 3); inner = row0 + 8 * (t & 7); outer_n = kend; inner_n = nrows; }
+    if (!tr) { outer = row0 + t / (BK / E); inner = k0 + E * (t % (BK / E)); outer_n = nrows; inner_n = kend; }
+    else { outer = k0 + t / (T / E); inner = row0 + E * (t % (T / E)); outer_n = kend; inner_n = nrows; }
     const float* q = base + (size_t)outer * ld + inner;
-    if (vec && outer < outer_n && inner + 8 <= inner_n) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(q), y = *reinterpret_cast<const f32x4*>(q + 4);
-        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; v[4] = y[0]; v[5] = y[1]; v[6] = y[2]; v[7] = y[3];
+    if (vec && outer < outer_n && inner + E <= inner_n) {
+#pragma unroll
+        for (int j = 0; j < E / 4; ++j) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(q + 4 * j);
+            v[4 * j] = x[0]; v[4 * j + 1] = x[1]; v[4 * j + 2] = x[2]; v[4 * j + 3] = x[3];
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (outer < outer_n && inner + i < inner_n) ? q[i] : 0.f;
+        for (int i = 0; i < E; ++i) v[i] = (outer < outer_n && inner + i < inner_n) ? q[i] : 0.f;
     }
 }
-__device__ __forceinline__ void f32_tile_store(float* __restrict__ s, int tr, int t, const float (&v)[8]) {
+template <int T, int BK>
+__device__ __forceinline__ void f32_tile_store(float* __restrict__ s, int tr, int t, const float (&v)[T * BK / 256]) {
+    constexpr int E = T * BK / 256, LD = T + 16;
     if (!tr) {
-        const int r = t >> 2, k = 8 * (t & 3);
+        const int r = t / (BK / E), k = E * (t % (BK / E));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s[(k + i) * FLD + r] = v[i];
+        for (int i = 0; i < E; ++i) s[(k + i) * LD + r] = v[i];
     } else {
-        const int k = t >> 3, r = 8 * (t & 7);
-        *reinterpret_cast<f32x4*>(&s[k * FLD + r]) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(&s[k * FLD + r + 4]) = f32x4{v[4], v[5], v[6], v[7]};
+        const int k = t / (T / E), r = E * (t % (T / E));
+#pragma unroll
+        for (int j = 0; j < E / 4; ++j) *reinterpret_cast<f32x4*>(&s[k * LD + r + 4 * j]) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
     }
 }
 
+template <int T, int FBK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
-    __shared__ __attribute__((aligned(16))) float As[FBK * FLD];
-    __shared__ __attribute__((aligned(16))) float Bs[FBK * FLD];
+    constexpr int LD = T + 16, NI = T / 32, E = T * FBK / 256;       // NI x NI MFMA tiles of 16 x 16 per wave
+    __shared__ __attribute__((aligned(16))) float As[FBK * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[FBK * LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
     const int lr = lane & 15, lq = lane >> 4;
-    f32x4 acc[2][2];
+    f32x4 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ra[8], rb[8];
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ra[E], rb[E];
     const int kbeg = blockIdx.z * p.ksplit, kend = min(p.K, kbeg + p.ksplit);
-    f32_tile_load(p.A, p.lda, p.a_tr, p.a_vec, m0, p.M, kbeg, kend, t, ra);
-    f32_tile_load(p.B, p.ldb, p.b_tr, p.b_vec, n0, p.N, kbeg, kend, t, rb);
+    f32_tile_load<T, FBK>(p.A, p.lda, p.a_tr, p.a_vec, m0, p.M, kbeg, kend, t, ra);
+    f32_tile_load<T, FBK>(p.B, p.ldb, p.b_tr, p.b_vec, n0, p.N, kbeg, kend, t, rb);
     for (int k0 = kbeg; k0 < kend; k0 += FBK) {
         __syncthreads();                                   // everybody is done with the previous tile
-        f32_tile_store(As, p.a_tr, t, ra);
-        f32_tile_store(Bs, p.b_tr, t, rb);
+        f32_tile_store<T, FBK>(As, p.a_tr, t, ra);
+        f32_tile_store<T, FBK>(Bs, p.b_tr, t, rb);
         __syncthreads();
         if (k0 + FBK < kend) {
-            f32_tile_load(p.A, p.lda, p.a_tr, p.a_vec, m0, p.M, k0 + FBK, kend, t, ra);
-            f32_tile_load(p.B, p.ldb, p.b_tr, p.b_vec, n0, p.N, k0 + FBK, kend, t, rb);
+            f32_tile_load<T, FBK>(p.A, p.lda, p.a_tr, p.a_vec, m0, p.M, k0 + FBK, kend, t, ra);
+            f32_tile_load<T, FBK>(p.B, p.ldb, p.b_tr, p.b_vec, n0, p.N, k0 + FBK, kend, t, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < FBK; kk += 4) {
-            float a[2], b[2];
+            float a[NI], b[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(kk + lq) * FLD + wm * 32 + i * 16 + lr];       // A[row = lane & 15][k = lane >> 4]
+            for (int i = 0; i < NI; ++i) a[i] = As[(kk + lq) * LD + wm * (T / 2) + i * 16 + lr];       // A[row = lane & 15][k = lane >> 4]
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + lq) * FLD + wn * 32 + j * 16 + lr];       // B[k = lane >> 4][col = lane & 15]
+            for (int j = 0; j < NI; ++j) b[j] = Bs[(kk + lq) * LD + wn * (T / 2) + j * 16 + lr];       // B[k = lane >> 4][col = lane & 15]
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     // D: row = 4 (lane >> 4) + reg, col = lane & 15
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + j * 16 + lr;
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * (T / 2) + j * 16 + lr;
             if (n >= p.N) continue;
             const float bv = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + 4 * lq + r;
+                const int m = m0 + wm * (T / 2) + i * 16 + 4 * lq + r;
                 if (m < p.M) {
                     float* c = p.C + (size_t)m * p.ldc + n;
                     const float v = acc[i][j][r] + bv;
@@ -124,16 +135,20 @@ int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t 
                  int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, void* stream) {
     GFE_REQUIRE(A && B && C, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && K > 0 && M <= 0x7fffffff && N <= 0x7fffffff && K <= 0x7fffffff, GFE_ERR_SHAPE);
-    GFE_REQUIRE(ceil_div(M, FBM) <= 65535 && split_k >= 1 && split_k <= 64, GFE_ERR_SHAPE);
+    GFE_REQUIRE(ceil_div(M, 32) <= 65535 && split_k >= 1 && split_k <= 64, GFE_ERR_SHAPE);
     GemmF32Params p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.a_tr = a_tr != 0; p.b_tr = b_tr != 0; p.accumulate = accumulate != 0;
     // 16-byte loads: 16-byte aligned base and leading dimension; a thread's 8 elements run along k (K-major) or along rows
     p.a_vec = ((uintptr_t)A % 16 == 0) && lda % 4 == 0;
     p.b_vec = ((uintptr_t)B % 16 == 0) && ldb % 4 == 0;
-    p.ksplit = (int)(ceil_div(ceil_div(K, split_k), FBK) * FBK);
+    p.ksplit = (int)(ceil_div(ceil_div(K, split_k), 128) * 128);
     const unsigned nz = (unsigned)ceil_div(K, p.ksplit);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)ceil_div(N, FBN), (unsigned)ceil_div(M, FBM), nz), dim3(256), 0, (hipStream_t)stream, p);
+    // 64 x 64 tiles only when they alone put >= 512 blocks on the chip; otherwise four times as many 32 x 32 blocks, a quarter of the MFMAs each
+    if (ceil_div(M, 64) * ceil_div(N, 64) * nz >= 512)
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 32>), dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64), nz), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<32, 128>), dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), nz), dim3(256), 0, (hipStream_t)stream, p);
     return gfe_launch_status();
 }
 

@@ -390,10 +390,11 @@ def gemm_f32(a, a_t, b, b_t, bias=None, accum_into=None):
     ld = lambda t: t.stride(0) if t.shape[0] > 1 else t.shape[1]
     assert (b.shape[0] if b_t else b.shape[1]) == K and unit(a) and unit(b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32
-    blocks = -(-M // 64) * -(-N // 64)
-    # launch-bound sizes (a launch costs ~5 us whatever it does; the atomics of a split add 5-10 us): split only the few-block deep
-    # shapes (x_proj: 5 blocks x 1024 deep) so that ~64 blocks are in flight with >= 8 k-steps each
-    split_k = 1 if blocks >= 32 or K < 512 else max(1, min(8, K // 256, 64 // blocks))
+    # launch-bound sizes: the kernel uses 32 x 32 x 128 tiles below 512 blocks of 64 x 64; a block's time is its number of 128-deep
+    # k-steps (one exposed memory round trip + 32 f32 MFMAs each), so K is split -- f32 atomics -- until ~1024 blocks are in flight,
+    # keeping >= 2 k-steps per block and the atomic traffic (output bytes x splits at ~1.3 TB/s) below ~8 MB
+    blocks32 = -(-M // 32) * -(-N // 32)
+    split_k = max(1, min(8, K // 256, 1024 // blocks32, (8 << 20) // max(1, 4 * M * N)))
     if accum_into is not None:
         assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and unit(accum_into) and bias is None
         out = accum_into

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Runs on the GPU box: bench JSON lines + rocprofv3 kernel stats (+ scan PMC) -> gpurun_out/r02/ (copied to profiles/r02/ afterwards).
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/step_b8_bench.json 2> /dev/null
+python3 $R/bench.py --no-pipeline > $O/step_b8_serial_bench.json 2> /dev/null
+python3 $R/bench.py --workload gen128 > $O/gen128_b2_bench.json 2> /dev/null
+python3 $R/bench.py --workload vit3d > $O/vit3d_b8_bench.json 2> /dev/null
+for b in 1 8 64; do python3 $R/bench.py --workload scan --batch $b > $O/scan_b${b}_bench.json 2> /dev/null; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan8 -o scan -- python3 $R/bench.py --workload scan --batch 8 --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan1 -o scan -- python3 $R/bench.py --workload scan --batch 1 --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gen128 -o gen -- python3 $R/bench.py --workload gen128 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv64 -o conv64 -- python3 $R/tools/conv_bench.py 64 96 8 20 > /dev/null 2>&1
+cp $O/prof_step/step_kernel_stats.csv $O/step_b8_kernel_stats.csv
+cp $O/prof_scan8/scan_kernel_stats.csv $O/scan_b8_kernel_stats.csv
+cp $O/prof_scan1/scan_kernel_stats.csv $O/scan_b1_kernel_stats.csv
+cp $O/prof_gen128/gen_kernel_stats.csv $O/gen128_b2_kernel_stats.csv
+cp $O/prof_conv64/conv64_kernel_stats.csv $O/conv64_b8_kernel_stats.csv
+# scan traffic (separate PMC passes, kernel trace only)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_scan_fetch -o p -- python3 $R/bench.py --workload scan --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_scan_write -o p -- python3 $R/bench.py --workload scan --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+$R/exp_build/valu_rates > $O/valu_rates.txt 2>&1
+cd $R
+python3 - <<PY
+import csv, glob, collections, os, json
+O = "$O"
+out = open(os.path.join(O, "scan_traffic.txt"), "w")
+res = {}
+for d, scale in (("pmc_scan_fetch", 2.0), ("pmc_scan_write", 1.0)):      # gfx950: FETCH_SIZE reports half of wide streaming reads (MI355X_MICROARCH.md)
+    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+    if not f: continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"]
+        if "sscan2" not in k: continue
+        agg[k[k.index("sscan2"):][:40]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        kb = sum(v) / len(v) * scale            # counters are in KB
+        res.setdefault(k, {})[d] = kb * 1024
+        line = f"{d:16s} {k:42s} per launch {kb * 1024 / 1e6:9.1f} MB (x{scale:g} applied)"
+        print(line); out.write(line + "\n")
+out.close()
+json.dump(res, open(os.path.join(O, "scan_traffic.json"), "w"), indent=1)
+PY
+for f in $O/*_bench.json; do echo "$(basename $f): $(cut -c1-300 $f)"; done
