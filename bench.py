@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- measures BASELINE.json's metric on MI355X and prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan|vit3d]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan|vit3d|normalise|gen128|gentrain]
 
 workload `step` (default): one classify_mamba training step (frozen generator fwd + head fwd/bwd + per-parameter
 clip + Adam) on a synthetic batch of 8 volumes of 96^3 per GPU (BASELINE config 5's per-GPU share == config 3 + bwd).
@@ -12,6 +12,7 @@ workload `scan`: BASELINE config 2, the fused selective scan alone (L=4096, ED=1
 workload `vit3d`: the synthetic 3-D ViT of SURVEY 8-d (96^3, 8^3 patches -> 1729 tokens, dim 512, depth 4, 8 heads x 64), forward;
 its roofline object is the flash-attention kernel against the bf16 MFMA peak.
 
+workload `gentrain`: SURVEY 8-f1, one generator training step (L1 + Adam) on 128^3 volumes (gfe_hip/gen_train.py).
 workload `gen128`: BASELINE config 4, the generator forward alone (main_gan_vit.py:69) on 2 volumes of 128^3.
 
 N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
@@ -314,12 +315,61 @@ class Gen128Workload:
         return {"generator_gflop_per_volume": self.GFLOP_PER_VOL}
 
 
+class GenTrainWorkload(Gen128Workload):
+    """one generator TRAINING step of main_gan_vit.py:68-82 (L1(model(mri), pet) -> backward -> Adam) on 128^3 volumes,
+    train mode (dropout on), bf16 activations / f32 parameter gradients, FlatAdam without clipping."""
+    name = "Residual_mid_UNet3D_vit training step (main_gan_vit: L1 + Adam), 128^3, synthetic (row f-1)"
+
+    def __init__(self, batch):
+        super().__init__(batch)
+        from gfe_hip.train_ops import FlatAdam
+        self.gen.train()
+        self.opt = FlatAdam([p for p in self.gen.parameters()], lr=1e-4, max_norm=float("inf"))
+        self.target = torch.tanh(torch.randn(batch, 1, *self.vol, generator=torch.Generator().manual_seed(7))).cuda()
+        self.loss = None
+
+    def step(self):
+        from gfe_hip.gen_train import train_step
+        self.loss = train_step(self.gen, self.opt, self.x, self.target)
+
+    def roofline(self, iters=5):
+        """Dominant kernel of the backward: the weight-gradient GEMMs (27 taps x (64 x V) @ (V x 64) reduction-major products)."""
+        from gfe_hip import gen_train as GT
+        B = self.batch
+        xh = torch.randn(B, 128, 128, 128, 64, device="cuda").to(torch.bfloat16)
+        d = torch.randn(B, 128, 128, 128, 64, device="cuda").to(torch.bfloat16)
+        run = lambda: GT.conv_wgrad(xh, d, GT.K.CONV3_TAPS)
+        run()
+        ms = time_region(run, iters)
+        flops = 2.0 * 27 * 64 * 64 * B * 128 ** 3
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": None, "kernel": "conv_wgrad = pad copies + 27 x gemm_nt (Conv3d 3x3x3 64->64 @128^3 weight gradient), per call",
+                "launch_ms": round(ms, 4), "algorithmic_flops": flops}
+
+    def cpu_baseline(self):
+        """torch CPU fp32 autograd through oracle.ref_ops.generator + L1 on ONE 128^3 volume (forward + backward, no optimizer)."""
+        import torch.nn.functional as F
+        from oracle import ref_ops as O
+        sd = {k: v.detach().float().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in self.gen.state_dict().items()}
+        x, tgt = self.x[:1].cpu(), self.target[:1].cpu()
+        t0 = time.perf_counter()
+        _, _, pet = O.generator(x, sd)
+        F.l1_loss(pet, tgt).backward()
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "autograd through oracle.ref_ops.generator + L1, 1 volume of 128^3, fp32, torch CPU"}
+
+    def extra(self):
+        return {"generator_gflop_per_volume_fwd": self.GFLOP_PER_VOL, "l1_loss": None if self.loss is None else round(float(self.loss), 6)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise", "gen128"])
+    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise", "gen128", "gentrain"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (volumes for `step`, sequences for `scan`; default 8, gen128: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph (experimental: for host-bound batches of 1-4 volumes; "
@@ -327,7 +377,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="step workload: strictly serial step (generator, then head) on one stream")
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 2 if a.workload == "gen128" else 8
+        a.batch = 2 if a.workload in ("gen128", "gentrain") else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -348,6 +398,12 @@ def main():
         wl = Gen128Workload(a.batch)
         steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 3
         metric, unit, dtype = "MRI volumes/sec (128^3 bf16) MRI->PET generator forward (main_gan_vit, config 4)", "volumes/s", "bf16"
+        cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "128x128x128",
+               "parallelism": f"replicas x{n_gpus}"}
+    elif a.workload == "gentrain":
+        wl = GenTrainWorkload(a.batch)
+        steps, warmup = a.steps or 10, a.warmup if a.warmup is not None else 2
+        metric, unit, dtype = "MRI volumes/sec (128^3 bf16) MRI->PET generator training step (main_gan_vit, L1 + Adam) [row f-1]", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "128x128x128",
                "parallelism": f"replicas x{n_gpus}"}
     elif a.workload == "scan":

@@ -27,7 +27,10 @@ constexpr int QW = 32;            // query rows per wave
 #define GFE_ATTN_WAVES 8
 #endif
 constexpr int ANW = GFE_ATTN_WAVES;            // waves per block
-constexpr int KT = 64;            // keys per tile
+#ifndef GFE_ATTN_KT
+#define GFE_ATTN_KT 64
+#endif
+constexpr int KT = GFE_ATTN_KT;   // keys per tile
 constexpr int TILE_BYTES = KT * AD * 2;     // 8 KiB
 
 struct AttnParams {
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
     auto dma = [&](int t, int buf) {
         // 16 pieces per tile pair (8 K + 8 V), 4 per wave: piece pc = wave + 4*i covers rows 8*pc .. 8*pc+7 of K (i < 2) or V
 #pragma unroll
-        for (int i = 0; i < 8 / ANW; ++i) {
+        for (int i = 0; i < (KT / 8) / ANW; ++i) {
             const int pc = wave + ANW * i, row = 8 * pc + (lane >> 3), slot = lane & 7;
             const unsigned key = (unsigned)(t * KT + row);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t)(smem + buf * TILE_BYTES + pc * 1024), 16,
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
         const bool ragged = t == ntile - 1 && (p.n & (KT - 1));
 
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2) {
+        for (int kb2 = 0; kb2 < KT / 32; ++kb2) {
             // ---- S^T = K Q^T for a 32-key block: four 16-wide d steps
             f32x16 s;
 #pragma unroll

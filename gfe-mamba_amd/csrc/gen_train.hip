@@ -1,0 +1,266 @@
+// Backward-pass helpers of the generator (conv3d backward / generator training step, main_gan_vit.py:68-82).
+//
+// The heavy products of the backward run on the kernels the forward already has -- dgrad of a 3x3x3 conv is the same implicit GEMM with
+// flipped taps and transposed weights (conv_igemm), wgrad is a voxel-reduction GEMM (gemm_nt, reduction-major operands) -- so what is
+// left are the HBM-bound elementwise / reduction passes around them, on channels-last bf16 tensors (B, V, C), 8 channels (16 B) per lane:
+//   gn_apply        x^ = scale[b,c] * x + shift[b,c]                 GroupNorm output materialised (the forward folds it into the weights; the
+//                                                                    weight gradient needs it as the conv's input)   buildingblocks.py:55-67
+//   mask_relu       dy * (y > 0)                                     ReLU backward from the stored output
+//   gn_bwd_sums     S1[b,c] = sum_v dx^, S2[b,c] = sum_v dx^ * xn    xn = (x - mu) * rstd
+//   gn_bwd_apply    dx = rstd * (gamma * dx^ - a[b,g] - xn * b[b,g]) (+ a second gradient flowing into the same tensor)
+//   maxpool2_bwd    routes dy to the arg-max of every 2x2x2 window   buildingblocks.py:284 (nn.MaxPool3d(2))
+//   out1_bwd        final 1x1x1 conv C -> 1: dx = dy * w, dw, db     model.py:123, 162
+//   in1_wgrad       first 1x1x1 lift 1 -> C: dw = sum dr * x, db     buildingblocks.py:191-198
+//   colsum_bf16     bias gradient of a 1x1x1 lift: sum over voxels
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&o)[8]) {
+    o[0] = bf16lo_to_f32(v.x); o[1] = bf16hi_to_f32(v.x); o[2] = bf16lo_to_f32(v.y); o[3] = bf16hi_to_f32(v.y);
+    o[4] = bf16lo_to_f32(v.z); o[5] = bf16hi_to_f32(v.z); o[6] = bf16lo_to_f32(v.w); o[7] = bf16hi_to_f32(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&o)[8]) {
+    return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+}
+
+// items = B * V * C / 8; item i -> (b, v, c8)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       bf16_t* __restrict__ y, int64_t V, int C, int64_t items) {
+    const int c8n = C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % c8n) * 8;
+        const int64_t b = i / ((int64_t)c8n * V);
+        float f[8];
+        unpack8(reinterpret_cast<const uint4*>(x)[i], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = fmaf(f[k], scale[b * C + c0 + k], shift[b * C + c0 + k]);
+        reinterpret_cast<uint4*>(y)[i] = pack8(f);
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_relu_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ out, int64_t items) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        float g[8], o[8];
+        unpack8(reinterpret_cast<const uint4*>(dy)[i], g);
+        unpack8(reinterpret_cast<const uint4*>(y)[i], o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+        reinterpret_cast<uint4*>(out)[i] = pack8(g);
+    }
+}
+
+// grid (voxel chunks, B); block 256: thread -> channel octet tid % (C/8), voxel lane tid / (C/8); partial sums -> LDS -> f32 atomics
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const bf16_t* __restrict__ dxh, const bf16_t* __restrict__ x, const float* __restrict__ mu,
+                                                          const float* __restrict__ rstd, float* __restrict__ S1, float* __restrict__ S2,
+                                                          int64_t V, int C, int64_t vchunk) {
+    extern __shared__ float sm[];                 // [2][C]
+    const int c8n = C / 8, b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int oct = threadIdx.x % c8n, vl = threadIdx.x / c8n, vlanes = 256 / c8n;
+    if (vl < vlanes) {
+        float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { m[k] = mu[(size_t)b * C + oct * 8 + k]; r[k] = rstd[(size_t)b * C + oct * 8 + k]; }
+        const int64_t v0 = (int64_t)blockIdx.x * vchunk, v1 = min(V, v0 + vchunk);
+        for (int64_t v = v0 + vl; v < v1; v += vlanes) {
+            const size_t it = ((size_t)b * V + v) * c8n + oct;
+            float g[8], xv[8];
+            unpack8(reinterpret_cast<const uint4*>(dxh)[it], g);
+            unpack8(reinterpret_cast<const uint4*>(x)[it], xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] = fmaf(g[k], (xv[k] - m[k]) * r[k], s2[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { atomicAdd(&sm[oct * 8 + k], s1[k]); atomicAdd(&sm[C + oct * 8 + k], s2[k]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(S1 + (size_t)b * C + i, sm[i]); atomicAdd(S2 + (size_t)b * C + i, sm[C + i]); }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ dxh, const bf16_t* __restrict__ x, const float* __restrict__ mu,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb, const bf16_t* __restrict__ add_in,
+                                                           bf16_t* __restrict__ dx, int64_t V, int C, int64_t items) {
+    const int c8n = C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % c8n) * 8;
+        const int64_t b = i / ((int64_t)c8n * V);
+        float g[8], xv[8], a[8];
+        unpack8(reinterpret_cast<const uint4*>(dxh)[i], g);
+        unpack8(reinterpret_cast<const uint4*>(x)[i], xv);
+        if (add_in) unpack8(reinterpret_cast<const uint4*>(add_in)[i], a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t j = (size_t)b * C + c0 + k;
+            const float xn = (xv[k] - mu[j]) * rstd[j];
+            float d = rstd[j] * (gamma[c0 + k] * g[k] - ca[j] - xn * cb[j]);
+            if (add_in) d += a[k];
+            g[k] = d;
+        }
+        reinterpret_cast<uint4*>(dx)[i] = pack8(g);
+    }
+}
+
+// one thread per (output voxel, channel octet): the first maximum of the window in (d, h, w) scan order gets the gradient (ATen rule)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                           int D, int H, int W, int C, int64_t items) {
+    const int c8n = C / 8, od = D / 2, oh = H / 2, ow = W / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int oct = (int)(t % c8n); t /= c8n;
+        const int w = (int)(t % ow); t /= ow;
+        const int h = (int)(t % oh); t /= oh;
+        const int d = (int)(t % od); const int64_t b = t / od;
+        float g[8], best[8], out[8][8];
+        int arg[8];
+        unpack8(reinterpret_cast<const uint4*>(dy)[i], g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; arg[k] = 0; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t src = ((((size_t)b * D + 2 * d + (j >> 2)) * H + 2 * h + ((j >> 1) & 1)) * W + 2 * w + (j & 1)) * c8n + oct;
+            float xv[8];
+            unpack8(reinterpret_cast<const uint4*>(x)[src], xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (j == 0 || xv[k] > best[k]) { best[k] = xv[k]; arg[k] = j; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[j][k] = arg[k] == j ? g[k] : 0.f;
+            const size_t dst = ((((size_t)b * D + 2 * d + (j >> 2)) * H + 2 * h + ((j >> 1) & 1)) * W + 2 * w + (j & 1)) * c8n + oct;
+            reinterpret_cast<uint4*>(dx)[dst] = pack8(out[j]);
+        }
+    }
+}
+
+// final conv C -> 1: x (rows, C) bf16, dy (rows) f32, w (C): dx = dy * w (bf16); dw[c] += sum dy * x; db += sum dy
+__global__ __launch_bounds__(256) void out1_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                       bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int64_t rows, int C, int64_t rchunk) {
+    extern __shared__ float sm[];                 // [C + 1]
+    const int c8n = C / 8;
+    for (int i = threadIdx.x; i <= C; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int oct = threadIdx.x % c8n, rl = threadIdx.x / c8n, rlanes = 256 / c8n;
+    if (rl < rlanes) {
+        float wv[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv[k] = w[oct * 8 + k];
+        const int64_t r0 = (int64_t)blockIdx.x * rchunk, r1 = min(rows, r0 + rchunk);
+        for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+            const float g = dy[r];
+            float xv[8], o[8];
+            unpack8(reinterpret_cast<const uint4*>(x)[(size_t)r * c8n + oct], xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { o[k] = g * wv[k]; acc[k] = fmaf(g, xv[k], acc[k]); }
+            reinterpret_cast<uint4*>(dx)[(size_t)r * c8n + oct] = pack8(o);
+            if (oct == 0) sb += g;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&sm[oct * 8 + k], acc[k]);
+        if (oct == 0) atomicAdd(&sm[C], sb);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dw + i, sm[i]);
+    if (threadIdx.x == 0) atomicAdd(db, sm[C]);
+}
+
+// first lift 1 -> C: x (rows) f32, dr (rows, C) bf16: dw[c] += sum dr * x, db[c] += sum dr
+__global__ __launch_bounds__(256) void in1_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dr, float* __restrict__ dw, float* __restrict__ db,
+                                                        int64_t rows, int C, int64_t rchunk) {
+    extern __shared__ float sm[];                 // [2][C]
+    const int c8n = C / 8;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int oct = threadIdx.x % c8n, rl = threadIdx.x / c8n, rlanes = 256 / c8n;
+    if (rl < rlanes) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int64_t r0 = (int64_t)blockIdx.x * rchunk, r1 = min(rows, r0 + rchunk);
+        for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+            const float xv = x ? x[r] : 1.f;
+            float g[8];
+            unpack8(reinterpret_cast<const uint4*>(dr)[(size_t)r * c8n + oct], g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k] = fmaf(g[k], xv, a[k]); s[k] += g[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { atomicAdd(&sm[oct * 8 + k], a[k]); atomicAdd(&sm[C + oct * 8 + k], s[k]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) { if (dw) atomicAdd(dw + i, sm[i]); atomicAdd(db + i, sm[C + i]); }
+}
+
+static unsigned grid_for(int64_t items) { int64_t g = ceil_div(items, 256); return (unsigned)(g > 8192 ? 8192 : g); }
+
+}  // namespace
+
+extern "C" {
+
+int gfe_gn_apply(const void* x, const float* scale, const float* shift, void* y, int64_t B, int64_t V, int64_t C, void* stream) {
+    GFE_REQUIRE(x && scale && shift && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && V > 0 && C > 0 && C % 8 == 0, GFE_ERR_SHAPE);
+    const int64_t items = B * V * C / 8;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, (bf16_t*)y, V, (int)C, items);
+    return gfe_launch_status();
+}
+
+int gfe_mask_relu_bf16(const void* dy, const void* y, void* out, int64_t n, void* stream) {
+    GFE_REQUIRE(dy && y && out, GFE_ERR_NULL);
+    GFE_REQUIRE(n > 0 && n % 8 == 0, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(mask_relu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)out, n / 8);
+    return gfe_launch_status();
+}
+
+int gfe_gn_bwd_sums(const void* dxhat, const void* x, const float* mu, const float* rstd, float* S1_zeroed, float* S2_zeroed,
+                    int64_t B, int64_t V, int64_t C, void* stream) {
+    GFE_REQUIRE(dxhat && x && mu && rstd && S1_zeroed && S2_zeroed, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && V > 0 && C > 0 && C % 8 == 0 && C <= 2048, GFE_ERR_SHAPE);
+    int64_t chunks = ceil_div(V, 2048); if (chunks > 1024) chunks = 1024;
+    const int64_t vchunk = ceil_div(V, chunks);
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3((unsigned)ceil_div(V, vchunk), (unsigned)B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)dxhat, (const bf16_t*)x, mu, rstd, S1_zeroed, S2_zeroed, V, (int)C, vchunk);
+    return gfe_launch_status();
+}
+
+int gfe_gn_bwd_apply(const void* dxhat, const void* x, const float* mu, const float* rstd, const float* gamma, const float* coef_a, const float* coef_b,
+                     const void* add_in, void* dx, int64_t B, int64_t V, int64_t C, void* stream) {
+    GFE_REQUIRE(dxhat && x && mu && rstd && gamma && coef_a && coef_b && dx, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && V > 0 && C > 0 && C % 8 == 0, GFE_ERR_SHAPE);
+    const int64_t items = B * V * C / 8;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dxhat, (const bf16_t*)x, mu, rstd, gamma,
+                       coef_a, coef_b, (const bf16_t*)add_in, (bf16_t*)dx, V, (int)C, items);
+    return gfe_launch_status();
+}
+
+int gfe_maxpool2_bwd(const void* x, const void* dy, void* dx_zeroed, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, void* stream) {
+    GFE_REQUIRE(x && dy && dx_zeroed, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, GFE_ERR_SHAPE);
+    const int64_t items = B * (D / 2) * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx_zeroed,
+                       (int)D, (int)H, (int)W, (int)C, items);
+    return gfe_launch_status();
+}
+
+int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream) {
+    GFE_REQUIRE(x && dy && w && dx && dw_accum && db_accum, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, GFE_ERR_SHAPE);
+    int64_t chunks = ceil_div(rows, 4096); if (chunks > 2048) chunks = 2048;
+    const int64_t rchunk = ceil_div(rows, chunks);
+    hipLaunchKernelGGL(out1_bwd_kernel, dim3((unsigned)ceil_div(rows, rchunk)), dim3(256), (size_t)(C + 1) * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)x, dy, w, (bf16_t*)dx, dw_accum, db_accum, rows, (int)C, rchunk);
+    return gfe_launch_status();
+}
+
+int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream) {
+    GFE_REQUIRE(dr && db_accum, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, GFE_ERR_SHAPE);
+    int64_t chunks = ceil_div(rows, 4096); if (chunks > 2048) chunks = 2048;
+    const int64_t rchunk = ceil_div(rows, chunks);
+    hipLaunchKernelGGL(in1_wgrad_kernel, dim3((unsigned)ceil_div(rows, rchunk)), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream,
+                       x, (const bf16_t*)dr, dw_accum, db_accum, rows, (int)C, rchunk);
+    return gfe_launch_status();
+}
+
+}  // extern "C"

@@ -229,9 +229,9 @@ def conv_c1_k3_tables(w32_oct, scale, shift, w1, b1):
     sh = scale * b1 + shift
     # weight-only factors, cached: Wt[(t, o)][c] = W[o][c][t] and Wm[(cls, o)][c] = sum_t mask[cls][t] W[o][c][t]; the per-sample tables
     # are then two small f32 MFMA GEMMs (gfe_gemm_f32), no library GEMM on the path
-    key = (w32_oct.data_ptr(), w32_oct._version)
+    key = (w32_oct, w32_oct._version)               # identity, not address: a rebuilt pack may land on the freed one's address
     ent = _C1_WT.get(str(dev))
-    if ent is None or ent[0] != key:
+    if ent is None or ent[0][0] is not key[0] or ent[0][1] != key[1]:
         cout, cin = w32_oct.shape[0], w32_oct.shape[1]
         wt = w32_oct.permute(2, 0, 1).reshape(27 * cout, cin).contiguous()
         wm = gemm_f32(m, False, w32_oct.permute(2, 0, 1).reshape(27, cout * cin).contiguous(), True).reshape(64 * cout, cin)

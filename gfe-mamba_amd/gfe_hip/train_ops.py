@@ -263,6 +263,7 @@ class FlatAdam:
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, chunk=8192):
         self.params = [p for p in params]
+        self.epoch = [0]
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         offs = np.concatenate([[0], np.cumsum([(s + 7) // 8 * 8 for s in sizes])])     # 32-B aligned tensors
@@ -279,6 +280,7 @@ class FlatAdam:
             p.data = self.flat_p[o:o + s].view(p.shape)
             p.grad = self.flat_g[o:o + s].view(p.shape)
             p._gfe_flat_grad = True          # opt-in for the in-place wgrad accumulation (_grad_slot)
+            p._gfe_epoch = self.epoch        # shared update counter: caches derived from p (packed conv weights) key on it
             for c0 in range(0, s, chunk):
                 rec.append((o + c0, min(chunk, s - c0), tid))
         tab = np.zeros(len(rec), dtype=np.dtype([("off", "<i8"), ("len", "<i4"), ("tid", "<i4")]))
@@ -330,6 +332,7 @@ class FlatAdam:
         from .step import allreduce_grads_
         scale = allreduce_grads_(self.flat_g, world_size, group)         # SUM over ranks; the mean is folded into grad_scale
         self.t += 1
+        self.epoch[0] += 1
         self.norm2.zero_()
         call("gfe_clip_adam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.flat_p16),
              ptr(self.chunks), self.nchunks, ptr(self.norm2), scale, self.max_norm, self.lr, self.betas[0], self.betas[1],

@@ -16,13 +16,14 @@ from gfe_hip import nn_ops as K
 
 
 class _PackCache:
-    """Packed bf16 weights, rebuilt when the source parameters change (load_state_dict / .to())."""
+    """Packed bf16 weights, rebuilt when the source parameters change (load_state_dict / .to() / a FlatAdam update, which rewrites the
+    storage from a kernel without a version bump and therefore counts its steps in p._gfe_epoch)."""
 
     def __init__(self):
         self.sig, self.val = None, None
 
     def get(self, params, build):
-        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        sig = tuple((p.data_ptr(), p._version, str(p.device), getattr(p, "_gfe_epoch", (0,))[0]) for p in params)
         if sig != self.sig:
             with torch.no_grad():
                 self.val = build()

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 25
+#define GFE_ABI_VERSION 26
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -287,6 +287,29 @@ int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt,
 /* Weight gradient of the above: dW[s][hw] = sum_{b,c} dout[b][c][s] * mid[b][hw][c]; dout: (B, 2C, S) f32; dW: (S, HW) f32. */
 int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* dout, float* dW,
                          int64_t B, int64_t HW, int64_t C, int64_t S, void* stream);
+
+/* ---- backward-pass helpers of the generator (main_gan_vit.py:68-82; csrc/gen_train.hip) ------------------------------
+ * Channels-last bf16 tensors (B, V, C), C % 8 == 0.  The products of the backward reuse gfe_conv3d_* (dgrad = the forward kernel with
+ * flipped taps and transposed weights) and gfe_gemm_ex (wgrad = voxel-reduction GEMM); these are the passes around them. */
+/* x^ = scale[b,c] * x + shift[b,c]: the GroupNorm output (buildingblocks.py:55-67) materialised as the weight gradient's conv input. */
+int gfe_gn_apply(const void* x, const float* scale, const float* shift, void* y, int64_t B, int64_t V, int64_t C, void* stream);
+/* ReLU backward from the stored output: out = dy * (y > 0); n elements, n % 8 == 0. */
+int gfe_mask_relu_bf16(const void* dy, const void* y, void* out, int64_t n, void* stream);
+/* GroupNorm backward, pass 1: S1[b,c] += sum_v dx^, S2[b,c] += sum_v dx^ * (x - mu[b,c]) * rstd[b,c]  (mu / rstd: the group's values per channel). */
+int gfe_gn_bwd_sums(const void* dxhat, const void* x, const float* mu, const float* rstd, float* S1_zeroed, float* S2_zeroed,
+                    int64_t B, int64_t V, int64_t C, void* stream);
+/* pass 2: dx = rstd * (gamma * dx^ - coef_a[b,c] - xn * coef_b[b,c]) (+ add_in: a second gradient into the same tensor, or NULL);
+ * coef_a / coef_b = the group's mean of gamma * S1 / gamma * S2 over (channels of the group x voxels), per channel. */
+int gfe_gn_bwd_apply(const void* dxhat, const void* x, const float* mu, const float* rstd, const float* gamma, const float* coef_a, const float* coef_b,
+                     const void* add_in, void* dx, int64_t B, int64_t V, int64_t C, void* stream);
+/* nn.MaxPool3d(2) backward (buildingblocks.py:284): dy (B, D/2, H/2, W/2, C) -> dx (B, D, H, W, C), zero on entry; the first maximum of
+ * a window in (d, h, w) order receives the gradient. */
+int gfe_maxpool2_bwd(const void* x, const void* dy, void* dx_zeroed, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, void* stream);
+/* final 1x1x1 conv C -> 1 (model.py:123, 162) backward: x (rows, C) bf16, dy (rows) f32: dx = dy * w; dw += sum dy * x; db += sum dy. */
+int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream);
+/* 1x1x1 lift gradients from dr (rows, C) bf16: db[c] += sum dr; with x (rows) f32 of a one-channel input also dw[c] += sum dr * x
+ * (x == NULL and dw == NULL: bias gradient only). */
+int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream);
 
 /* ---- small operators of the trainable head, f32, one launch per operator and direction (csrc/head_ops.hip) ----------------- */
 

@@ -303,6 +303,38 @@ def combine_classifier_vit_mid(mid_input, mid_output, sd, pre=""):
 # ------------------------------------------------------------------------------------------------
 
 
+_PATTERN = None          # tests only: recorded ReLU / max-pool selections replayed in call order (activation_pattern)
+
+
+class activation_pattern:
+    """Replay a recorded activation pattern inside generator(): every ReLU multiplies by the next recorded 0/1 mask and every 2x2x2
+    max-pool takes the recorded one-hot selection, in call order.  The gradient of a piecewise-linear network is a function of its
+    activation pattern; a bf16 forward flips ~0.1 % of near-zero ReLUs against fp32, each flip an O(1) change of some gradient terms,
+    so gradient parity is checked at the SAME pattern (tests/test_gen_train_gpu.py) and the flipped fraction is checked separately."""
+
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        global _PATTERN
+        _PATTERN = iter(self.masks)
+        return self
+
+    def __exit__(self, *exc):
+        global _PATTERN
+        _PATTERN = None
+
+
+def _relu(x):
+    return F.relu(x) if _PATTERN is None else x * next(_PATTERN).to(x.dtype)
+
+
+def _max_pool2(x):
+    if _PATTERN is None:
+        return F.max_pool3d(x, 2)
+    return F.avg_pool3d(x * next(_PATTERN).to(x.dtype), 2) * 8.0      # the one-hot selection summed over each window
+
+
 def single_conv(x, sd, pre, relu, num_groups=8):
     """SingleConv order 'gcr'/'gc' (pytorch3dunet/unet3d/buildingblocks.py:38-67, 108-115): GroupNorm over
     in_channels -> Conv3d k3 p1 no bias -> optional ReLU."""
@@ -310,7 +342,7 @@ def single_conv(x, sd, pre, relu, num_groups=8):
     g = num_groups if C >= num_groups else 1                         # :62-63
     x = F.group_norm(x, g, sd[pre + "groupnorm.weight"], sd[pre + "groupnorm.bias"], eps=1e-5)
     x = F.conv3d(x, sd[pre + "conv.weight"], None, padding=1)
-    return F.relu(x) if relu else x
+    return _relu(x) if relu else x
 
 
 def resnet_block(x, sd, pre):
@@ -321,7 +353,7 @@ def resnet_block(x, sd, pre):
         r = x                                                        # :198 Identity
     o = single_conv(r, sd, pre + "conv2.", relu=True)
     o = single_conv(o, sd, pre + "conv3.", relu=False)
-    return F.relu(o + r)                                             # :226-227
+    return _relu(o + r)                                              # :226-227
 
 
 def fold_mid(x, md1=8):
@@ -451,7 +483,7 @@ def generator(x, sd, pre="", levels=3, vit_patch=None, vit_heads=6, vit_depth=4,
     feats = []
     for i in range(levels):
         if i > 0:
-            x = F.max_pool3d(x, 2)                                   # buildingblocks.py:284, 306-307
+            x = _max_pool2(x)                                        # buildingblocks.py:284, 306-307
         x = resnet_block(x, sd, f"{pre}encoders.{i}.basic_module.")
         feats.insert(0, x)
     feats = feats[1:]
