@@ -333,7 +333,7 @@ class GenTrainWorkload(Gen128Workload):
         self.loss = train_step(self.gen, self.opt, self.x, self.target)
 
     def roofline(self, iters=5):
-        """Dominant kernel of the backward: the weight-gradient GEMMs (27 taps x (64 x V) @ (V x 64) reduction-major products)."""
+        """Dominant kernel of the backward: the fused weight gradient (27 taps x (64 x V) @ (V x 64), reduction over voxels; csrc/conv_wgrad.hip)."""
         from gfe_hip import gen_train as GT
         B = self.batch
         xh = torch.randn(B, 128, 128, 128, 64, device="cuda").to(torch.bfloat16)
@@ -344,7 +344,7 @@ class GenTrainWorkload(Gen128Workload):
         flops = 2.0 * 27 * 64 * 64 * B * 128 ** 3
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": None, "kernel": "conv_wgrad = pad copies + 27 x gemm_nt (Conv3d 3x3x3 64->64 @128^3 weight gradient), per call",
+                "traffic": None, "kernel": "conv_wgrad_kernel<7> + sum_splits (Conv3d 3x3x3 64->64 @128^3 weight gradient, all 27 taps in one launch)",
                 "launch_ms": round(ms, 4), "algorithmic_flops": flops}
 
     def cpu_baseline(self):

@@ -72,7 +72,12 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-constexpr int TD = 8, TH = 8, TW = 8;          // output tile (class-grid voxels)
+#if !defined(GFE_CONV_TD)
+#define GFE_CONV_TD 8
+#endif
+constexpr int TD = GFE_CONV_TD, TH = 8, TW = 8;   // output tile (class-grid voxels)
+constexpr int A_BUFS = TD == 8 ? 2 : 1;        // TD 4: two independent 4-wave blocks per CU, each with ONE tile buffer (the other block fills its stalls)
+constexpr int NBLK = TD == 8 ? 256 : 512;      // persistent blocks
 constexpr int NWAVES = TD;                     // one wave per output d-plane
 constexpr int NTHREADS = NWAVES * 64;
 constexpr int VSTRIDE = 64;                    // bytes per voxel / weight row in LDS (32 bf16)
@@ -125,8 +130,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     constexpr int W_PIECES = (WSTAGE_ROWS + 15) / 16;        // 1-KiB pieces per stage
     constexpr int W_PER_WAVE = (W_PIECES + DMA_WAVES - 1) / DMA_WAVES;
     uint8_t* sA = smem;                                      // 2 x A_BYTES
-    uint8_t* sW = smem + 2 * A_BYTES;                        // 2 x W_PIECES KiB
-    float* sRed = reinterpret_cast<float*>(smem + 2 * A_BYTES + 2 * W_PIECES * 1024);   // [NWAVES][2][WROWS_TAP] GroupNorm partials of a tile
+    uint8_t* sW = smem + A_BUFS * A_BYTES;                   // 2 x W_PIECES KiB
+    float* sRed = reinterpret_cast<float*>(smem + A_BUFS * A_BYTES + 2 * W_PIECES * 1024);   // [NWAVES][2][WROWS_TAP] GroupNorm partials of a tile
     float* sR1 = sRed + NWAVES * 2 * WROWS_TAP;          // RES1: [2][64] weight / bias of the 1x1x1 lift whose output is the residual
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         const int ut1 = (ut + 1 == upt) ? 0 : ut + 1;
         const int group1 = ut1 / p.nslab, slab1 = ut1 - group1 * p.nslab;
         if (next_unit && ut1 == 0) { nxt_t += tile_stride; nxt = decode(nxt_t); }
-        const uint8_t* aT = sA + (u & 1) * A_BYTES;
+        const uint8_t* aT = sA + (A_BUFS == 2 ? (u & 1) * A_BYTES : 0);
         const int ntaps_u = MC ? p.c_ntaps[cur.cls] : p.ntaps, tap0_u = MC ? p.c_tap0[cur.cls] : 0;
         const int nstage = (ntaps_u + TPS - 1) / TPS;
 
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // stage, the unit's tile) was drained BEFORE the previous unit's epilogue (below), so that epilogue's stores stay in
             // flight across this barrier instead of being waited for (vmcnt retires in order)
             if (!a_wave && s > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (A_BUFS == 1) { if (a_wave && s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // the tile issued after the previous unit
             __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): no LDS read of the previous stage is still pending
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");                   // no LDS access is scheduled across the barrier
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // 2 pieces per stage (1.93), every wave 1/8 of the tile in "its" stage (1.79), all DMA on the weight waves (1.67), block-
             // staggered burst stage (no change), and an address-arithmetic-free burst with the tile origin in the scalar offset
             // (2.11: the 64 misses then sit in front of the next stages' weight pieces in the CU's in-order vector-memory path)
-            if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE);
+            if constexpr (A_BUFS == 2) { if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE); }
 #endif
 
             GFE_STAMP(3);
@@ -397,7 +403,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         }
 
         GFE_STAMP(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // see the stage barrier: nothing but the epilogue's stores crosses the unit boundary
+        if constexpr (A_BUFS == 1) {
+            // single tile buffer: once every wave has read its last fragments the next unit's tile is fetched over it, under the epilogue
+            // (and under the CU's other block); the activation waves wait for it at the next unit's first barrier
+            if (next_unit) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (a_wave) a_dma(nxt, slab1, 0, 0, A_PER_WAVE);
+            }
+            if (!a_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // see the stage barrier: nothing but the epilogue's stores crosses the unit boundary
+        }
 
 #if defined(GFE_EXP_NOEPI)     // timing experiment only: results are never stored
         if (slab == p.nslab - 1 && u + 1 == nunits) {
@@ -693,12 +711,12 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
 template <int NT, int TPS, bool REG27, bool STATS, bool MC = false, bool RES1 = false, bool OUT1 = false>
 int conv_launch(const ConvParams& p, hipStream_t st) {
     constexpr int W_PIECES = (TPS * NT * 16 + 15) / 16;
-    const size_t lds = 2 * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * NT * 16 * sizeof(float) + ((RES1 || OUT1) ? 512 : 0);
+    const size_t lds = A_BUFS * (size_t)A_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * NT * 16 * sizeof(float) + ((RES1 || OUT1) ? 512 : 0);
     const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw * (MC ? p.ncls : 1);
     if (tiles > 0x7fffffff) return GFE_ERR_SHAPE;
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
-    q.tiles_per_block = (int)ceil_div(tiles, 256);
+    q.tiles_per_block = (int)ceil_div(tiles, NBLK);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1, OUT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -715,14 +733,14 @@ int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W) { return (int)(ceil_div(D,
 int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout) {
     const int64_t tps = gfe_conv3d_tiles(D, H, W), tiles = B * tps;
     if (gfe_conv3d_cout_pad(Cout) > 64) return (int)tps;                    // several channel groups: one slot per tile
-    const int64_t tpb = ceil_div(tiles, 256);
+    const int64_t tpb = ceil_div(tiles, NBLK);
     return (int)ceil_div(tiles, tpb);                                        // one slot per persistent block
 }
 
 int gfe_convt3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout) {
     const int64_t tps = gfe_conv3d_tiles(D, H, W), items = B * tps * 8;
     if (gfe_conv3d_cout_pad(Cout) > 64) return (int)(tps * 8);                // (tile, class) slots
-    const int64_t ipb = ceil_div(items, 256);
+    const int64_t ipb = ceil_div(items, NBLK);
     const int slots = (int)ceil_div(items, ipb);                             // one slot per persistent block
     const int slots_res = convt_resident_grid(B, D, H, W, nullptr);          // ... of either kernel (the dispatch depends on Cin)
     return slots > slots_res ? slots : slots_res;

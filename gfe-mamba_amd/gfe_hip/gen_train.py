@@ -20,10 +20,12 @@ Here every layer is a torch.autograd.Function over the same HIP kernels:
 
 Activations are channels-last bf16; parameter gradients are f32.  Dropout follows module.training (main_gan_vit trains with it on; the
 parity tests run eval mode so that the reference's autograd gradients are deterministic)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
-from . import call, nn_ops as K, ptr, stream
+from . import call, lib, nn_ops as K, ptr, stream
 from .head_ops import layernorm_rows, sdpa_small
 from .nn_ops import BF16
 from .train_ops import linear
@@ -52,6 +54,15 @@ def conv_wgrad(inp, dout, taps):
     one reduction-major GEMM per tap over spatially zero-padded copies (a tap is then a row offset).  Returns (ntaps, Co, Ci) f32."""
     B, D, H, W, Ci = inp.shape
     Co = dout.shape[-1]
+    if Ci % 32 == 0 and Co % 64 == 0 and len(taps) <= 27 and os.environ.get("GFE_WGRAD_GEMM") != "1":
+        # one fused launch for all taps (csrc/conv_wgrad.hip): each tensor is read about once instead of once per tap
+        ns = lib().gfe_conv3d_wgrad_splits(B, D, H, W, Ci, Co)
+        assert ns > 0, ns
+        part = torch.empty((ns, len(taps), Co, Ci), dtype=torch.float32, device=inp.device)
+        out = torch.empty((len(taps), Co, Ci), dtype=torch.float32, device=inp.device)
+        tarr, tptr = K._i8(taps)
+        call("gfe_conv3d_wgrad", ptr(inp.contiguous()), ptr(dout.contiguous()), ptr(part), ptr(out), tptr, len(taps), B, D, H, W, Ci, Co, stream())
+        return out
     xp = F.pad(inp, (0, 0, 1, 1, 1, 1, 1, 1)).reshape(-1, Ci)
     dp = F.pad(dout, (0, 0, 1, 1, 1, 1, 1, 1)).reshape(-1, Co)
     R = xp.shape[0]

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 26
+#define GFE_ABI_VERSION 27
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -310,6 +310,15 @@ int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, 
 /* 1x1x1 lift gradients from dr (rows, C) bf16: db[c] += sum dr; with x (rows) f32 of a one-channel input also dw[c] += sum dr * x
  * (x == NULL and dw == NULL: bias gradient only). */
 int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream);
+
+/* Weight gradient of a tap-list convolution (the backward of nn.Conv3d k3 p1 / the parity classes of ConvTranspose3d k3 s2 p1,
+ * pytorch3dunet/unet3d/buildingblocks.py:46-52, 523-537), ALL taps in one launch (csrc/conv_wgrad.hip):
+ *   dw[t][co][ci] = sum_v dout[v][co] * x[v + taps[t]][ci]     x (B, D, H, W, Ci), dout (B, D, H, W, Co) bf16 channels-last,
+ *   taps_host: ntaps x 3 int8 offsets in {-1, 0, 1} (HOST memory, read before the call returns), ntaps <= 27,
+ *   Ci % 32 == 0, Co % 64 == 0.  dw (ntaps, Co, Ci) f32 is WRITTEN; part_ws holds gfe_conv3d_wgrad_splits() * ntaps * Co * Ci floats. */
+int gfe_conv3d_wgrad_splits(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Ci, int64_t Co);
+int gfe_conv3d_wgrad(const void* x, const void* dout, float* part_ws, float* dw, const int8_t* taps_host, int ntaps,
+                     int64_t B, int64_t D, int64_t H, int64_t W, int64_t Ci, int64_t Co, void* stream);
 
 /* ---- small operators of the trainable head, f32, one launch per operator and direction (csrc/head_ops.hip) ----------------- */
 
