@@ -139,8 +139,9 @@ class ScanWorkload:
         t_b = max(t_s - t_f, 1e-6)
         gbs = (self.bytes_fwd + self.bytes_bwd) / (t_s * 1e-3) / 1e9
         from gfe_hip.step_bench import measured_traffic
+        traffic = measured_traffic("scan_b8", ("profiles", "r02", "traffic_r02.json")) if (self.B, self.L, self.ED) == (8, 4096, 1024) else None
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "traffic_source": None,
+                "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r02/traffic_r02.json (committed rocprofv3 PMC passes of this command, not this run)",
                 "kernel": "sscan2_fwd + sscan2_bwd (fused selective scan, state-pair lanes; one launch each way from B = 8, three each way when L is chunked)",
                 "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                 "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),

@@ -136,6 +136,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
+#if defined(GFE_EXP_KPRIO)     // experiment: issue priority over the waves of OTHER kernels that share the SIMD (the head's small launches on the second stream)
+    __builtin_amdgcn_s_setprio(GFE_EXP_KPRIO);
+#endif
     if constexpr (RES1) { if (tid < 64) { sR1[tid] = p.res1_w[tid]; sR1[64 + tid] = p.res1_b[tid]; } }      // visible after the first stage barrier
     if constexpr (OUT1) { if (tid < 64) sR1[tid] = p.out1_w[tid]; }
     const int ntiles = p.B * p.ntd * p.nth * p.ntw * (MC ? p.ncls : 1);       // work items: (tile, class) with the class innermost

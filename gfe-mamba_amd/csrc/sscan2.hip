@@ -131,6 +131,16 @@ struct Tile {
 };
 
 // One block = 32 channels x one chunk.  STATE_ONLY (K1 of the chunked plan): end state from h = 0 and sum(dt), no output.
+// A block's 32 channels are a 64-byte segment of every (b, t) row of the bf16 tensors: HALF a 128-byte line, the other half belongs to the
+// neighbouring channel group.  Workgroups go to the 8 XCDs round-robin, so with the identity mapping the two halves are fetched by two
+// different L2s -- every input line crosses the HBM interface twice (FETCH_SIZE 420 MB for 201 MB of forward inputs, profiles/r02).
+// Groups 2k and 2k + 1 are therefore given to blocks x and x + 8 (same XCD, dispatched together): the second half is an L2 hit.
+__device__ __forceinline__ int xcd_paired_group(int x, int G) {
+    if (G & 15) return x;
+    const int xcd = x & 7, j = x >> 3;
+    return 2 * (xcd + 8 * (j >> 1)) + (j & 1);
+}
+
 template <typename T, bool STATE_ONLY>
 __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
     typedef typename Vec4<T>::type V4;
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
     const int cl = 8 * w + cw;                                   // channel within the block
-    const int e0 = blockIdx.x * CB, c = blockIdx.y, b = blockIdx.z;
+    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
     const int e = e0 + cl;
     const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
     const T* __restrict__ u = (const T*)p.u;
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
     const int cl = 8 * w + cw;
-    const int e0 = blockIdx.x * CB, c = blockIdx.y, b = blockIdx.z;
+    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
     const int e = e0 + cl;
     const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
     const T* __restrict__ u = (const T*)p.u;

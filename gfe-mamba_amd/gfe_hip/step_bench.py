@@ -9,12 +9,12 @@ from .step import ClassifyStep, build_models
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-def measured_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v13.json: FETCH_SIZE x2 as the
-    gfx950 correction prescribes + WRITE_SIZE, separate passes); None when the file does not travel with the tree."""
+def measured_traffic(key, rel=("profiles", "r01", "traffic_v13.json")):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v13.json, profiles/r02/traffic_r02.json:
+    FETCH_SIZE x2 as the gfx950 correction prescribes + WRITE_SIZE, separate passes); None when the file does not travel with the tree."""
     import json
     import os
-    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01", "traffic_v13.json")
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), *rel)
     try:
         return float(json.load(open(f))[key]["traffic_bytes"])          # a committed rocprofv3 measurement, not this run's
     except (OSError, KeyError, ValueError):

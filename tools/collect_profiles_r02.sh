@@ -8,12 +8,17 @@ python3 $R/bench.py > $O/step_b8_bench.json 2> /dev/null
 python3 $R/bench.py --no-pipeline > $O/step_b8_serial_bench.json 2> /dev/null
 python3 $R/bench.py --workload gen128 > $O/gen128_b2_bench.json 2> /dev/null
 python3 $R/bench.py --workload vit3d > $O/vit3d_b8_bench.json 2> /dev/null
+python3 $R/bench.py --workload gentrain > $O/gentrain_b2_bench.json 2> /dev/null
 for b in 1 8 64; do python3 $R/bench.py --workload scan --batch $b > $O/scan_b${b}_bench.json 2> /dev/null; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan8 -o scan -- python3 $R/bench.py --workload scan --batch 8 --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan1 -o scan -- python3 $R/bench.py --workload scan --batch 1 --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gen128 -o gen -- python3 $R/bench.py --workload gen128 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv64 -o conv64 -- python3 $R/tools/conv_bench.py 64 96 8 20 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gentrain -o gentrain -- python3 $R/bench.py --workload gentrain --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vit3d -o vit -- python3 $R/bench.py --workload vit3d --no-cpu-baseline > /dev/null 2>&1
+cp $O/prof_gentrain/gentrain_kernel_stats.csv $O/gentrain_b2_kernel_stats.csv
+cp $O/prof_vit3d/vit_kernel_stats.csv $O/vit3d_b8_kernel_stats.csv
 cp $O/prof_step/step_kernel_stats.csv $O/step_b8_kernel_stats.csv
 cp $O/prof_scan8/scan_kernel_stats.csv $O/scan_b8_kernel_stats.csv
 cp $O/prof_scan1/scan_kernel_stats.csv $O/scan_b1_kernel_stats.csv
@@ -44,5 +49,9 @@ for d, scale in (("pmc_scan_fetch", 2.0), ("pmc_scan_write", 1.0)):      # gfx95
         print(line); out.write(line + "\n")
 out.close()
 json.dump(res, open(os.path.join(O, "scan_traffic.json"), "w"), indent=1)
+tot = sum(sum(v.values()) for v in res.values())
+json.dump({"scan_b8": {"traffic_bytes": tot, "per_kernel": res,
+                       "method": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 reports half of coalesced reads at 4, 8 and 16 B per lane, tools/probes/fetch_calib.hip) and --pmc WRITE_SIZE, separate passes, mean per launch of sscan2_fwd + sscan2_bwd at B=8 L=4096 ED=1024 N=16 bf16"}},
+          open(os.path.join(O, "traffic_r02.json"), "w"), indent=1)
 PY
 for f in $O/*_bench.json; do echo "$(basename $f): $(cut -c1-300 $f)"; done
