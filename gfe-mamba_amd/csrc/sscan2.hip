@@ -708,7 +708,7 @@ int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out,
     } else {
         const int64_t waves = B * (ED / 8);                       // one wave = 8 channels x 8 state pairs
         if (waves < 768) {                                        // cannot fill 1024 SIMDs: cut L (two passes + carry)
-            const int64_t want = ceil_div(1024, waves);
+            const int64_t want = ceil_div(2048, waves);           // two waves per SIMD: measured -8 % (B = 1) / -7 % (B = 4) kernel time vs one
             T = ceil_div(ceil_div(L, want), SEG) * SEG;
             if (T < 64) T = 64;
         }
