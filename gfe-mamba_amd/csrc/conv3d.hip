@@ -449,6 +449,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                     const int ch_ = h0 + 2 * xt + (lr >> 3), cw_ = w0 + (lr & 7);
                     if (ch_ >= p.H || cw_ >= p.W) continue;
                     const unsigned o = (unsigned)(((wave * p.H + 2 * xt + (lr >> 3)) * p.W + (lr & 7)) * p.Cout + c0);   // inside the tile's box
+                    uint4 rv[2];                                                 // skip / residual rows first: one L2 round trip together with the bias rows
+                    if (res_t) { const uint4* rp = reinterpret_cast<const uint4*>(res_t + o); rv[0] = rp[0]; rv[1] = rp[1]; }
                     if (p.bias_tab) {
                         const int cls = (cd == 0) | ((cd == p.D - 1) << 1) | ((ch_ == 0) << 2) | ((ch_ == p.H - 1) << 3) |
                                         ((cw_ == 0) << 4) | ((cw_ == p.W - 1) << 5);
@@ -481,8 +483,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         }
                     }
                     float o1 = 0.f;
-                    uint4 rv[2];
-                    if (res_t) { const uint4* rp = reinterpret_cast<const uint4*>(res_t + o); rv[0] = rp[0]; rv[1] = rp[1]; }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const uint32_t rw[4] = {rv[h].x, rv[h].y, rv[h].z, rv[h].w};
