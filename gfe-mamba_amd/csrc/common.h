@@ -87,3 +87,20 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- zero fill as a KERNEL --------------------------------------------------------------------------------------------------------
+// hipMemsetAsync inside a stream capture becomes a memset NODE, and on this ROCm graph replay does not keep such a node ordered behind
+// the kernel nodes in front of it: when the target block of the graph's private pool had an earlier tenant in the same graph, the
+// replayed memset clobbers that tenant's live data (tools/graph_gen_bisect.py: every piece of the generator replays bit-exactly on its
+// own, the composition returned garbage from the second replay on, and downstream kernels then died with HSA_STATUS_ERROR_EXCEPTION).
+// A fill kernel is an ordinary kernel node.  bytes must be a multiple of 4, p 4-byte aligned.
+static __global__ __launch_bounds__(256) void gfe_zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline void gfe_zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gfe_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n);
+}

@@ -766,7 +766,7 @@ int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, 
     const int cp = gfe_conv3d_cout_pad(Cout), nslab = (int)ceil_div(Cin, 32);
     const int NT = (cp < 64 ? cp : 64) / 16;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(T_ws, 0, (size_t)B * ntaps * cp * sizeof(float), st);
+    gfe_zero_async(T_ws, (size_t)B * ntaps * cp * sizeof(float), st);
     hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)nslab * ntaps * cp * 4, 256), (unsigned)B), dim3(256), 0, st,
                        w_packed_f32, gn_scale, gn_shift, (bf16_t*)w_out, T_ws, nslab, ntaps, cp, (int)Cin);
     hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)64 * cp, 256), (unsigned)B), dim3(256), 0, st,

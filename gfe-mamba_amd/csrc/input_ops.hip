@@ -179,7 +179,7 @@ int gfe_adaptive_normal(const float* x, float* y, uint32_t* ws, int64_t B, int64
     GFE_REQUIRE(x && y && ws, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 65535 && n > 0 && n < (1LL << 32), GFE_ERR_SHAPE);       // counts and ranks are 32-bit
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, (size_t)B * WS_WORDS * sizeof(uint32_t), st) != hipSuccess) return GFE_ERR_HIP;
+    gfe_zero_async(ws, (size_t)B * WS_WORDS * sizeof(uint32_t), st);
     const int64_t per = (int64_t)HIST_THREADS * 4 * 8;                               // ~8 float4 per thread
     const unsigned gx = (unsigned)(ceil_div(n, per) < 2048 ? ceil_div(n, per) : 2048);
     const dim3 grid(gx, (unsigned)B);

@@ -221,7 +221,7 @@ int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld,
     const int rpb = (int)ceil_div(M, rblocks);
     rblocks = ceil_div(M, rpb);
     hipStream_t st = (hipStream_t)stream;
-    if (rblocks > 1 && !accumulate) (void)hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
+    if (rblocks > 1 && !accumulate) gfe_zero_async(out, (size_t)N * sizeof(float), st);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)rblocks), dim3(256), 0, st, x, out, (int)M, (int)N, ld, accumulate, rpb);
     return gfe_launch_status();
 }

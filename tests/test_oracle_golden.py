@@ -177,3 +177,57 @@ def test_adaptive_normal_bit_exact():
     for name in AN_CASES:
         got = O.adaptive_normal(torch.from_numpy(fx[name + ".x"].copy())).numpy()
         assert np.array_equal(got, fx[name + ".y"], equal_nan=True), name
+
+
+def test_activation_pattern_replay_reproduces_the_plain_generator():
+    """oracle.ref_ops.activation_pattern (used by the f-1 gradient parity tests): replaying the generator's OWN ReLU masks and max-pool
+    selections must give the same output and the same parameter gradients as the plain evaluation."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    f = (8, 16, 32)
+    sd = {}
+    def conv(pre, cin, cout):
+        sd[pre + "groupnorm.weight"] = 1 + 0.1 * torch.randn(cin); sd[pre + "groupnorm.bias"] = 0.1 * torch.randn(cin)
+        sd[pre + "conv.weight"] = torch.randn(cout, cin, 3, 3, 3) / (27 * cin) ** 0.5
+    cin = 1
+    for i, c in enumerate(f):
+        pre = f"encoders.{i}.basic_module."
+        sd[pre + "conv1.weight"] = torch.randn(c, cin, 1, 1, 1) / cin ** 0.5; sd[pre + "conv1.bias"] = 0.1 * torch.randn(c)
+        conv(pre + "conv2.", c, c); conv(pre + "conv3.", c, c)
+        cin = c
+    x = torch.randn(1, 1, 8, 8, 8)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+    def encoders(p, record=None):
+        t = x
+        for i in range(3):
+            if i > 0:
+                if record is not None:
+                    y, idx = F.max_pool3d(t, 2, return_indices=True)
+                    m = torch.zeros_like(t).flatten(2).scatter_(2, idx.flatten(2), 1.0).view_as(t)
+                    record.append(m)
+                t = O._max_pool2(t)
+            r = F.conv3d(t, p[f"encoders.{i}.basic_module.conv1.weight"], p[f"encoders.{i}.basic_module.conv1.bias"])
+            if record is not None:
+                o2 = O.single_conv(r, p, f"encoders.{i}.basic_module.conv2.", relu=False)
+                record.append((o2 > 0).float())
+                o3 = O.single_conv(F.relu(o2), p, f"encoders.{i}.basic_module.conv3.", relu=False)
+                record.append(((o3 + r) > 0).float())
+            t = O.resnet_block(t, p, f"encoders.{i}.basic_module.")
+        return t
+
+    rec = []
+    with torch.no_grad():
+        encoders(sd, rec)
+    y0 = encoders(params)
+    y0.square().sum().backward()
+    g0 = {k: v.grad.clone() for k, v in params.items()}
+    for v in params.values():
+        v.grad = None
+    with O.activation_pattern(rec):
+        y1 = encoders(params)
+    y1.square().sum().backward()
+    assert torch.allclose(y0, y1, atol=1e-6)
+    for k, v in params.items():
+        assert torch.allclose(v.grad, g0[k], atol=1e-5, rtol=1e-5), k
+    assert O._PATTERN is None
