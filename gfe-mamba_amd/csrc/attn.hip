@@ -32,6 +32,11 @@ constexpr int ANW = GFE_ATTN_WAVES;            // waves per block
 #endif
 constexpr int KT = GFE_ATTN_KT;   // keys per tile
 constexpr int TILE_BYTES = KT * AD * 2;     // 8 KiB
+#ifndef GFE_ATTN_RING
+#define GFE_ATTN_RING 2        // 3 (tile t+2 in flight, counted vmcnt waits) measured 104.6 vs 99-101 us: the DMA's cost is not its latency
+#endif
+constexpr int RING = GFE_ATTN_RING;         // K/V tiles in LDS: tile t+RING-1 is in flight while tile t is multiplied (2: one tile ahead)
+constexpr int PIECES_PER_WAVE = 2 * ((KT / 8) / ANW);   // LDS-DMA instructions one wave issues per tile (K + V)
 
 struct AttnParams {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
@@ -51,7 +56,7 @@ __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((
 // (HIP: the second __launch_bounds__ argument is the minimum number of waves per SIMD: 4 keeps the kernel at <= 128 VGPRs)
 __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer / LDS-DMA builtins)
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * TILE_BYTES];      // K[2], V[2]
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * RING * TILE_BYTES];      // K[RING], V[RING]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -94,19 +99,24 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
             const unsigned key = (unsigned)(t * KT + row);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t)(smem + buf * TILE_BYTES + pc * 1024), 16,
                                                      key * row_bytes_k + ((slot ^ (row & 7)) * 16), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t)(smem + (2 + buf) * TILE_BYTES + pc * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t)(smem + (RING + buf) * TILE_BYTES + pc * 1024), 16,
                                                      key * row_bytes_v + ((slot ^ (((row >> 1) & 1) << 2)) * 16), 0, 0, 0);
         }
     };
 
     dma(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RING > 2) { if (ntile > 1) dma(1, 1); }
+    // vmcnt retires in order: leaving the newest tile's pieces outstanding is a COUNTED wait (a vmcnt(0) here would drain the prefetch)
+    if (RING > 2 && ntile > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (PIECES_PER_WAVE & 15) | ((PIECES_PER_WAVE >> 4) << 14));
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) dma(t + 1, (t + 1) & 1);                  // lands under this tile's MFMAs; nobody reads that buffer any more
-        const uint8_t* sk = smem + (t & 1) * TILE_BYTES;
-        const uint8_t* sv = smem + (2 + (t & 1)) * TILE_BYTES;
+#if !defined(GFE_ATTN_EXP_NODMA)     // timing experiment only: K/V tiles are never restaged
+        if (t + RING - 1 < ntile) dma(t + RING - 1, (t + RING - 1) % RING);   // lands under the next tiles' MFMAs; nobody reads that buffer any more
+#endif
+        const uint8_t* sk = smem + (t % RING) * TILE_BYTES;
+        const uint8_t* sv = smem + (RING + (t % RING)) * TILE_BYTES;
         const bool ragged = t == ntile - 1 && (p.n & (KT - 1));
 
 #pragma unroll
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile landed (this wave's pieces); the barrier makes all of it visible
+        // tile t+1 has landed (this wave's pieces; the barrier makes all of it visible) while tile t+2's pieces, issued above, stay in flight
+        if (RING > 2 && t + RING - 1 < ntile) __builtin_amdgcn_s_waitcnt(0x0f70 | (PIECES_PER_WAVE & 15) | ((PIECES_PER_WAVE >> 4) << 14));
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
