@@ -293,6 +293,81 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
     }
 }
 
+// ---- LayerNorm over LONG rows (the generator ViT's LayerNorm(patch_dim), patch_dim = 262,144 at 128^3, 64 rows): one block per row
+// leaves 192 CUs idle and walks 1 MB three times from one CU (1.8 ms backward).  A row is cut into `splits` segments, grid (splits, rows):
+//   moments: per-segment mean and centred second moment (two local passes, the segment stays in L2), combined with Chan's formula
+//   apply:   every block recombines the <= 64 partials of its row in double and normalises its segment
+__global__ __launch_bounds__(256) void ln_long_moments_kernel(const float* __restrict__ x, float* __restrict__ part, int dim, int seg) {
+    __shared__ float scratch[32];
+    const int r = blockIdx.y, sp = blockIdx.x, d0 = sp * seg, d1 = min(dim, d0 + seg);
+    const float* xp = x + (size_t)r * dim;
+    float s = 0.f;
+    for (int d = d0 + threadIdx.x; d < d1; d += 256) s += xp[d];
+    const float mu = block_sum(s, scratch) / (float)(d1 - d0);
+    float v = 0.f;
+    for (int d = d0 + threadIdx.x; d < d1; d += 256) { const float c = xp[d] - mu; v = fmaf(c, c, v); }
+    v = block_sum(v, scratch + 16);
+    if (threadIdx.x == 0) { part[((size_t)r * gridDim.x + sp) * 2] = mu; part[((size_t)r * gridDim.x + sp) * 2 + 1] = v; }
+}
+__device__ __forceinline__ void ln_long_combine(const float* __restrict__ part, int r, int splits, int dim, int seg, float eps, float& mu_o, float& rs_o) {
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int k = 0; k < splits; ++k) {
+        const double nk = (double)(min(dim, (k + 1) * seg) - k * seg), mk = part[((size_t)r * splits + k) * 2], vk = part[((size_t)r * splits + k) * 2 + 1];
+        const double delta = mk - mean, tot = n + nk;
+        m2 += vk + delta * delta * n * nk / tot;
+        mean += delta * nk / tot;
+        n = tot;
+    }
+    mu_o = (float)mean;
+    rs_o = (float)(1.0 / sqrt(m2 / n + (double)eps));                  // biased variance (torch.nn.LayerNorm)
+}
+__global__ __launch_bounds__(256) void ln_long_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ part, float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int dim, int seg, float eps) {
+    const int r = blockIdx.y, sp = blockIdx.x, d0 = sp * seg, d1 = min(dim, d0 + seg);
+    float mu, rs;
+    ln_long_combine(part, r, gridDim.x, dim, seg, eps, mu, rs);
+    const float* xp = x + (size_t)r * dim;
+    for (int d = d0 + threadIdx.x; d < d1; d += 256) y[(size_t)r * dim + d] = fmaf((xp[d] - mu) * rs, gamma[d], beta[d]);
+    if (sp == 0 && threadIdx.x == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+// backward: segment sums of g = dy * gamma and g * xhat, then dx / dgamma / dbeta per segment
+__global__ __launch_bounds__(256) void ln_long_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ dy, float* __restrict__ part,
+                                                               int dim, int seg) {
+    __shared__ float scratch[32];
+    const int r = blockIdx.y, sp = blockIdx.x, d0 = sp * seg, d1 = min(dim, d0 + seg);
+    const float mu = mean[r], rs = rstd[r];
+    const float* xp = x + (size_t)r * dim;
+    const float* gp = dy + (size_t)r * dim;
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = d0 + threadIdx.x; d < d1; d += 256) {
+        const float xh = (xp[d] - mu) * rs, g = gp[d] * gamma[d];
+        s1 += g; s2 = fmaf(g, xh, s2);
+    }
+    s1 = block_sum(s1, scratch);
+    s2 = block_sum(s2, scratch + 16);
+    if (threadIdx.x == 0) { part[((size_t)r * gridDim.x + sp) * 2] = s1; part[((size_t)r * gridDim.x + sp) * 2 + 1] = s2; }
+}
+__global__ __launch_bounds__(256) void ln_long_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ dy, const float* __restrict__ part,
+                                                                float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int dim, int seg) {
+    const int r = blockIdx.y, sp = blockIdx.x, d0 = sp * seg, d1 = min(dim, d0 + seg);
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < (int)gridDim.x; ++k) { a1 += part[((size_t)r * gridDim.x + k) * 2]; a2 += part[((size_t)r * gridDim.x + k) * 2 + 1]; }
+    const float s1 = (float)(a1 / dim), s2 = (float)(a2 / dim);
+    const float mu = mean[r], rs = rstd[r];
+    const float* xp = x + (size_t)r * dim;
+    const float* gp = dy + (size_t)r * dim;
+    for (int d = d0 + threadIdx.x; d < d1; d += 256) {
+        const float xh = (xp[d] - mu) * rs, g = gp[d] * gamma[d];
+        dx[(size_t)r * dim + d] = rs * (g - s1 - xh * s2);
+        atomicAdd(dgamma + d, gp[d] * xh);
+        atomicAdd(dbeta + d, gp[d]);
+    }
+}
+constexpr int LN_LONG_DIM = 16384, LN_LONG_SEG = 4096, LN_LONG_MAX_SPLITS = 64;
+
 // ---- GEGLU + dropout ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad_(float x) {
@@ -426,17 +501,31 @@ int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const flo
     return gfe_launch_status();
 }
 
-int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, float* ws,
                            int64_t rows, int64_t dim, float eps, void* stream) {
     GFE_REQUIRE(x && gamma && beta && y && mean && rstd, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    if (dim >= LN_LONG_DIM && ws && rows <= 65535) {
+        int splits = (int)ceil_div(dim, (int64_t)LN_LONG_SEG); if (splits > LN_LONG_MAX_SPLITS) splits = LN_LONG_MAX_SPLITS;
+        const int seg = (int)ceil_div(dim, (int64_t)splits);
+        hipLaunchKernelGGL(ln_long_moments_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, ws, (int)dim, seg);
+        hipLaunchKernelGGL(ln_long_apply_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, ws, y, mean, rstd, (int)dim, seg, eps);
+        return gfe_launch_status();
+    }
     hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (int)dim, eps);
     return gfe_launch_status();
 }
 int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
-                           float* dgamma, float* dbeta, int64_t rows, int64_t dim, void* stream) {
+                           float* dgamma, float* dbeta, float* ws, int64_t rows, int64_t dim, void* stream) {
     GFE_REQUIRE(x && gamma && mean && rstd && dy && dx && dgamma && dbeta, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    if (dim >= LN_LONG_DIM && ws && rows <= 65535) {
+        int splits = (int)ceil_div(dim, (int64_t)LN_LONG_SEG); if (splits > LN_LONG_MAX_SPLITS) splits = LN_LONG_MAX_SPLITS;
+        const int seg = (int)ceil_div(dim, (int64_t)splits);
+        hipLaunchKernelGGL(ln_long_bwd_sums_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, (int)dim, seg);
+        hipLaunchKernelGGL(ln_long_bwd_apply_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, dx, dgamma, dbeta, (int)dim, seg);
+        return gfe_launch_status();
+    }
     hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, (int)dim);
     return gfe_launch_status();
 }

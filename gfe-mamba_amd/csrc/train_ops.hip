@@ -265,7 +265,9 @@ int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, co
     // bias corrections as torch.optim.Adam computes them (Python doubles): 1 - 0.999^t in f32 loses ~1e-5 relative to cancellation
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const Chunk*)chunks, norm2_zeroed, grad_scale);
+    // max_norm = +inf (plain Adam, the generator's optimizer): the clip coefficient is 1 for every tensor, whatever the norms (zeros here)
+    if (max_norm < 3.0e38f)
+        hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const Chunk*)chunks, norm2_zeroed, grad_scale);
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_bf16, (const Chunk*)chunks,
                        norm2_zeroed, grad_scale, max_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)eps, (float)(1.0 / sqrt(bc2)));
     return gfe_launch_status();

@@ -79,8 +79,12 @@ class _GroupNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps):
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        scale, shift = K.groupnorm_scale_shift(x.detach(), g, b, groups, eps)          # (B, C): x^ = scale * x + shift
-        xhat = gn_apply(x.detach(), scale, shift)
+        xd = x.detach()
+        part = getattr(x, "gn_partials", None)             # written by the producing conv's epilogue: no statistics pass over x
+        if part is not None:
+            xd.gn_partials = part
+        scale, shift = K.groupnorm_scale_shift(xd, g, b, groups, eps)                 # (B, C): x^ = scale * x + shift
+        xhat = gn_apply(xd, scale, shift)
         rstd = scale / g                                                              # scale = gamma * rstd, shift = beta - mu * scale
         mu = (b - shift) / scale
         ctx.save_for_backward(x.detach(), g, mu.contiguous(), rstd.contiguous())
@@ -110,7 +114,7 @@ class _Conv3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xhat, weight, res, relu):
         cout = weight.shape[0]
-        y = K.conv_igemm(xhat.detach(), K.pack_conv3(weight), K.CONV3_TAPS, cout, res=None if res is None else res.detach(), relu=relu)
+        y = K.conv_igemm(xhat.detach(), K.pack_conv3(weight), K.CONV3_TAPS, cout, res=None if res is None else res.detach(), relu=relu, stats=True)
         if relu and PATTERN_LOG is not None:
             PATTERN_LOG.append(y > 0)
         ctx.save_for_backward(xhat.detach(), weight, y if relu else None)
@@ -138,7 +142,7 @@ class _Conv1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         cout = weight.shape[0]
-        y = K.conv_igemm(x.detach(), K.pack_conv1(weight), [(0, 0, 0)], cout, bias=bias.detach().float().contiguous())
+        y = K.conv_igemm(x.detach(), K.pack_conv1(weight), [(0, 0, 0)], cout, bias=bias.detach().float().contiguous(), stats=True)
         ctx.save_for_backward(x.detach(), weight)
         return y
 

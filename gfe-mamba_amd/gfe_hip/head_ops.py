@@ -158,7 +158,8 @@ class _LayerNormRows(torch.autograd.Function):
         rows, dim = x2.shape
         y = torch.empty_like(x2)
         st = torch.empty((2, rows), dtype=torch.float32, device=x.device)
-        call("gfe_layernorm_rows_fwd", ptr(x2), ptr(g_), ptr(b_), ptr(y), ptr(st[0]), ptr(st[1]), rows, dim, float(eps), stream())
+        ws = torch.empty(rows * 128, dtype=torch.float32, device=x.device) if dim >= 16384 else None     # long rows: segment partials
+        call("gfe_layernorm_rows_fwd", ptr(x2), ptr(g_), ptr(b_), ptr(y), ptr(st[0]), ptr(st[1]), ptr(ws), rows, dim, float(eps), stream())
         ctx.save_for_backward(x2, g_, st)
         ctx.refs = (gamma, beta)
         ctx.xs = xs
@@ -172,7 +173,8 @@ class _LayerNormRows(torch.autograd.Function):
         d = dy.float().reshape(rows, dim).contiguous()
         dx = torch.empty_like(x2)
         (dg, own_g), (db, own_b) = _acc_target(gamma), _acc_target(beta)
-        call("gfe_layernorm_rows_bwd", ptr(x2), ptr(g_), ptr(st[0]), ptr(st[1]), ptr(d), ptr(dx), ptr(dg), ptr(db), rows, dim, stream())
+        ws = torch.empty(rows * 128, dtype=torch.float32, device=x2.device) if dim >= 16384 else None
+        call("gfe_layernorm_rows_bwd", ptr(x2), ptr(g_), ptr(st[0]), ptr(st[1]), ptr(d), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, dim, stream())
         return dx.view(ctx.xs), (None if own_g else dg), (None if own_b else db), None
 
 

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 27
+#define GFE_ABI_VERSION 28
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -352,11 +352,12 @@ int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const flo
                        float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, void* stream);
 
 /* nn.LayerNorm(dim) over (rows, dim) f32 (mamba_transformer.py:79-82, corss_ft_transformer.py:16); mean / rstd (rows) kept for the
- * backward, which ACCUMULATES dgamma / dbeta (f32 atomics) and writes dx. */
-int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+ * backward, which ACCUMULATES dgamma / dbeta (f32 atomics) and writes dx.  ws: NULL, or rows * 128 floats of scratch -- with it, rows of
+ * dim >= 16384 (the generator ViT's LayerNorm(patch_dim), vit.py:101-105) are cut into up to 64 segments that run on different CUs. */
+int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, float* ws,
                            int64_t rows, int64_t dim, float eps, void* stream);
 int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
-                           float* dgamma, float* dbeta, int64_t rows, int64_t dim, void* stream);
+                           float* dgamma, float* dbeta, float* ws, int64_t rows, int64_t dim, void* stream);
 
 /* GEGLU (corss_ft_transformer.py:10-13: x, gates = chunk(2); x * gelu(gates), exact erf) followed by Dropout(p_drop) (:19):
  * x (rows, 2F) -> y (rows, F).  The mask is a counter-based hash of (seed, element index): the backward regenerates it from the

@@ -236,3 +236,23 @@ def test_generator_train_steps_reduce_the_l1_loss_and_refresh_the_frozen_packs()
         again = generator_forward_train(gen, x).float()
     assert rel_err(after, again) < 2e-2                             # frozen-forward path == training forward on the UPDATED weights
     assert rel_err(after, before) > 5e-2
+
+
+@pytest.mark.parametrize("rows,dim", [(6, 16384), (3, 50000), (64, 262144)])
+def test_long_row_layernorm_vs_torch(rows, dim):
+    """gfe_layernorm_rows on rows of >= 16384 elements (the generator ViT's LayerNorm(patch_dim), vit.py:101-105): segments of a row run
+    on different CUs (Chan-combined moments); forward, dx, dgamma, dbeta against torch in fp64, with a large common offset in the rows."""
+    from gfe_hip.head_ops import layernorm_rows
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, dim, generator=g) + 3.0 * torch.randn(rows, 1, generator=g)).to(DEV).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(dim, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.1 * torch.randn(dim, generator=g)).to(DEV).requires_grad_(True)
+    w = torch.randn(rows, dim, generator=g).to(DEV)
+    y = layernorm_rows(x, gamma, beta)
+    (y * w).sum().backward()
+    xr, gr, br = [t.detach().double().cpu().requires_grad_(True) for t in (x, gamma, beta)]
+    yr = F.layer_norm(xr, (dim,), gr, br)
+    (yr * w.double().cpu()).sum().backward()
+    e = dict(y=rel_err(y, yr), dx=rel_err(x.grad, xr.grad), dgamma=rel_err(gamma.grad, gr.grad), dbeta=rel_err(beta.grad, br.grad))
+    print("long-row LayerNorm (%d, %d): %s" % (rows, dim, {k: "%.1e" % v for k, v in e.items()}))
+    assert max(e.values()) < 2e-5, e
