@@ -130,7 +130,14 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     __shared__ float red[16];
     const Chunk ck = chunks[blockIdx.x];
     float s = 0.f;
-    for (int i = threadIdx.x; i < ck.len; i += 256) { const float v = g[ck.off + i] * gscale; s = fmaf(v, v, s); }
+    const int n4 = ck.len >> 2;                                   // chunk offsets are multiples of 8 elements (FlatAdam): 16-byte lanes
+    const float4* g4 = reinterpret_cast<const float4*>(g + ck.off);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 t = g4[i];
+        const float a = t.x * gscale, b = t.y * gscale, c = t.z * gscale, d = t.w * gscale;
+        s = fmaf(a, a, s); s = fmaf(b, b, s); s = fmaf(c, c, s); s = fmaf(d, d, s);
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < ck.len; i += 256) { const float v = g[ck.off + i] * gscale; s = fmaf(v, v, s); }
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(norm2 + ck.tid, s);
 }
@@ -142,15 +149,30 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const Chunk ck = chunks[blockIdx.x];
     // torch.nn.utils.clip_grad_norm_ on ONE tensor: coef = max_norm / (norm + 1e-6), clamped to 1 (classify_mamba.py:106-107)
     const float coef = fminf(max_norm / (sqrtf(norm2[ck.tid]) + 1e-6f), 1.0f) * gscale;
-    for (int i = threadIdx.x; i < ck.len; i += 256) {
+    // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps); lr / bc1 and 1 / sqrt(bc2) come from the host in double
+    auto upd = [&](float gi, float& mi, float& vi, float& pi) {
+        gi *= coef;
+        mi = fmaf(b1, mi, (1.f - b1) * gi);
+        vi = fmaf(b2, vi, (1.f - b2) * gi * gi);
+        pi = pi - step_size * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
+    };
+    const int n4 = ck.len >> 2;                                   // 16-byte lanes: seven f32 streams and one bf16 stream at full width
+    const float4* g4 = reinterpret_cast<const float4*>(g + ck.off);
+    float4* m4 = reinterpret_cast<float4*>(m + ck.off);
+    float4* v4 = reinterpret_cast<float4*>(v + ck.off);
+    float4* p4 = reinterpret_cast<float4*>(p + ck.off);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 gv = g4[i];
+        float4 mv = m4[i], vv = v4[i], pv = p4[i];
+        upd(gv.x, mv.x, vv.x, pv.x); upd(gv.y, mv.y, vv.y, pv.y); upd(gv.z, mv.z, vv.z, pv.z); upd(gv.w, mv.w, vv.w, pv.w);
+        m4[i] = mv; v4[i] = vv; p4[i] = pv;
+        if (p16) reinterpret_cast<uint2*>(p16 + ck.off)[i] = make_uint2(pack_bf16x2(pv.x, pv.y), pack_bf16x2(pv.z, pv.w));
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < ck.len; i += 256) {
         const int64_t k = ck.off + i;
-        const float gi = g[k] * coef;
-        const float mi = fmaf(b1, m[k], (1.f - b1) * gi);
-        const float vi = fmaf(b2, v[k], (1.f - b2) * gi * gi);
-        m[k] = mi; v[k] = vi;
-        // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps); lr / bc1 and 1 / sqrt(bc2) come from the host in double
-        const float pn = p[k] - step_size * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
-        p[k] = pn;
+        float mi = m[k], vi = v[k], pn = p[k];
+        upd(g[k], mi, vi, pn);
+        m[k] = mi; v[k] = vi; p[k] = pn;
         if (p16) p16[k] = f32_to_bf16(pn);
     }
 }
