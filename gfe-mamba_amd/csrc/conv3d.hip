@@ -664,7 +664,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 __global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict__ w32, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, bf16_t* __restrict__ wout, float* __restrict__ T,
                                                          int nslab, int ntaps, int CoutPad, int Cin) {
-    // one thread per 8 consecutive k of one (slab, tap, row): coalesced 32-B reads / 16-B writes; T accumulated with atomics
+    // one thread per 8 consecutive k of one (slab, tap, row): coalesced 32-B reads / 16-B writes; T holds one partial per (sample, slab,
+    // tap, row), summed over the slabs in a fixed order by fold_bias_kernel: no atomics, no zero fill, bit-reproducible bias tables
     const int b = blockIdx.y;
     const int64_t nrows = (int64_t)nslab * ntaps * CoutPad;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (slab*ntaps*CoutPad + tap*CoutPad + row) * 4 + chunk
@@ -688,12 +689,12 @@ __global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict
         make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
     acc += __shfl_xor(acc, 1, 64);                                     // the 4 chunks of a row sit in adjacent lanes
     acc += __shfl_xor(acc, 2, 64);
-    if (chunk == 0) atomicAdd(T + (size_t)b * ntaps * CoutPad + tr, acc);
+    if (chunk == 0) T[((size_t)b * nslab + sl) * ntaps * CoutPad + tr] = acc;
 }
 
 // bias_tab[b][cls][channel] = sum over the taps that stay inside the volume for boundary class cls of T[b][tap][row(channel)]
 __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict__ T, float* __restrict__ tab, const int8_t* __restrict__ taps,
-                                                        int ntaps, int CoutPad, int NT) {
+                                                        int ntaps, int CoutPad, int NT, int nslab) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;            // cls * CoutPad + packed row
     if (i >= 64 * CoutPad) return;
@@ -703,7 +704,8 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
         const int dd = taps[3 * t], dh = taps[3 * t + 1], dw = taps[3 * t + 2];
         const bool outside = (dd < 0 && (cls & 1)) || (dd > 0 && (cls & 2)) || (dh < 0 && (cls & 4)) || (dh > 0 && (cls & 8)) ||
                              (dw < 0 && (cls & 16)) || (dw > 0 && (cls & 32));
-        if (!outside) acc += T[((size_t)b * ntaps + t) * CoutPad + rho];
+        if (!outside)
+            for (int sl = 0; sl < nslab; ++sl) acc += T[(((size_t)b * nslab + sl) * ntaps + t) * CoutPad + rho];
     }
     // packed row -> channel (same permutation as the weight packing)
     const int g = rho / (NT * 16), r = rho - g * (NT * 16);
@@ -766,11 +768,10 @@ int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, 
     const int cp = gfe_conv3d_cout_pad(Cout), nslab = (int)ceil_div(Cin, 32);
     const int NT = (cp < 64 ? cp : 64) / 16;
     hipStream_t st = (hipStream_t)stream;
-    gfe_zero_async(T_ws, (size_t)B * ntaps * cp * sizeof(float), st);
     hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)nslab * ntaps * cp * 4, 256), (unsigned)B), dim3(256), 0, st,
                        w_packed_f32, gn_scale, gn_shift, (bf16_t*)w_out, T_ws, nslab, ntaps, cp, (int)Cin);
     hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)64 * cp, 256), (unsigned)B), dim3(256), 0, st,
-                       T_ws, bias_tab, tap_offsets_dev, ntaps, cp, NT);
+                       T_ws, bias_tab, tap_offsets_dev, ntaps, cp, NT, nslab);
     return gfe_launch_status();
 }
 

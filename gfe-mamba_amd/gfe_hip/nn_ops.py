@@ -75,7 +75,7 @@ def fold_groupnorm(w_packed_f32, scale, shift, taps, cin, cout):
     cp = cout_pad(cout)
     dev = scale.device
     wout = torch.empty((B,) + tuple(w_packed_f32.shape), dtype=BF16, device=dev)
-    T = torch.empty((B, len(taps), cp), dtype=torch.float32, device=dev)
+    T = torch.empty((B, (cin + 31) // 32, len(taps), cp), dtype=torch.float32, device=dev)      # per-slab partials of the bias fold
     tab = torch.empty((B, 64, cp), dtype=torch.float32, device=dev)
     call("gfe_conv3d_fold_groupnorm", ptr(w_packed_f32), ptr(scale), ptr(shift), ptr(wout), ptr(T), ptr(tab),
          ptr(taps_on_device(taps, dev)), B, cin, cout, len(taps), stream())

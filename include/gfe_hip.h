@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 28
+#define GFE_ABI_VERSION 29
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -166,7 +166,8 @@ int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* c
  * (create_conv order 'g' before 'c', buildingblocks.py:55-67; zero padding is applied AFTER the norm):
  *   w_out[b] = bf16(w_packed_f32 * scale[b, cin])                              (B sets in the gfe_conv3d_igemm layout)
  *   bias_tab[b][class][co] = sum over taps inside the volume for that boundary class of sum_ci W[t][co][ci]*shift[b,ci]
- * w_packed_f32: the packed layout in f32.  T_ws: (B, ntaps, CoutPad) f32 workspace.  tap_offsets_dev: DEVICE int8 ntaps x 3. */
+ * w_packed_f32: the packed layout in f32.  T_ws: (B, ceil(Cin / 32), ntaps, CoutPad) f32 workspace (per-slab partials, summed in a fixed
+ * order: the tables are bit-reproducible).  tap_offsets_dev: DEVICE int8 ntaps x 3. */
 int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, const float* gn_shift, void* w_out, float* T_ws,
                               float* bias_tab, const int8_t* tap_offsets_dev, int64_t B, int64_t Cin, int64_t Cout, int ntaps, void* stream);
 

@@ -160,8 +160,11 @@ def _grad_and_update_errors(fx, names, params, opt):
             continue                                   # Adam normalises pure round-off there
         delta = opt.flat_p[int(o):int(o) + s] - before[int(o):int(o) + s]
         ref, gref = tt(fx["dslice." + k]), tt(fx["gslice." + k])
-        # Adam's first step is lr * g / (|g| + eps) ~ lr * sign(g): compare where the reference gradient is not round-off
-        m = gref.abs() > 0.02 * gref.abs().max()
+        # Adam's first step is lr * g / (|g| + eps): ~ lr * sign(g) where the clipped gradient is far above eps = 1e-8, but LINEAR in g
+        # where it is not (A_log: |g| ~ 1e-8), and there it only repeats the gradient comparison above with that element's own
+        # relative error.  Compare the update where the reference gradient is neither round-off nor in the linear regime.
+        coef = min(1.0, 1.0 / (float(fx["gnorm." + k]) + 1e-6))
+        m = (gref.abs() > 0.02 * gref.abs().max()) & (gref.abs() * coef > 1e-6)
         if m.any():
             e = ((_slices(delta, 64).double().cpu() - ref)[m].abs().max() / ref.abs().max()).item()
             if e > worst["dslice"][0]:
