@@ -22,6 +22,7 @@ struct GemmParams {
     int64_t lda, ldb, ldc, ldres;
     int M, N, K, ksplit;      // ksplit: K range per blockIdx.z (multiple of BK)
     int out_f32, res_f32, act, atomic;
+    float* part;              // split-K without atomics: range z stores its tile to part[z][M][N], summed in a fixed order afterwards
     int a_mode, b_mode;       // bit 0: f32 source (rounded to bf16 on load); bit 1: reduction-major source,
                               // element (row, k) at base[k * ld + row] (the operand of a dgrad / wgrad, no transpose pass)
 };
@@ -197,6 +198,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
             const int n = n0 + wn * 64 + j * 16 + lq * 4;
             if (n >= p.N) continue;                       // N % 4 == 0
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.atomic && p.part) {
+                *reinterpret_cast<float4*>(p.part + ((size_t)blockIdx.z * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                continue;
+            }
             if (p.atomic) {
                 float* c = (float*)p.C + (size_t)m * p.ldc + n;
                 if (p.bias && blockIdx.z == 0) {
@@ -295,16 +300,41 @@ int gemm_launch_b(const GemmParams& p, int nsplit, hipStream_t st) {
     }
 }
 
+// C[m][n] += bias[n] + part[0][m][n] + part[1][m][n] + ...  (fixed order: bit-reproducible, unlike the atomics it replaces)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias,
+                                                            int M, int N, int64_t ldc, int nsplit) {
+    const int n4 = N >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        float4 s = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < nsplit; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)z * M + m) * N + n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4* c = reinterpret_cast<float4*>(C + (size_t)m * ldc + n);
+        float4 o = *c;
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        *c = o;
+    }
+}
+
 int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
     int64_t ks = ceil_div(ceil_div((int64_t)p.K, split_k), BK) * BK;
     const int nsplit = (int)ceil_div((int64_t)p.K, ks);
     p.ksplit = (int)ks; p.atomic = nsplit > 1;
+    if (nsplit <= 1) p.part = nullptr;
+    if (p.part && (p.ldc & 3)) return GFE_ERR_SHAPE;          // the reduction reads / writes C 16 bytes at a time
+    int rc;
     switch (p.a_mode) {
-        case 0: return gemm_launch_b<0>(p, nsplit, st);
-        case 1: return gemm_launch_b<1>(p, nsplit, st);
-        case 2: return gemm_launch_b<2>(p, nsplit, st);
-        default: return gemm_launch_b<3>(p, nsplit, st);
+        case 0: rc = gemm_launch_b<0>(p, nsplit, st); break;
+        case 1: rc = gemm_launch_b<1>(p, nsplit, st); break;
+        case 2: rc = gemm_launch_b<2>(p, nsplit, st); break;
+        default: rc = gemm_launch_b<3>(p, nsplit, st); break;
     }
+    if (rc != GFE_OK || !p.part) return rc;
+    int64_t blocks = ceil_div((int64_t)p.M * (p.N >> 2), 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.part, (float*)p.C, p.bias, p.M, p.N, p.ldc, nsplit);
+    return gfe_launch_status();
 }
 
 }  // namespace
@@ -313,7 +343,7 @@ extern "C" {
 
 int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
-                     int act, int out_f32, int split_k, void* stream) {
+                     int act, int out_f32, int split_k, float* splitk_ws, void* stream) {
     GFE_REQUIRE(A && B && C, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(M <= 0x7fffffff && N <= 0x7fffffff && K <= 0x7fffffff, GFE_ERR_SHAPE);
@@ -322,13 +352,13 @@ int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.res = res;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
-    p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.a_mode = p.b_mode = 0;
+    p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.a_mode = p.b_mode = 0; p.part = splitk_ws;
     return gemm_dispatch(p, split_k, (hipStream_t)stream);
 }
 
 int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t ldb, int b_mode, void* C, int64_t ldc,
                 int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
-                int act, int out_f32, int split_k, void* stream) {
+                int act, int out_f32, int split_k, float* splitk_ws, void* stream) {
     GFE_REQUIRE(A && B && C, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(M <= 0x7fffffff && N <= 0x7fffffff && K <= 0x7fffffff, GFE_ERR_SHAPE);
@@ -341,7 +371,7 @@ int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t l
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.res = res;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
-    p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.a_mode = a_mode; p.b_mode = b_mode;
+    p.out_f32 = out_f32; p.res_f32 = res_f32; p.act = act; p.a_mode = a_mode; p.b_mode = b_mode; p.part = splitk_ws;
     return gemm_dispatch(p, split_k, (hipStream_t)stream);
 }
 

@@ -29,6 +29,7 @@ struct GemmF32Params {
     const float* A; const float* B; float* C; const float* bias;
     int64_t lda, ldb, ldc;
     int M, N, K, a_tr, b_tr, accumulate, a_vec, b_vec, ksplit;
+    float* part;             // split-K partials [range][M][N], or NULL (f32 atomics)
 };
 
 // E = T * BK / 256 elements of a T-row x BK-deep operand tile per thread (256 threads).  K-major source: row = t / (BK / E),
@@ -120,11 +121,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
                 if (m < p.M) {
                     float* c = p.C + (size_t)m * p.ldc + n;
                     const float v = acc[i][j][r] + bv;
-                    if (gridDim.z > 1) atomicAdd(c, v);          // C zeroed by the caller (or a gradient buffer being added to)
+                    if (gridDim.z > 1 && p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];   // summed in a fixed order afterwards
+                    else if (gridDim.z > 1) atomicAdd(c, v);     // C zeroed by the caller (or a gradient buffer being added to)
                     else *c = p.accumulate ? v + *c : v;
                 }
             }
         }
+}
+
+// C = (accumulate ? C : 0) + bias + part[0] + part[1] + ...: the split-K ranges in a fixed order (bit-reproducible)
+__global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias,
+                                                              int M, int N, int64_t ldc, int nsplit, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)M * N; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+        float s = bias ? bias[n] : 0.f;
+        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * M * N + i];
+        float* c = C + (size_t)m * ldc + n;
+        *c = accumulate ? *c + s : s;
+    }
 }
 
 }  // namespace
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 extern "C" {
 
 int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, float* C, int64_t ldc,
-                 int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, void* stream) {
+                 int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, float* splitk_ws, void* stream) {
     GFE_REQUIRE(A && B && C, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && K > 0 && M <= 0x7fffffff && N <= 0x7fffffff && K <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(ceil_div(M, 32) <= 65535 && split_k >= 1 && split_k <= 64, GFE_ERR_SHAPE);
@@ -144,11 +158,16 @@ int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t 
     p.b_vec = ((uintptr_t)B % 16 == 0) && ldb % 4 == 0;
     p.ksplit = (int)(ceil_div(ceil_div(K, split_k), 128) * 128);
     const unsigned nz = (unsigned)ceil_div(K, p.ksplit);
+    p.part = nz > 1 ? splitk_ws : nullptr;
     // 64 x 64 tiles only when they alone put >= 512 blocks on the chip; otherwise four times as many 32 x 32 blocks, a quarter of the MFMAs each
     if (ceil_div(M, 64) * ceil_div(N, 64) * nz >= 512)
         hipLaunchKernelGGL((gemm_f32_kernel<64, 32>), dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64), nz), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<32, 128>), dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), nz), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.part) {
+        int64_t blocks = ceil_div(M * N, 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p.part, C, bias, (int)M, (int)N, ldc, (int)nz, accumulate != 0);
+    }
     return gfe_launch_status();
 }
 

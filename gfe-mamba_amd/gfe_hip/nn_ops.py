@@ -336,7 +336,7 @@ def fold_mid(x, md1=8, inverse=False, shape=None):
 
 # ---- GEMM / ViT ops ---------------------------------------------------------------------------------------------------
 def _auto_split_k(M, N, K):
-    """few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (f32 atomics)"""
+    """few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (partials + a fixed-order sum)"""
     bm = 64 if (M <= 64 or (M % 128 != 0 and M % 128 <= 64 and M < 1024)) else 128
     blocks = -(-M // bm) * -(-N // 128)
     return max(1, min(K // 256, 256 // blocks)) if blocks < 128 else 1
@@ -353,8 +353,16 @@ def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=Non
         out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
     call("gfe_gemm_bf16_nt", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),
          ptr(res), 0 if res is None else res.stride(0), int(res is not None and res.dtype == torch.float32),
-         act, int(out.dtype == torch.float32), split_k, stream())
+         act, int(out.dtype == torch.float32), split_k, ptr(_splitk_ws(split_k, M, N, out)), stream())
     return out
+
+
+def _splitk_ws(split_k, M, N, out):
+    """Workspace of the deterministic split-K (range partials, summed in a fixed order): bit-reproducible results where f32 atomics
+    differ from run to run.  None for a single range, or where the row stride of C rules out the 16-byte reduction."""
+    if split_k <= 1 or out.stride(0) % 4:
+        return None
+    return torch.empty(split_k * M * N, dtype=torch.float32, device=out.device)
 
 
 def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1, accum_into=None):
@@ -376,7 +384,8 @@ def gemm_ex(a, a_t, b, b_t, bias=None, out_dtype=torch.float32, split_k=1, accum
     else:
         out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
     call("gfe_gemm_ex", ptr(a), a.stride(0), mode(a, a_t), ptr(b), b.stride(0), mode(b, b_t), ptr(out), out.stride(0), M, N, K,
-         ptr(bias), ptr(res), 0 if res is None else res.stride(0), int(res is not None), 0, int(out.dtype == torch.float32), split_k, stream())
+         ptr(bias), ptr(res), 0 if res is None else res.stride(0), int(res is not None), 0, int(out.dtype == torch.float32), split_k,
+         ptr(_splitk_ws(split_k, M, N, out)), stream())
     return out
 
 
@@ -391,17 +400,18 @@ def gemm_f32(a, a_t, b, b_t, bias=None, accum_into=None):
     assert (b.shape[0] if b_t else b.shape[1]) == K and unit(a) and unit(b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32
     # launch-bound sizes: the kernel uses 32 x 32 x 128 tiles below 512 blocks of 64 x 64; a block's time is its number of 128-deep
-    # k-steps (one exposed memory round trip + 32 f32 MFMAs each), so K is split -- f32 atomics -- until ~1024 blocks are in flight,
-    # keeping >= 2 k-steps per block and the atomic traffic (output bytes x splits at ~1.3 TB/s) below ~8 MB
+    # k-steps (one exposed memory round trip + 32 f32 MFMAs each), so K is split -- range partials + a fixed-order sum, bit-reproducible --
+    # until ~1024 blocks are in flight, keeping >= 2 k-steps per block and the partial traffic (output bytes x splits) below ~8 MB
     blocks32 = -(-M // 32) * -(-N // 32)
     split_k = max(1, min(8, K // 256, 1024 // blocks32, (8 << 20) // max(1, 4 * M * N)))
     if accum_into is not None:
         assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and unit(accum_into) and bias is None
         out = accum_into
     else:
-        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=torch.float32, device=a.device)
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ws = torch.empty(split_k * M * N, dtype=torch.float32, device=a.device) if split_k > 1 else None
     call("gfe_gemm_f32", ptr(a), ld(a), int(a_t), ptr(b), ld(b), int(b_t), ptr(out), ld(out), M, N, K,
-         ptr(bias), int(accum_into is not None), split_k, stream())
+         ptr(bias), int(accum_into is not None), split_k, ptr(ws), stream())
     return out
 
 

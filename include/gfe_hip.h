@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 29
+#define GFE_ABI_VERSION 30
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -208,10 +208,12 @@ int gfe_fold_mid(const void* src, void* dst, int64_t B, int64_t D, int64_t H, in
 /* C[M][N] = act(A[M][K] . B[N][K]^T + bias) + res   -- y = x W^T + b with W stored (N, K) like nn.Linear.weight.
  *   A, B bf16 (lda, ldb in elements, multiples of 8; K % 8 == 0, N % 4 == 0).  bias (N) f32 or NULL.
  *   res: (M, ldres) bf16|f32 or NULL.  act: 0 none, 1 exact-erf GELU.  C: bf16 or f32 (out_f32).
- *   split_k > 1: K is cut into split_k ranges accumulated with f32 atomics into a ZEROED f32 C (no act/res). */
+ *   split_k > 1: K is cut into split_k ranges that are ADDED into an f32 C the caller initialised (zeros, or an accumulation target;
+ *   no act/res): with splitk_ws (split_k * M * N floats, ldc % 4 == 0) every range stores its tile there and a second launch sums the
+ *   ranges in a fixed order (bit-reproducible); with splitk_ws == NULL the ranges add with f32 atomics. */
 int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
-                     int act, int out_f32, int split_k, void* stream);
+                     int act, int out_f32, int split_k, float* splitk_ws, void* stream);
 
 /* The same GEMM with per-operand source modes, so that the backward of a Linear needs no cast / transpose pass:
  *   mode bit 0: the operand is f32 in memory (rounded to bf16 while it is staged; ld % 4 == 0 instead of % 8);
@@ -222,17 +224,19 @@ int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
  * K % 8 == 0 unless both operands are reduction-major.  Everything else as gfe_gemm_bf16_nt. */
 int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t ldb, int b_mode, void* C, int64_t ldc,
                 int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
-                int act, int out_f32, int split_k, void* stream);
+                int act, int out_f32, int split_k, float* splitk_ws, void* stream);
 
 /* Exact-f32 GEMM on the f32 matrix cores for the trainable head's small Linears (the reference trains the head in fp32:
  * classify_mamba.py:69-74; Mamba projections mamba.py:204, 235-238, 223; q / out projections sd_cross_atten.py:42-45; GEGLU FF
  * corss_ft_transformer.py:15-22; logits mamba_transformer.py:79-82).
  *   C[M][N] (+)= op(A)[M][K] op(B)[N][K]^T (+ bias[n]), all f32, any sizes / alignments.
  *   a_tr / b_tr != 0: the operand is stored reduction-major, element (row, k) at base[k * ld + row].
- *   accumulate != 0: add to C (a gradient buffer).  split_k > 1: K ranges are added with f32 atomics -- C must be zeroed, or be the
- *   buffer that is accumulated into. */
+ *   accumulate != 0: add to C (a gradient buffer).  split_k > 1 with splitk_ws (split_k * M * N floats): every K range stores its
+ *   tile there and a second launch writes C = (accumulate ? C : 0) + bias + the ranges in a fixed order (bit-reproducible; C needs no
+ *   zero fill).  split_k > 1 with splitk_ws == NULL: the ranges are added with f32 atomics -- C must be zeroed, or be the buffer that
+ *   is accumulated into. */
 int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, float* C, int64_t ldc,
-                 int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, void* stream);
+                 int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, float* splitk_ws, void* stream);
 
 /* out[b][c][r] = in[b][r][c], bf16 (operand re-layout for dgrad / wgrad). */
 int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream);

@@ -329,8 +329,9 @@ for graphed in (False, True):
 assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-4, (l0, l1)
 assert (p0 - p1).abs().max().item() < 2e-4           # 3 Adam steps of 1e-4 each: identical up to atomics-order noise
 print("GRAPHED_STEP_OK")
-# full size (96^3, 64/128/256 channels, B = 1): the captured generator must keep reproducing the eager outputs (the memset-node bug
-# returned garbage from the second replay on); the residual differences are the f32-atomics order of the split-K GEMMs / bias tables
+# full size (96^3, 64/128/256 channels, B = 1): the captured generator must keep reproducing the eager outputs BIT FOR BIT (the
+# memset-node bug returned garbage from the second replay on; the frozen generator has no atomics left: fixed-order bias-table fold
+# and split-K sums)
 gen, head, ft = build_models()
 xf = det.det_inputs(1, (96, 96, 96), seed=5)[0].cuda()
 with torch.no_grad():
@@ -345,8 +346,7 @@ with torch.no_grad():
     for i in range(4):
         g.replay(); torch.cuda.synchronize()
         for name, a, b in zip(("mid_input", "mid_output", "pet"), res, ref):
-            err = ((a.float() - b.float()).abs().max() / b.float().abs().max()).item()
-            assert err < 2e-2, (i, name, err)
+            assert torch.equal(a, b), (i, name, int((a != b).sum()))
 print("GRAPHED_FULL_OK")
 """
 
