@@ -300,9 +300,12 @@ int gemm_launch_b(const GemmParams& p, int nsplit, hipStream_t st) {
     }
 }
 
-// C[m][n] += bias[n] + part[0][m][n] + part[1][m][n] + ...  (fixed order: bit-reproducible, unlike the atomics it replaces)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias,
-                                                            int M, int N, int64_t ldc, int nsplit) {
+// The split-K ranges summed in a fixed order (bit-reproducible, unlike the atomics it replaces), then the GEMM's epilogue:
+//   plain f32 product (no act / res): C[m][n] += bias[n] + sum   (C was initialised by the caller: zeros or an accumulation target)
+//   otherwise:                        C[m][n] = act(bias[n] + sum) + res[m][n], stored as f32 or bf16
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, void* __restrict__ Cv, const float* __restrict__ bias,
+                                                            const void* __restrict__ res, int M, int N, int64_t ldc, int64_t ldres, int nsplit,
+                                                            int out_f32, int res_f32, int act, int overwrite) {
     const int n4 = N >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
@@ -311,10 +314,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)z * M + m) * N + n);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        float4* c = reinterpret_cast<float4*>(C + (size_t)m * ldc + n);
-        float4 o = *c;
-        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-        *c = o;
+        if (!overwrite) {
+            float4* c = reinterpret_cast<float4*>((float*)Cv + (size_t)m * ldc + n);
+            float4 o = *c;
+            o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+            *c = o;
+            continue;
+        }
+        if (act == 1) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
+        if (res) {
+            if (res_f32) {
+                const float4 rv = *reinterpret_cast<const float4*>((const float*)res + (size_t)m * ldres + n);
+                s.x += rv.x; s.y += rv.y; s.z += rv.z; s.w += rv.w;
+            } else {
+                const uint2 rv = *reinterpret_cast<const uint2*>((const bf16_t*)res + (size_t)m * ldres + n);
+                s.x += bf16lo_to_f32(rv.x); s.y += bf16hi_to_f32(rv.x); s.z += bf16lo_to_f32(rv.y); s.w += bf16hi_to_f32(rv.y);
+            }
+        }
+        if (out_f32) *reinterpret_cast<float4*>((float*)Cv + (size_t)m * ldc + n) = s;
+        else *reinterpret_cast<uint2*>((bf16_t*)Cv + (size_t)m * ldc + n) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
     }
 }
 
@@ -333,7 +351,9 @@ int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
     }
     if (rc != GFE_OK || !p.part) return rc;
     int64_t blocks = ceil_div((int64_t)p.M * (p.N >> 2), 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.part, (float*)p.C, p.bias, p.M, p.N, p.ldc, nsplit);
+    const int overwrite = (p.act != 0 || p.res != nullptr || !p.out_f32) ? 1 : 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.part, p.C, p.bias, p.res, p.M, p.N, p.ldc, p.ldres, nsplit,
+                       p.out_f32, p.res_f32, p.act, overwrite);
     return gfe_launch_status();
 }
 
@@ -347,7 +367,7 @@ int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
     GFE_REQUIRE(A && B && C, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(M <= 0x7fffffff && N <= 0x7fffffff && K <= 0x7fffffff, GFE_ERR_SHAPE);
-    GFE_REQUIRE(split_k >= 1 && (split_k == 1 || (out_f32 && !res && act == 0)), GFE_ERR_SHAPE);
+    GFE_REQUIRE(split_k >= 1 && (split_k == 1 || splitk_ws || (out_f32 && !res && act == 0)), GFE_ERR_SHAPE);
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.res = res;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
@@ -366,7 +386,7 @@ int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t l
     // 16-byte vector loads: ld a multiple of 8 (bf16) / 4 (f32); a K-major operand also needs K % 8 == 0
     GFE_REQUIRE(lda % ((a_mode & 1) ? 4 : 8) == 0 && ldb % ((b_mode & 1) ? 4 : 8) == 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(((a_mode & 2) && (b_mode & 2)) || K % 8 == 0, GFE_ERR_SHAPE);
-    GFE_REQUIRE(split_k >= 1 && (split_k == 1 || (out_f32 && !res && act == 0)), GFE_ERR_SHAPE);
+    GFE_REQUIRE(split_k >= 1 && (split_k == 1 || splitk_ws || (out_f32 && !res && act == 0)), GFE_ERR_SHAPE);
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.res = res;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;

@@ -4,6 +4,7 @@ Pure plumbing: shape checks, output allocation (torch caching allocator), raw po
 Activations of the generator are channels-last bf16: (B, D, H, W, C).
 """
 import ctypes
+import os
 import itertools
 
 import numpy as np
@@ -339,7 +340,7 @@ def _auto_split_k(M, N, K):
     """few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (partials + a fixed-order sum)"""
     bm = 64 if (M <= 64 or (M % 128 != 0 and M % 128 <= 64 and M < 1024)) else 128
     blocks = -(-M // bm) * -(-N // 128)
-    return max(1, min(K // 256, 256 // blocks)) if blocks < 128 else 1
+    return max(1, min(K // 128, 256 // blocks)) if blocks < 128 else 1
 
 
 def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=None):
@@ -347,10 +348,16 @@ def gemm_nt(a, b, bias=None, res=None, act=0, out_dtype=BF16, split_k=1, out=Non
     M, K = a.shape
     N = b.shape[0]
     assert a.dtype == BF16 and b.dtype == BF16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
-    if split_k == 1 and out is None and out_dtype == torch.float32 and res is None and act == 0 and K >= 1024:
+    plain = out_dtype == torch.float32 and res is None and act == 0
+    if split_k == 1 and out is None and K >= (1024 if plain else 256) and (plain or os.environ.get("GFE_GEMM_EPI_SPLIT", "0") == "1"):
+        # plain f32 products are cut along K automatically.  GEMMs with an epilogue (bias, GELU, residual, bf16 out) can be cut too -- the
+        # epilogue then runs in the fixed-order reduction over the ranges' tiles -- but for the ViT's M = 256-row GEMMs that measured no
+        # gain in the step (704.9 vs 704.6 volumes/s), so it is opt-in (GFE_GEMM_EPI_SPLIT=1)
         split_k = _auto_split_k(M, N, K)
+        if not plain and (N % 4 or split_k * M * N * 4 > (64 << 20)):
+            split_k = 1
     if out is None:
-        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=out_dtype, device=a.device)
+        out = (torch.zeros if split_k > 1 and plain else torch.empty)((M, N), dtype=out_dtype, device=a.device)
     call("gfe_gemm_bf16_nt", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),
          ptr(res), 0 if res is None else res.stride(0), int(res is not None and res.dtype == torch.float32),
          act, int(out.dtype == torch.float32), split_k, ptr(_splitk_ws(split_k, M, N, out)), stream())
