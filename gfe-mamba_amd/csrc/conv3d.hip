@@ -277,6 +277,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         for (int i = 0; i < NSTAT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
     }
 
+#if !defined(GFE_EXP_NO_APRIO)
+    // Static issue priority for the younger half of the block (waves 4-7, here also the activation-DMA waves): between the two waves of a
+    // SIMD the older one wins every arbitration, so the younger half trails into each stage barrier (MI355X_MICROARCH.md, "Static priority
+    // for the younger half").  One s_setprio for the whole kernel, no per-stage flips: 64->64 @96^3 1.485-1.493 -> 1.473 ms, 128->128 @48^3
+    // 0.746 -> 0.731, the step 702-708 -> 713-715 volumes/s (same box, alternating runs).  Priority for the weight waves instead: slower (1.50).
+    if (a_wave) __builtin_amdgcn_s_setprio(1);
+#endif
+#if defined(GFE_EXP_WPRIO)     // ... or for the older half (the weight-DMA waves, whose pieces every stage barrier waits for)
+    if (!a_wave) __builtin_amdgcn_s_setprio(GFE_EXP_WPRIO);
+#endif
     if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur, 0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
