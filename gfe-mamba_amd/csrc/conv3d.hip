@@ -323,6 +323,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #endif
             GFE_STAMP(2);
             // refill the buffers nobody reads any more: next stage's weights, and (once per unit) the next unit's tile
+            auto issue_dma = [&]() {
 #if !defined(GFE_EXP_NOW)      // timing experiment only: weights are never restaged
             if (!a_wave) {
                 if (s + 1 < nstage) w_dma(cur, group, slab, s + 1, (gstage + 1) & 1);
@@ -336,6 +337,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // (2.11: the 64 misses then sit in front of the next stages' weight pieces in the CU's in-order vector-memory path)
             if constexpr (A_BUFS == 2) { if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE); }
 #endif
+            };
+            // 27-tap path: the first tap's fragment reads go out BEFORE the DMA instructions, so their LDS round trip runs under the 3 (weight
+            // waves) / 16 (activation waves, stage 0) DMA issues instead of in front of the first MFMA: 1.449-1.456 -> 1.427-1.439 ms
+#if defined(GFE_EXP_DMA_FIRST)
+            constexpr bool DMA_LATE = false;
+#else
+            constexpr bool DMA_LATE = REG27;
+#endif
+            if constexpr (!DMA_LATE) issue_dma();
 
             GFE_STAMP(3);
             const uint8_t* wb = sW + (gstage & 1) * (W_PIECES * 1024) + wbase;
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #else
                 if constexpr (PIPE) { frag_load(0, 0); __builtin_amdgcn_sched_barrier(0); }
 #endif
+                if constexpr (DMA_LATE) { issue_dma(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     const int set = PIPE ? (tl & 1) : 0;
