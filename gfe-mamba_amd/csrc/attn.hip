@@ -114,9 +114,6 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
-#if !defined(GFE_ATTN_EXP_NODMA)     // timing experiment only: K/V tiles are never restaged
-        if (t + RING - 1 < ntile) dma(t + RING - 1, (t + RING - 1) % RING);   // lands under the next tiles' MFMAs; nobody reads that buffer any more
-#endif
         const uint8_t* sk = smem + (t % RING) * TILE_BYTES;
         const uint8_t* sv = smem + (RING + (t % RING)) * TILE_BYTES;
         const bool ragged = t == ntile - 1 && (p.n & (KT - 1));
@@ -130,6 +127,11 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
             bf16x8 kf[4];
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) kf[ds] = *reinterpret_cast<const bf16x8*>(sk + k_off(32 * kb2 + ql, 2 * ds + hi));
+#if !defined(GFE_ATTN_EXP_NODMA)     // NODMA: timing experiment only, K/V tiles are never restaged
+            // the next tile's DMA instructions go out behind the first K fragment reads (nobody reads that ring slot any more); it lands
+            // under the next tiles' MFMAs
+            if (kb2 == 0 && t + RING - 1 < ntile) dma(t + RING - 1, (t + RING - 1) % RING);
+#endif
 #if defined(GFE_ATTN_PRIO)
             __builtin_amdgcn_s_setprio(1);
 #endif
