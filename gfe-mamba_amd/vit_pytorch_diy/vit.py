@@ -5,6 +5,8 @@ cls_token, transformer.layers.{l}.{0,1}..., transformer.norm).  torch layers onl
 kernels on a channels-last bf16 image (B, H, W, C) and returns the same layout.  Eval-mode semantics (dropouts are
 identities): the ViT only lives inside the frozen generator.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -106,10 +108,11 @@ class ViT(nn.Module):
         # to_patch_embedding: patchify + LN(patch_dim) -> Linear -> LN(dim)   (vit.py:95-100)
         tok = K.layernorm(img, *w["ln_p"], rows=B * n, length=pd, out_dtype=BF16, in_map=pm)
         # weight-streaming GEMM (K = patch_dim = 147,456 at 96^3): 128-row tiles when there are more than 64 rows (gemm.hip), and
-        # ~192 blocks in all -- more K-splits only add f32 atomics (measured at B=8: 24 splits 113 us, 64 splits 170 us)
+        # ~384 blocks in all (with the ranges' tiles in a workspace and a fixed-order sum instead of f32 atomics; GEMM + reduction at B=8:
+        # 24 splits 119 + 9 us, 48 splits 85 + 16 us, 64 splits 90 + 19 us)
         rows = B * n
         mblk, nblk = (1 if rows <= 64 else -(-rows // 128)), -(-dim // 128)
-        split = max(1, min(pd // 512, -(-192 // (mblk * nblk))))
+        split = max(1, min(pd // 512, -(-int(os.environ.get("GFE_VIT_EMBED_BLOCKS", "384")) // (mblk * nblk))))
         emb = K.gemm_nt(tok, w["w_embed"], bias=w["b_embed"], out_dtype=torch.float32, split_k=split)
         emb = K.layernorm(emb, *w["ln_e"], rows=B * n, length=dim, out_dtype=torch.float32)
         x = K.vit_embed(emb, w["cls"], w["pos"], B, n, dim).view(B * (n + 1), dim)          # vit.py:127-130
