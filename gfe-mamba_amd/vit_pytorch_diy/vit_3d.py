@@ -47,7 +47,7 @@ class ViT(nn.Module):
 
     def _weights(self):
         params = list(self.parameters())
-        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        sig = tuple((p.data_ptr(), p._version, str(p.device), getattr(p, "_gfe_epoch", (0,))[0]) for p in params)   # FlatAdam rewrites storage without a version bump
         if sig != self._sig:
             with torch.no_grad():
                 f = lambda p: p.detach().float().contiguous()
