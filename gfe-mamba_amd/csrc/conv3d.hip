@@ -95,6 +95,7 @@ constexpr unsigned OOB = 0x80000000u;          // buffer offset beyond num_recor
 struct ConvParams {
     const bf16_t* x; const bf16_t* w; const float* bias; const float* bias_tab; const bf16_t* res; bf16_t* y;
     const float* res1_x; const float* res1_w; const float* res1_b;   // residual computed on the fly from a one-channel volume: w[c] * x + b[c]
+    bf16_t* pool_y;                                                    // RES1 only: also write MaxPool3d(2) of the (ReLU'd) result, (B, D/2, H/2, W/2, Cout)
     const float* out1_w; float out1_b; float* out1_y;                  // OUT1: a 1x1x1 conv Cout -> 1 of the result instead of storing the result
     long long w_batch_stride;                  // elements between per-sample weight sets (0: shared)
     int B, D, H, W, Cin, Cout, CoutPad;
@@ -456,6 +457,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // across the block's tiles and are reduced / stored only when the (sample, channel group) changes or the block ends.
             // 64-channel single-class launches are always stride-1 convs (the host sends anything else to the multi-class variant)
             constexpr bool FAST_OK = !MC && (!STATS || OCT) && NT == 4;
+            // Fused MaxPool3d(2) of the result (the encoder's pooling, buildingblocks.py:284, of the first block: saves re-reading the
+            // 906 MB tensor).  w and h neighbours of a voxel are lanes lane^1 / lane^8 of the same wave (DPP), the d neighbour is the wave
+            // next door: the 2x2 maxima go through the tile buffer this unit has just finished with (the next unit's tile lands in the
+            // other one), wave pairs meet there behind a barrier, the even wave writes the 4x4x(its plane pair) pooled voxels as whole
+            // 128-byte rows.  ReLU'd bf16 values are non-negative, so the maximum is v_pk_max_i16 on the packed words.
+            uint8_t* pool_scr = smem + (A_BUFS == 2 ? (u & 1) * A_BYTES : 0);
+            bool pooling = false;
+            if constexpr (RES1 && FAST_OK) {
+                pooling = p.pool_y != nullptr;                                  // block-uniform
+                if (pooling) {                                                   // every wave has read its last fragments of this tile
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
             if constexpr (FAST_OK) {
               if (cd < p.D && c0 < p.Cout) {
                 // ---- the common case (stride-1 conv, one destination per voxel): a 64-bit scalar tile base + 32-bit lane offsets, no
@@ -504,6 +520,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         }
                     }
                     float o1 = 0.f;
+                    uint32_t pq[8];                                               // RES1 pooling: the voxel's 16 packed channels
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const uint32_t rw[4] = {rv[h].x, rv[h].y, rv[h].z, rv[h].w};
@@ -540,6 +557,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                             o1 = fmaf(bf16lo_to_f32(pk[3]), wb.z, o1); o1 = fmaf(bf16hi_to_f32(pk[3]), wb.w, o1);
                         } else {
                             reinterpret_cast<uint4*>(y_t + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        }
+                        if constexpr (RES1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pq[4 * h + j] = pk[j];
+                        }
+                    }
+                    if constexpr (RES1) {
+                        if (pooling) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const uint32_t wn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pq[k], 0xb1, 0xf, 0xf, true);     // lane ^ 1: w neighbour
+                                pq[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pq[k]), __builtin_bit_cast(s16x2, wn)));
+                                const uint32_t hn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pq[k], 0x128, 0xf, 0xf, true);    // lane ^ 8: h neighbour
+                                pq[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pq[k]), __builtin_bit_cast(s16x2, hn)));
+                            }
+                            if ((lr & 9) == 0) {                                  // even w, even h: [wave][xt][w / 2][lq] x 32 B
+                                uint4* dst = reinterpret_cast<uint4*>(pool_scr + ((((wave * 4 + xt) * 4 + (lr >> 1)) * 4 + lq) << 5));
+                                dst[0] = make_uint4(pq[0], pq[1], pq[2], pq[3]); dst[1] = make_uint4(pq[4], pq[5], pq[6], pq[7]);
+                            }
                         }
                     }
                     if constexpr (OUT1) {
@@ -631,6 +667,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                                     else *reinterpret_cast<uint2*>(p.y + o) = make_uint2(pk[0], pk[1]);
                                 }
                             }
+                }
+            }
+            if constexpr (RES1 && FAST_OK) {
+                if (pooling) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (!(wave & 1)) {                                           // lane -> (h pair xt, w pair, channel quad) of plane pair wave / 2
+                        const int xt = lane >> 4, wq = (lane >> 2) & 3, q4 = lane & 3;
+                        const uint4* a = reinterpret_cast<const uint4*>(pool_scr + ((((wave * 4 + xt) * 4 + wq) * 4 + q4) << 5));
+                        const uint4* c = reinterpret_cast<const uint4*>(pool_scr + (((((wave + 1) * 4 + xt) * 4 + wq) * 4 + q4) << 5));
+                        const uint4 a0 = a[0], a1 = a[1], c0_ = c[0], c1_ = c[1];
+                        auto mx = [](uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, y))); };
+                        const int pd_ = (d0 >> 1) + (wave >> 1), ph_ = (h0 >> 1) + xt, pw_ = (w0 >> 1) + wq;
+                        if (pd_ < (p.D >> 1) && ph_ < (p.H >> 1) && pw_ < (p.W >> 1)) {
+                            uint4* dst = reinterpret_cast<uint4*>(p.pool_y + ((((size_t)b * (p.D >> 1) + pd_) * (p.H >> 1) + ph_) * (p.W >> 1) + pw_) * p.Cout + q4 * 16);
+                            dst[0] = make_uint4(mx(a0.x, c0_.x), mx(a0.y, c0_.y), mx(a0.z, c0_.z), mx(a0.w, c0_.w));
+                            dst[1] = make_uint4(mx(a1.x, c1_.x), mx(a1.y, c1_.y), mx(a1.z, c1_.z), mx(a1.w, c1_.w));
+                        }
+                    }
                 }
             }
             if constexpr (STATS) {
@@ -818,7 +874,7 @@ static int conv_igemm_impl(const void* x, const void* w_packed, int64_t w_batch_
                            int ostride, int op_d, int op_h, int op_w, int oshift, int relu,
                            float* stats_ws, int64_t stats_nblk, int64_t stats_slot0,
                            const float* res1_x, const float* res1_w, const float* res1_b,
-                           const float* out1_w, float out1_b, float* out1_y, void* stream) {
+                           const float* out1_w, float out1_b, float* out1_y, void* pool_y, void* stream) {
     GFE_REQUIRE(x && w_packed && (y || out1_y) && tap_offsets, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
@@ -828,7 +884,7 @@ static int conv_igemm_impl(const void* x, const void* w_packed, int64_t w_batch_
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = bias; p.bias_tab = bias_tab;
     p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = w_batch_stride;
     p.res1_x = res1_x; p.res1_w = res1_w; p.res1_b = res1_b;
-    p.out1_w = out1_w; p.out1_b = out1_b; p.out1_y = out1_y;
+    p.out1_w = out1_w; p.out1_b = out1_b; p.out1_y = out1_y; p.pool_y = (bf16_t*)pool_y;
     p.B = (int)B; p.D = (int)D; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.CoutPad = gfe_conv3d_cout_pad(Cout);
     p.OD = (int)OD; p.OH = (int)OH; p.OW = (int)OW;
@@ -892,6 +948,7 @@ static int conv_igemm_impl(const void* x, const void* w_packed, int64_t w_batch_
     if (res1_x) {
         // residual from a one-channel volume: only the plain 27-tap 64-channel variant carries that epilogue
         GFE_REQUIRE(res1_w && res1_b && !res && reg27 && NT == 4 && Cout == 64, GFE_ERR_SHAPE);
+        GFE_REQUIRE(!pool_y || (relu && D % 2 == 0 && H % 2 == 0 && W % 2 == 0), GFE_ERR_SHAPE);      // pooled maxima are taken on ReLU'd (non-negative) bf16 bits
         return conv_launch<4, 3, true, false, false, true>(p, st);
     }
     return reg27 ? conv_launch<4, 3, true, false>(p, st) : conv_launch<4, 3, false, false>(p, st);
@@ -905,15 +962,15 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
                      int ostride, int op_d, int op_h, int op_w, int oshift, int relu,
                      float* stats_ws, int64_t stats_nblk, int64_t stats_slot0, void* stream) {
     return conv_igemm_impl(x, w_packed, w_batch_stride, bias, bias_tab, res, y, B, D, H, W, Cin, Cout, OD, OH, OW, ntaps, tap_offsets,
-                           ostride, op_d, op_h, op_w, oshift, relu, stats_ws, stats_nblk, stats_slot0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, stream);
+                           ostride, op_d, op_h, op_w, oshift, relu, stats_ws, stats_nblk, stats_slot0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, stream);
 }
 
 int gfe_conv3d_k3_lift_residual(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, void* y,
                                 int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, const int8_t* tap_offsets, int relu,
-                                const float* vol, const float* lift_w, const float* lift_b, void* stream) {
+                                const float* vol, const float* lift_w, const float* lift_b, void* pool_out, void* stream) {
     GFE_REQUIRE(vol && lift_w && lift_b, GFE_ERR_NULL);
     return conv_igemm_impl(x, w_packed, w_batch_stride, nullptr, bias_tab, nullptr, y, B, D, H, W, Cin, Cout, D, H, W, 27, tap_offsets,
-                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, vol, lift_w, lift_b, nullptr, 0.f, nullptr, stream);
+                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, vol, lift_w, lift_b, nullptr, 0.f, nullptr, pool_out, stream);
 }
 
 int gfe_conv3d_k3_out1(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, const void* res,
@@ -921,7 +978,7 @@ int gfe_conv3d_k3_out1(const void* x, const void* w_packed, int64_t w_batch_stri
                        const float* out_w, float out_b, float* out_y, void* stream) {
     GFE_REQUIRE(out_w && out_y, GFE_ERR_NULL);
     return conv_igemm_impl(x, w_packed, w_batch_stride, nullptr, bias_tab, res, nullptr, B, D, H, W, Cin, Cout, D, H, W, 27, tap_offsets,
-                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, nullptr, nullptr, nullptr, out_w, out_b, out_y, stream);
+                           1, 0, 0, 0, 0, relu, nullptr, 0, 0, nullptr, nullptr, nullptr, out_w, out_b, out_y, nullptr, stream);
 }
 
 int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* cls_woff, const int* cls_ntaps, const int8_t* cls_parity,
@@ -963,7 +1020,7 @@ int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* c
     ConvParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.bias = nullptr; p.bias_tab = nullptr;
     p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.w_batch_stride = 0;
-    p.res1_x = nullptr; p.res1_w = nullptr; p.res1_b = nullptr; p.out1_w = nullptr; p.out1_b = 0.f; p.out1_y = nullptr;
+    p.res1_x = nullptr; p.res1_w = nullptr; p.res1_b = nullptr; p.out1_w = nullptr; p.out1_b = 0.f; p.out1_y = nullptr; p.pool_y = nullptr;
     p.B = (int)B; p.D = (int)D; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Cout = (int)Cout;
     p.CoutPad = gfe_conv3d_cout_pad(Cout);
     p.OD = (int)OD; p.OH = (int)OH; p.OW = (int)OW;

@@ -256,15 +256,20 @@ def lift_groupnorm_affine(x, w1, b1, gamma, beta, groups, eps=1e-5):
     return ss[0], ss[1]
 
 
-def conv3_lift_residual(x, w_packed, tab, cout, vol, lift_w, lift_b, relu=True):
+def conv3_lift_residual(x, w_packed, tab, cout, vol, lift_w, lift_b, relu=True, pool=True):
     """27-tap conv of x (B, D, H, W, Cin) bf16 with per-sample folded weights + bias table, plus the residual w[c] * vol + b[c]
-    recomputed in the epilogue from the one-channel volume (gfe_conv3d_k3_lift_residual)."""
+    recomputed in the epilogue from the one-channel volume (gfe_conv3d_k3_lift_residual).  pool: the epilogue also writes
+    MaxPool3d(2) of the result (attached as `out.pooled2`; the next Encoder takes it instead of re-reading the tensor)."""
     B, D, H, W, cin = x.shape
     assert x.dtype == BF16 and x.is_contiguous() and vol.dtype == torch.float32 and vol.is_contiguous() and w_packed.dim() == 5
     out = torch.empty((B, D, H, W, cout), dtype=BF16, device=x.device)
+    pool = pool and relu and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and os.environ.get("GFE_NO_FUSED_POOL") != "1"
+    pooled = torch.empty((B, D // 2, H // 2, W // 2, cout), dtype=BF16, device=x.device) if pool else None
     _, tptr = _i8(CONV3_TAPS)
     call("gfe_conv3d_k3_lift_residual", ptr(x), ptr(w_packed), w_packed.stride(0), ptr(tab), ptr(out), B, D, H, W, cin, cout, tptr, int(relu),
-         ptr(vol), ptr(lift_w), ptr(lift_b), stream())
+         ptr(vol), ptr(lift_w), ptr(lift_b), ptr(pooled), stream())
+    if pooled is not None:
+        out.pooled2 = pooled
     return out
 
 

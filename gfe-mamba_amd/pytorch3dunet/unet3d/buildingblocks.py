@@ -168,7 +168,8 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         if self.pooling is not None:
-            x = K.maxpool2(x)
+            pooled = getattr(x, "pooled2", None)          # the producing conv already pooled its result in the epilogue (first block)
+            x = pooled if pooled is not None else K.maxpool2(x)
         return self.basic_module(x)
 
 

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 30
+#define GFE_ABI_VERSION 31
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -420,12 +420,14 @@ int gfe_conv3d_c1_k3(const void* x, const float* weff, const float* bias_tab, vo
  *  - gfe_lift_groupnorm_affine: the GroupNorm(G groups) scale / shift (B, C) of r_c = w_c x + b_c from the first two moments of x
  *    (x: (B, S) f32; ws: B * 128 doubles of scratch);
  *  - gfe_conv3d_k3_lift_residual: gfe_conv3d_igemm for a stride-1 27-tap 64-channel conv (per-sample folded weights + bias table as
- *    usual, no statistics) whose residual is r, recomputed in the epilogue from vol (B, D, H, W) f32 and the lift's lift_w / lift_b (64). */
+ *    usual, no statistics) whose residual is r, recomputed in the epilogue from vol (B, D, H, W) f32 and the lift's lift_w / lift_b (64).
+ *    pool_out: NULL, or (B, D/2, H/2, W/2, 64) bf16 that receives nn.MaxPool3d(2) of the result (the next encoder's pooling,
+ *    buildingblocks.py:284, 306-307) from the epilogue -- needs relu != 0 and even D, H, W; bit-identical to pooling y afterwards. */
 int gfe_lift_groupnorm_affine(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                               float* scale, float* shift, double* ws, int64_t B, int64_t S, int64_t C, int64_t G, float eps, void* stream);
 int gfe_conv3d_k3_lift_residual(const void* x, const void* w_packed, int64_t w_batch_stride, const float* bias_tab, void* y,
                                 int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, const int8_t* tap_offsets, int relu,
-                                const float* vol, const float* lift_w, const float* lift_b, void* stream);
+                                const float* vol, const float* lift_w, const float* lift_b, void* pool_out, void* stream);
 
 /* gfe_conv3d_igemm for a stride-1 27-tap 64-channel conv (per-sample folded weights + bias table, optional bf16 residual, ReLU) that is
  * followed by the generator's final 1x1x1 conv Cout -> 1 (model.py:123, 165): the 64-channel result is rounded to bf16 as usual but

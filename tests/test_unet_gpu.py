@@ -431,3 +431,25 @@ def test_decoder_block_with_fused_final_conv_on_ragged_shapes(shape):
         ref = (F.relu(t + xn) * fw.view(1, 64, 1, 1, 1)).sum(1, keepdim=True) + fb
     assert fused.shape == (B, 1, D, H, W) and fused.dtype == torch.float32
     assert rel_err(fused, sep) < 5e-3 and rel_err(fused, ref) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 8, 24, 40), (1, 12, 10, 6)])
+def test_fused_maxpool_in_the_first_block_epilogue_is_bit_identical(shape):
+    """gfe_conv3d_k3_lift_residual with pool_out: the epilogue's MaxPool3d(2) (DPP within a wave for w / h, an LDS exchange between the
+    waves of a plane pair for d) equals pooling the stored result afterwards, bit for bit, on full, multi-tile and ragged (even) shapes;
+    and the first encoder hands it to the second (buildingblocks.py:284, 306-307)."""
+    from gfe_hip import nn_ops as K
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * H + W)
+    vol = torch.randn(B, D, H, W, generator=g).cuda()
+    x = torch.randn(B, D, H, W, 64, generator=g).to(torch.bfloat16).cuda()
+    w32 = K.pack_conv3((torch.randn(64, 64, 3, 3, 3, generator=g) / (27 * 64) ** 0.5).cuda(), torch.float32)
+    ss = K.groupnorm_scale_shift(x, torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), 8)
+    w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, 64, 64)
+    lw, lb = torch.randn(64, generator=g).cuda(), torch.randn(64, generator=g).cuda()
+    y = K.conv3_lift_residual(x, w, tab, 64, vol, lw, lb, relu=True)
+    assert getattr(y, "pooled2", None) is not None
+    y2 = K.conv3_lift_residual(x, w, tab, 64, vol, lw, lb, relu=True, pool=False)
+    assert getattr(y2, "pooled2", None) is None and torch.equal(y, y2)
+    assert torch.equal(y.pooled2, K.maxpool2(y2))
