@@ -373,7 +373,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise", "gen128", "gentrain"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (volumes for `step`, sequences for `scan`; default 8, gen128: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="step workload: replay zero_grad + forward + backward from a HIP graph (for host-bound batches of 1-4 volumes per GPU; DESIGN.md 6)")
+    ap.add_argument("--graph", action="store_true", help="step workload: replay the head (zero_grad + forward + backward) from a HIP graph inside the two-stream pipeline; with --no-pipeline the whole serial step (generator included) is one graph (DESIGN.md 6)")
     ap.add_argument("--no-pipeline", action="store_true", help="step workload: strictly serial step (generator, then head) on one stream")
     a = ap.parse_args()
     if a.batch is None:

@@ -382,7 +382,11 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t i) {
     z = z ^ (z >> 31);
     return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
 }
-__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int F, float p_drop, uint64_t seed) {
+// seed_step: NULL, or a device counter added (times an odd constant) to the seed -- a HIP graph bakes the by-value seed into the node,
+// so a replayed step draws a fresh mask only through memory (the captured step increments the counter once, before its forward)
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int F, float p_drop, uint64_t seed,
+                                                        const int64_t* __restrict__ seed_step) {
+    if (seed_step) seed += (uint64_t)(*seed_step) * 0xD1342543DE82EF95ull;
     const float keep = 1.0f / (1.0f - p_drop);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * F; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / F; const int f = (int)(i - r * F);
@@ -393,7 +397,8 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict_
     }
 }
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
-                                                        int64_t rows, int F, float p_drop, uint64_t seed) {
+                                                        int64_t rows, int F, float p_drop, uint64_t seed, const int64_t* __restrict__ seed_step) {
+    if (seed_step) seed += (uint64_t)(*seed_step) * 0xD1342543DE82EF95ull;
     const float keep = 1.0f / (1.0f - p_drop);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * F; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / F; const int f = (int)(i - r * F);
@@ -530,18 +535,18 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
     return gfe_launch_status();
 }
 
-int gfe_geglu_fwd(const float* x, float* y, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream) {
+int gfe_geglu_fwd(const float* x, float* y, int64_t rows, int64_t F, float p_drop, int64_t seed, const int64_t* seed_step, void* stream) {
     GFE_REQUIRE(x && y, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && F > 0 && rows * F <= 0x7fffffff && p_drop >= 0.f && p_drop < 1.f, GFE_ERR_SHAPE);
     int64_t g = ceil_div(rows * F, 256); if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, rows, (int)F, p_drop, (uint64_t)seed);
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, rows, (int)F, p_drop, (uint64_t)seed, seed_step);
     return gfe_launch_status();
 }
-int gfe_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream) {
+int gfe_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int64_t F, float p_drop, int64_t seed, const int64_t* seed_step, void* stream) {
     GFE_REQUIRE(x && dy && dx, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && F > 0 && rows * F <= 0x7fffffff && p_drop >= 0.f && p_drop < 1.f, GFE_ERR_SHAPE);
     int64_t g = ceil_div(rows * F, 256); if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, (int)F, p_drop, (uint64_t)seed);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, (int)F, p_drop, (uint64_t)seed, seed_step);
     return gfe_launch_status();
 }
 

@@ -192,27 +192,36 @@ class LayerNorm(torch.nn.LayerNorm):
 
 class _Geglu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p_drop, seed):
+    def forward(ctx, x, p_drop, seed, step_ctr):
         xs = x.shape
         F2 = xs[-1]
         x2 = _f(x).reshape(-1, F2)
         y = torch.empty((x2.shape[0], F2 // 2), dtype=torch.float32, device=x.device)
-        call("gfe_geglu_fwd", ptr(x2), ptr(y), x2.shape[0], F2 // 2, float(p_drop), int(seed), stream())
+        call("gfe_geglu_fwd", ptr(x2), ptr(y), x2.shape[0], F2 // 2, float(p_drop), int(seed), ptr(step_ctr), stream())
         ctx.save_for_backward(x2)
-        ctx.meta = (xs, float(p_drop), int(seed))
+        ctx.meta = (xs, float(p_drop), int(seed), step_ctr)
         return y.view(xs[:-1] + (F2 // 2,))
 
     @staticmethod
     def backward(ctx, dy):
         (x2,) = ctx.saved_tensors
-        xs, p_drop, seed = ctx.meta
+        xs, p_drop, seed, step_ctr = ctx.meta
         d = dy.float().reshape(x2.shape[0], -1).contiguous()
         dx = torch.empty_like(x2)
-        call("gfe_geglu_bwd", ptr(x2), ptr(d), ptr(dx), x2.shape[0], x2.shape[1] // 2, p_drop, seed, stream())
-        return dx.view(xs), None, None
+        call("gfe_geglu_bwd", ptr(x2), ptr(d), ptr(dx), x2.shape[0], x2.shape[1] // 2, p_drop, seed, ptr(step_ctr), stream())
+        return dx.view(xs), None, None, None
 
 
 _DROP_CALLS = [0]
+_STEP_CTR = [None]          # device int64 counter mixed into every dropout seed: set while a step is captured into / replayed from a HIP graph
+
+
+def set_dropout_step_counter(t):
+    """t: None, or a 1-element int64 CUDA tensor.  A HIP graph bakes the host-drawn seeds into its nodes; with a counter registered the
+    kernels add it (from memory) to their seed, and a captured step that increments it draws fresh masks on every replay."""
+    assert t is None or (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1)
+    _STEP_CTR[0] = t
+
 
 
 def geglu_dropout(x, p_drop=0.0, training=False):
@@ -224,7 +233,7 @@ def geglu_dropout(x, p_drop=0.0, training=False):
     if p > 0.0:
         _DROP_CALLS[0] += 1
         seed = (torch.initial_seed() * 1000003 + _DROP_CALLS[0]) & 0x7FFFFFFFFFFFFFFF
-    return _Geglu.apply(x, p, seed)
+    return _Geglu.apply(x, p, seed, _STEP_CTR[0] if p > 0.0 else None)
 
 
 class _BceSigmoid(torch.autograd.Function):

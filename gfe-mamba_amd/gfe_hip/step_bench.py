@@ -29,7 +29,7 @@ class StepWorkload:
     name = "classify_mamba train step (frozen generator fwd + head fwd/bwd + per-param clip + Adam), 96^3, synthetic"
 
     def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True):
-        self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline and not graph
+        self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline
         gen, head, ft = build_models(vol=vol, seed=0)
         import os
         ov = os.environ.get("GFE_OVERLAP_UPDATE")          # default off (see ClassifyStep); 1 turns it on for A/B runs
@@ -39,8 +39,10 @@ class StepWorkload:
         self.units = batch
 
     def step(self):
-        if self.graph:                                   # HIP-graph replay of zero_grad + forward + backward (small batches are host-bound)
+        if self.graph and not self.pipeline:             # HIP-graph replay of zero_grad + forward + backward (small batches are host-bound)
             return self.step_obj.train_step_graphed(*self.inputs)
+        if self.pipeline and self.graph:                 # the pipeline with the head's ~450 launches replayed from a graph
+            return self.step_obj.train_step_pipelined(*self.inputs, x_next=self.inputs[0], graph_head=True)
         if self.pipeline:
             # one head step (this batch) + one generator forward (the next batch; synthetic: the same volumes) per call, on two
             # streams: the frozen generator does not depend on the update (ClassifyStep.train_step_pipelined)

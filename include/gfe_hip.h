@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 31
+#define GFE_ABI_VERSION 32
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -366,9 +366,11 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
 
 /* GEGLU (corss_ft_transformer.py:10-13: x, gates = chunk(2); x * gelu(gates), exact erf) followed by Dropout(p_drop) (:19):
  * x (rows, 2F) -> y (rows, F).  The mask is a counter-based hash of (seed, element index): the backward regenerates it from the
- * same seed; p_drop = 0 in eval mode. */
-int gfe_geglu_fwd(const float* x, float* y, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream);
-int gfe_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int64_t F, float p_drop, int64_t seed, void* stream);
+ * same seed; p_drop = 0 in eval mode.  seed_step: NULL, or a DEVICE int64 counter that is mixed into the seed when the kernel runs -- a HIP
+ * graph bakes the by-value seed into its node, so a replayed step gets a fresh mask only through memory (the captured step increments
+ * the counter once before its forward; forward and backward of one step read the same value). */
+int gfe_geglu_fwd(const float* x, float* y, int64_t rows, int64_t F, float p_drop, int64_t seed, const int64_t* seed_step, void* stream);
+int gfe_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int64_t F, float p_drop, int64_t seed, const int64_t* seed_step, void* stream);
 
 /* BCELoss(sigmoid(logits), y), mean over n samples (classify_mamba.py:67, 104), logs clamped at -100 as torch does: loss[0], and
  * (dlogits != NULL) the gradient of that mean loss w.r.t. the logits in the same launch. */

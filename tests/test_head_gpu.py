@@ -537,3 +537,40 @@ def test_head_small_ops_vs_torch_and_reference_fixture():
     assert abs(loss.item() - lref.item()) < 1e-5 * max(1.0, lref.item())
     loss.backward(); lref.backward()
     assert (gz.grad.cpu() - cz.grad).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_dropout_masks_change_between_graph_replays():
+    """GEGLU + dropout under a HIP graph: the host-drawn seed is baked into the node, so the mask varies through the device step counter
+    (head_ops.set_dropout_step_counter) that the captured step increments -- two replays drop different units, forward and backward of
+    one replay use the same mask, and without the counter the replays would be identical."""
+    from gfe_hip import head_ops as Hd
+    x = torch.randn(64, 512, device=DEV, requires_grad=True)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+
+    def run():
+        ctr.add_(1)
+        x.grad = None
+        y = Hd.geglu_dropout(x, 0.3, training=True)
+        y.sum().backward()
+        return y.detach(), x.grad
+
+    Hd.set_dropout_step_counter(ctr)
+    try:
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y, gx = run()
+    finally:
+        Hd.set_dropout_step_counter(None)
+    g.replay(); torch.cuda.synchronize()
+    y1, g1 = y.clone(), gx.clone()
+    g.replay(); torch.cuda.synchronize()
+    y2, g2 = y.clone(), gx.clone()
+    drop1, drop2 = y1 == 0, y2 == 0
+    assert 0.2 < drop1.float().mean() < 0.4 and 0.2 < drop2.float().mean() < 0.4
+    assert (drop1 != drop2).float().mean() > 0.2                                  # fresh mask per replay
+    assert torch.equal(g1[:, :256] == 0, drop1) and torch.equal(g2[:, :256] == 0, drop2)       # backward of a replay uses its forward's mask
