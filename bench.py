@@ -427,7 +427,7 @@ def main():
         steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 5
         metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
-               "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph),
+               "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
                "pipeline": "generator(batch k+1) || head(batch k), 2 streams" if wl.pipeline else "none"}
 
     def barrier():

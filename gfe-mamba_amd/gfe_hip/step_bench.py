@@ -30,6 +30,9 @@ class StepWorkload:
 
     def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True):
         self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline
+        # batches of 1-4 volumes are host-bound (the head is ~450 launches): their head replays from a HIP graph unless GFE_NO_AUTO_GRAPH=1
+        import os as _os
+        self.graph_head = pipeline and (graph or (batch <= 4 and _os.environ.get("GFE_NO_AUTO_GRAPH") != "1"))
         gen, head, ft = build_models(vol=vol, seed=0)
         import os
         ov = os.environ.get("GFE_OVERLAP_UPDATE")          # default off (see ClassifyStep); 1 turns it on for A/B runs
@@ -41,7 +44,7 @@ class StepWorkload:
     def step(self):
         if self.graph and not self.pipeline:             # HIP-graph replay of zero_grad + forward + backward (small batches are host-bound)
             return self.step_obj.train_step_graphed(*self.inputs)
-        if self.pipeline and self.graph:                 # the pipeline with the head's ~450 launches replayed from a graph
+        if self.pipeline and self.graph_head:            # the pipeline with the head's ~450 launches replayed from a graph
             return self.step_obj.train_step_pipelined(*self.inputs, x_next=self.inputs[0], graph_head=True)
         if self.pipeline:
             # one head step (this batch) + one generator forward (the next batch; synthetic: the same volumes) per call, on two
