@@ -81,8 +81,8 @@ class StepWorkload:
         flops = 2.0 * 27 * 64 * 64 * self.batch * self.vol[0] * self.vol[1] * self.vol[2]
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": measured_traffic("conv_igemm_64to64_96cubed_b8") if self.batch == 8 else None,
-                "traffic_source": "profiles/r01/traffic_v13.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.batch == 8 else None,
+                "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r02", "traffic_r02.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if self.batch == 8 else None,
+                "traffic_source": "profiles/r02/traffic_r02.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.batch == 8 else None,
                 "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @96^3, ReLU)", "launch_ms": round(ms, 4),
                 "algorithmic_flops": flops}
 

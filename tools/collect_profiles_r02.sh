@@ -27,6 +27,8 @@ cp $O/prof_conv64/conv64_kernel_stats.csv $O/conv64_b8_kernel_stats.csv
 # scan traffic (separate PMC passes, kernel trace only)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_scan_fetch -o p -- python3 $R/bench.py --workload scan --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_scan_write -o p -- python3 $R/bench.py --workload scan --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_conv_fetch -o p -- python3 $R/tools/conv_bench.py 64 96 8 10 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_conv_write -o p -- python3 $R/tools/conv_bench.py 64 96 8 10 > /dev/null 2>&1
 $R/exp_build/valu_rates > $O/valu_rates.txt 2>&1
 cd $R
 python3 - <<PY
@@ -50,7 +52,18 @@ for d, scale in (("pmc_scan_fetch", 2.0), ("pmc_scan_write", 1.0)):      # gfx95
 out.close()
 json.dump(res, open(os.path.join(O, "scan_traffic.json"), "w"), indent=1)
 tot = sum(sum(v.values()) for v in res.values())
-json.dump({"scan_b8": {"traffic_bytes": tot, "per_kernel": res,
+conv = {}
+for d, scale in (("pmc_conv_fetch", 2.0), ("pmc_conv_write", 1.0)):
+    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+    if not f: continue
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "conv_igemm_kernel<4, 3, true, false" in r["Kernel_Name"]]
+    if v: conv[d] = sum(v) / len(v) * scale * 1024
+extra = {}
+if len(conv) == 2:
+    extra["conv_igemm_64to64_96cubed_b8"] = {"traffic_bytes": sum(conv.values()), "fetch_x2_bytes": conv["pmc_conv_fetch"], "write_bytes": conv["pmc_conv_write"],
+                                              "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of conv_igemm_kernel<4,3,true> in tools/conv_bench.py 64 96 8"}
+    print("conv 64->64 @96^3 B=8 traffic per launch: fetch %.2f GB (x2 applied) + write %.2f GB" % (conv["pmc_conv_fetch"] / 1e9, conv["pmc_conv_write"] / 1e9))
+json.dump({**extra, "scan_b8": {"traffic_bytes": tot, "per_kernel": res,
                        "method": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 reports half of coalesced reads at 4, 8 and 16 B per lane, tools/probes/fetch_calib.hip) and --pmc WRITE_SIZE, separate passes, mean per launch of sscan2_fwd + sscan2_bwd at B=8 L=4096 ED=1024 N=16 bf16"}},
           open(os.path.join(O, "traffic_r02.json"), "w"), indent=1)
 PY
