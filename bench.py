@@ -424,7 +424,7 @@ def main():
     else:
         from gfe_hip.step_bench import StepWorkload
         wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph, pipeline=not a.no_pipeline)
-        steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 5
+        steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 10     # (a fresh box needs a few steps before clocks / page-ins settle)
         metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
                "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
