@@ -373,7 +373,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise", "gen128", "gentrain"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (volumes for `step`, sequences for `scan`; default 8, gen128: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="step workload: replay the head (zero_grad + forward + backward) from a HIP graph inside the two-stream pipeline; with --no-pipeline the whole serial step (generator included) is one graph (DESIGN.md 6)")
+    ap.add_argument("--graph", action="store_true", help="step workload: with --no-pipeline, replay the whole serial step (generator included) from one HIP graph; inside the default two-stream pipeline it replays the head from a graph (already the default for batches of 1-4 volumes and for --gpus N > 1; GFE_NO_AUTO_GRAPH=1 turns that off; DESIGN.md 6)")
     ap.add_argument("--no-pipeline", action="store_true", help="step workload: strictly serial step (generator, then head) on one stream")
     a = ap.parse_args()
     if a.batch is None:
@@ -428,7 +428,7 @@ def main():
         metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
                "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
-               "pipeline": "generator(batch k+1) || head(batch k), 2 streams" if wl.pipeline else "none"}
+               "pipeline": ("generator(batch k+1) || head(batch k), 2 streams" + (", head replayed from a HIP graph" if getattr(wl, "graph_head", False) else "")) if wl.pipeline else "none"}
 
     def barrier():
         if world > 1:

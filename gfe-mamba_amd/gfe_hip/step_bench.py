@@ -30,9 +30,12 @@ class StepWorkload:
 
     def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True):
         self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline
-        # batches of 1-4 volumes are host-bound (the head is ~450 launches): their head replays from a HIP graph unless GFE_NO_AUTO_GRAPH=1
+        # The head (~450 launches: zero_grad, forward, loss, backward) can replay from a HIP graph inside the pipeline: host enqueue 8.5 ->
+        # 3.8 ms per 11 ms step at B=8.  On one GPU at B=8 the eager head is 0.8 % faster (742-744 vs 734-739 volumes/s) and stays the
+        # default; the graph is the default where the host is the risk: batches of 1-4 volumes (host-bound: 1.2-2.5x) and multi-rank runs
+        # (N processes enqueue at once and the step time is the MAX over ranks, so one rank's host hiccup costs every rank).
         import os as _os
-        self.graph_head = pipeline and (graph or (batch <= 4 and _os.environ.get("GFE_NO_AUTO_GRAPH") != "1"))
+        self.graph_head = pipeline and (graph or ((batch <= 4 or world > 1) and _os.environ.get("GFE_NO_AUTO_GRAPH") != "1"))
         gen, head, ft = build_models(vol=vol, seed=0)
         import os
         ov = os.environ.get("GFE_OVERLAP_UPDATE")          # default off (see ClassifyStep); 1 turns it on for A/B runs

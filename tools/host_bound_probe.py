@@ -6,8 +6,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "gfe-mamba_amd")]
 import torch
 from gfe_hip.step_bench import StepWorkload
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-for pipeline in (True, False):
-    wl = StepWorkload(B, pipeline=pipeline)
+for pipeline, graph in ((True, False), (True, True), (False, False)):
+    wl = StepWorkload(B, pipeline=pipeline, graph=graph)
     for _ in range(5):
         wl.step()
     torch.cuda.synchronize()
@@ -18,4 +18,4 @@ for pipeline in (True, False):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"B={B} pipeline={pipeline}: host enqueue {1e3 * (t1 - t0) / n:.2f} ms/step, GPU done {1e3 * (t2 - t0) / n:.2f} ms/step", flush=True)
+    print(f"B={B} pipeline={pipeline} graph_head={graph}: host enqueue {1e3 * (t1 - t0) / n:.2f} ms/step, GPU done {1e3 * (t2 - t0) / n:.2f} ms/step", flush=True)
