@@ -98,7 +98,7 @@ class ClassifyStep:
                     fwd_bwd()
                 cur.synchronize()
                 self._hgraph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._hgraph, stream=cur):
+                with torch.cuda.graph(self._hgraph, stream=cur, capture_error_mode="thread_local"):     # (RCCL's watchdog thread may touch the runtime meanwhile)
                     self._hloss = fwd_bwd()
             finally:
                 Hd.set_dropout_step_counter(None)
@@ -199,7 +199,7 @@ class ClassifyStep:
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(self._graph):
+                with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                     self._gloss = fwd_bwd()
             finally:
                 Hd.set_dropout_step_counter(None)
