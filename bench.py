@@ -386,7 +386,10 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # NOT device_id=...: binding the group to the device at init (eager communicator) makes every kernel of the step slower on this
+        # stack -- 10.9 -> 12.8-13.0 ms per step with a ONE-rank group and no collective at all (tools/dp_graph_probe.py: PROBE_PG_MODE=eager
+        # vs lazy); with the communicator created lazily on the first collective the step time is unchanged.
+        dist.init_process_group("nccl")
     n_gpus = world
     assert a.gpus == n_gpus or "WORLD_SIZE" in os.environ, "internal: --gpus N > 1 without WORLD_SIZE is started by maybe_self_launch()"
     # per-rank RNG stream for everything drawn on the device during the step (the GEGLU feed-forward's dropout mask,
@@ -432,7 +435,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
 
     for _ in range(warmup):
         wl.step()
