@@ -35,16 +35,12 @@ for p in (ROOT, SRC):
 
 
 
-def launch_command(n_gpus, argv, port=None):
+def launch_command(n_gpus, argv):
     """The command `bench.py --gpus N` starts when nobody has started the ranks for it: torch.distributed.run, one rank per GPU
-    of this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
-    import socket
-    if port is None:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    of this node.  `--standalone` lets torchrun bind its rendezvous store to a free port ITSELF (no bind-close-reuse race with
+    another bench or profile run on the host); `--local-addr 127.0.0.1` because the container hostname may not resolve."""
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            f"--nproc-per-node={n_gpus}", os.path.abspath(__file__)] + list(argv)
 
 
 def maybe_self_launch(argv=None):
@@ -64,7 +60,7 @@ def maybe_self_launch(argv=None):
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))    # N ranks share the host's cores
     return subprocess.call(launch_command(n, argv), env=env)
 
 
@@ -382,9 +378,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # started by torch.distributed.run (any N, ALSO N = 1): the process group, the barrier, the gradient all-reduce on the head stream
+    # and the graphed head are all live, so that a one-GPU box exercises exactly the code path the 8-GPU run takes (tests/test_multirank_gpu.py)
+    distributed = "WORLD_SIZE" in os.environ
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
-    if world > 1:
+    if distributed:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), (os.cpu_count() or 8) // max(world, 1))))    # N ranks share the host
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # NOT device_id=...: binding the group to the device at init (eager communicator) makes every kernel of the step slower on this
         # stack -- 10.9 -> 12.8-13.0 ms per step with a ONE-rank group and no collective at all (tools/dp_graph_probe.py: PROBE_PG_MODE=eager
@@ -426,7 +426,7 @@ def main():
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
     else:
         from gfe_hip.step_bench import StepWorkload
-        wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph, pipeline=not a.no_pipeline)
+        wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph, pipeline=not a.no_pipeline, distributed=distributed)
         steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 10     # (a fresh box needs a few steps before clocks / page-ins settle)
         metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
@@ -434,7 +434,7 @@ def main():
                "pipeline": ("generator(batch k+1) || head(batch k), 2 streams" + (", head replayed from a HIP graph" if getattr(wl, "graph_head", False) else "")) if wl.pipeline else "none"}
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier(device_ids=[local])
 
     for _ in range(warmup):
@@ -446,16 +446,22 @@ def main():
     for _ in range(steps):
         wl.step()
     torch.cuda.synchronize()
+    el_own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the slowest rank)
     barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    per_rank = None
+    if distributed:
         t = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
+        own = torch.tensor([el_own / steps * 1e3], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allr, own)
+        per_rank = [round(v.item(), 4) for v in allr]       # a host-bound or straggling rank shows up here
 
-    roof = wl.roofline()
-    comm = wl.allreduce_stats() if world > 1 and hasattr(wl, "allreduce_stats") else None
+    roof = wl.roofline() if rank == 0 else None              # one GPU's kernel figure; ranks > 0 go straight to the collective's barrier
+    comm = wl.allreduce_stats(local) if distributed and hasattr(wl, "allreduce_stats") else None
     cpu = None
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         cpu = wl.cpu_baseline()
@@ -469,8 +475,10 @@ def main():
             out["extra"] = extra() if callable(extra) else extra
         if comm:
             out["allreduce"] = comm
+        if per_rank is not None:
+            out["ms_per_step_by_rank"] = {"min": min(per_rank), "max": max(per_rank), "ranks": per_rank}
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -27,20 +27,22 @@ def shard_batch(tensors, rank, world_size):
     return out
 
 
-def allreduce_grads_(flat_grad, world_size, group=None):
+def allreduce_grads_(flat_grad, world_size, group=None, force=False):
     """The step's only collective: SUM all-reduce of the flat gradient buffer (RCCL on GPUs, gloo in the CPU tests).
-    Returns the scale the optimiser must apply (folded into the clip/Adam kernel instead of a separate pass)."""
+    Returns the scale the optimiser must apply (folded into the clip/Adam kernel instead of a separate pass).
+    `force`: issue the collective for a ONE-rank group too (the identity; lets a one-GPU box run the multi-rank code path)."""
     import torch.distributed as dist
-    if world_size > 1:
+    if world_size > 1 or force:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return dp_mean_scale(world_size)
 
 
 class ClassifyStep:
-    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None, overlap_update=None):
+    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None, overlap_update=None, force_collective=False):
         self.gen, self.head, self.ft = gen.eval(), head, ft
         self.all_params = list(head.parameters()) + list(ft.parameters())          # classify_mamba.py:57-61
         self.opt = FlatAdam(self.all_params, lr=lr, max_norm=max_norm)             # Adam(lr=1e-4) + per-parameter clip
+        self.opt.force_collective = bool(force_collective)                         # all_reduce even in a one-rank group
         self.world_size, self.group = world_size, group
         # The generator is frozen (classify_mamba.py:53,100), so its forward for step k+1 does not depend on update k: with
         # overlap_update the gradient all-reduce + Adam of step k run on a side stream underneath it (same arithmetic, same order
@@ -106,7 +108,7 @@ class ClassifyStep:
         for dst, src in zip(self._hin, ins):
             dst.copy_(src)
         self._hgraph.replay()
-        return self._hloss
+        return self._hloss.clone()            # the captured loss buffer is overwritten by the next replay: hand out a copy
 
     def train_step_pipelined(self, x, x_cat, x_num, y, x_next=None, graph_head=False):
         """One training step on (x, x_cat, x_num, y); if `x_next` (the next batch's volumes) is given, its generator forward is
@@ -207,8 +209,9 @@ class ClassifyStep:
             dst.copy_(src)
         self.opt.wait_updated()
         self._graph.replay()
+        loss = self._gloss.clone()            # (the graph's private buffer is overwritten by the next replay)
         self.opt.step(self.world_size, self.group)
-        return self._gloss
+        return loss
 
     @torch.no_grad()
     def eval_step(self, x, x_cat, x_num):

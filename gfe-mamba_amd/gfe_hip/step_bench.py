@@ -28,18 +28,22 @@ HEAD_GFLOP_PER_SAMPLE = 11.64
 class StepWorkload:
     name = "classify_mamba train step (frozen generator fwd + head fwd/bwd + per-param clip + Adam), 96^3, synthetic"
 
-    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True):
+    def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True, distributed=None):
         self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline
         # The head (~450 launches: zero_grad, forward, loss, backward) can replay from a HIP graph inside the pipeline: host enqueue 8.5 ->
         # 3.8 ms per 11 ms step at B=8.  On one GPU at B=8 the eager head is 0.8 % faster (742-744 vs 734-739 volumes/s) and stays the
         # default; the graph is the default where the host is the risk: batches of 1-4 volumes (host-bound: 1.2-2.5x) and multi-rank runs
         # (N processes enqueue at once and the step time is the MAX over ranks, so one rank's host hiccup costs every rank).
         import os as _os
-        self.graph_head = pipeline and (graph or ((batch <= 4 or world > 1) and _os.environ.get("GFE_NO_AUTO_GRAPH") != "1"))
+        # `distributed`: a process group is live (torchrun started us) -- true for a ONE-rank group too, which then runs the multi-rank
+        # code path: graphed head, all_reduce of the flat gradient buffer on the head stream in every step
+        self.distributed = (world > 1) if distributed is None else bool(distributed)
+        self.graph_head = pipeline and (graph or ((batch <= 4 or self.distributed) and _os.environ.get("GFE_NO_AUTO_GRAPH") != "1"))
         gen, head, ft = build_models(vol=vol, seed=0)
         import os
         ov = os.environ.get("GFE_OVERLAP_UPDATE")          # default off (see ClassifyStep); 1 turns it on for A/B runs
-        self.step_obj = ClassifyStep(gen, head, ft, world_size=world, overlap_update=None if ov is None else ov == "1")
+        self.step_obj = ClassifyStep(gen, head, ft, world_size=world, overlap_update=None if ov is None else ov == "1",
+                                     force_collective=self.distributed)
         x, x_cat, x_num, y = det.det_inputs(batch, vol, seed=1000 + rank)
         self.inputs = [t.cuda() for t in (x, x_cat, x_num, y)]
         self.units = batch
@@ -109,7 +113,7 @@ class StepWorkload:
         return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": "oracle/ref_ops.py (torch CPU fp32): generator fwd + head fwd/bwd on 1 volume of 96^3 (no optimiser)"}
 
-    def allreduce_stats(self, iters=10):
+    def allreduce_stats(self, local=0, iters=10):
         """The step's only collective, timed alone on every rank (max over ranks): SUM all-reduce of the flat f32 gradient buffer.
         bus GB/s = 2 (N-1)/N x bytes / time (the ring all-reduce's per-link traffic)."""
         import torch.distributed as dist
@@ -117,7 +121,7 @@ class StepWorkload:
         for _ in range(2):
             dist.all_reduce(g)
         torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -128,7 +132,7 @@ class StepWorkload:
         g.zero_()
         n, nbytes = self.world, g.numel() * 4
         return {"bytes": nbytes, "ms": round(dt.item() * 1e3, 4), "algbw_GBs": round(nbytes / dt.item() / 1e9, 1),
-                "busbw_GBs": round(2 * (n - 1) / n * nbytes / dt.item() / 1e9, 1), "collective": "all_reduce(SUM) of the flat f32 gradient buffer, RCCL"}
+                "busbw_GBs": round(2 * (n - 1) / n * nbytes / dt.item() / 1e9, 1), "ranks": n, "collective": "all_reduce(SUM) of the flat f32 gradient buffer, RCCL"}
 
     def extra(self):
         return {"generator_gflop_per_volume": GEN_GFLOP_PER_VOL, "head_gflop_per_sample": HEAD_GFLOP_PER_SAMPLE}

@@ -330,7 +330,7 @@ class FlatAdam:
 
     def _step(self, world_size, group):
         from .step import allreduce_grads_
-        scale = allreduce_grads_(self.flat_g, world_size, group)         # SUM over ranks; the mean is folded into grad_scale
+        scale = allreduce_grads_(self.flat_g, world_size, group, force=getattr(self, "force_collective", False))   # SUM over ranks; the mean is folded into grad_scale
         self.t += 1
         self.epoch[0] += 1
         self.norm2.zero_()

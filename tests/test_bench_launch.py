@@ -25,11 +25,12 @@ def test_gpus_2_builds_a_two_rank_torchrun_launch(bench, monkeypatch):
     cmd, env = calls[0]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert "--standalone" in cmd and "--master-port" not in cmd               # torchrun binds the rendezvous port itself: no bind-close-reuse race
+    assert cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"                  # the container hostname may not resolve
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]          # the ranks get the caller's arguments unchanged
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert int(env["OMP_NUM_THREADS"]) >= 1
     assert bench.maybe_self_launch(["--gpus=4"]) == 0 and "--nproc-per-node=4" in calls[1][0]
 
 

@@ -1,0 +1,154 @@
+"""The multi-rank code path (BASELINE config 5: batch-sharded DP, RCCL gradient all-reduce; classify_mamba.py:94-109)
+on the ONE GPU a test box has.
+
+* a one-rank `nccl` process group stands in for the N-rank one: lazily created communicator, `barrier(device_ids=...)`, watchdog
+  thread alive, a real `all_reduce` of the flat gradient buffer on the head stream in every step, head replayed from a HIP graph --
+  the exact configuration `bench.py --gpus N` runs -- and must give the same parameters as the plain step;
+* `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (how the driver starts N ranks) must print the JSON line
+  with the `allreduce` object and the per-rank step times;
+* `FlatAdam._step(world_size=2)` semantics with the PRODUCT's kernels: the SUM of two half-batch gradients, scaled by 1/2 inside
+  the clip/Adam kernel, must reproduce the full-batch step (what tests/test_dp_gloo.py checks with the oracle's gradient on CPU).
+
+Children are fresh processes started with subprocess (a child, never an exec of this GPU-initialised process)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def _run(cmd, timeout=900):
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, "child failed (%d)\n--- stdout ---\n%s\n--- stderr ---\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-6000:])
+    return r
+
+
+def test_one_rank_rccl_group_graphed_pipelined_step_equals_the_plain_step(tmp_path):
+    child = os.path.join(ROOT, "tests", "dp_child.py")
+    a, b = str(tmp_path / "nogroup.pt"), str(tmp_path / "group.pt")
+    _run([sys.executable, child, "steps", "nogroup", a])
+    _run([sys.executable, child, "steps", "group", b, str(_free_port())])
+    ra, rb = torch.load(a), torch.load(b)
+    dl = (ra["loss"] - rb["loss"]).abs().max().item()
+    dp = (ra["p"] - rb["p"]).abs()
+    dg = ((ra["g"] - rb["g"]).abs().max() / ra["g"].abs().max()).item()
+    frac = (dp > 1e-6).float().mean().item()
+    print("one-rank RCCL group vs no group, 5 graphed pipelined steps: max |dloss| %.2e, last gradient rel err %.2e, parameters: %.2e of the "
+          "elements differ by > 1e-6 (max %.2e), losses %s" % (dl, dg, frac, dp.max().item(), [round(v, 6) for v in rb["loss"].tolist()]))
+    assert torch.isfinite(rb["loss"]).all() and torch.isfinite(rb["p"]).all()
+    assert dl < 1e-6 and dg < 1e-5
+    # Parameters: the head still sums a few gradients with f32 atomics, so two runs of the SAME program agree to rounding, not bit for bit,
+    # and Adam turns a gradient element that is pure rounding noise (k_proj.bias: exactly zero in exact arithmetic) into a +-lr step of
+    # either sign.  So: all but a sliver of the 21.8 M elements within 1e-6 (1 % of one step's movement), none further than the 5 steps
+    # can carry two noise elements apart.
+    assert frac < 1e-3, frac
+    assert dp.max().item() <= 5 * 2 * 1e-4 * 1.01
+
+
+def test_bench_under_torchrun_with_one_rank_reports_the_allreduce():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node=1",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--no-cpu-baseline"]
+    r = _run(cmd)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    print("bench.py under torchrun (1 rank):", {k: out[k] for k in ("value", "ms_per_step", "allreduce", "ms_per_step_by_rank")})
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+    assert out["config"]["hip_graph"] is True and out["config"]["parallelism"] == "dp1"
+    ar = out["allreduce"]
+    assert ar["ranks"] == 1 and ar["bytes"] > 80e6 and ar["ms"] > 0             # the 21.8 M-parameter flat gradient buffer (87 MB)
+    assert len(out["ms_per_step_by_rank"]["ranks"]) == 1
+    assert out["roofline"]["frac"] > 0
+
+
+class _FrozenOutputs:
+    """Stands in for the frozen generator: hands out precomputed outputs for the rows the test selects, so that the comparison below
+    isolates the data-parallel arithmetic from the generator's own dependence on the batch it is run with."""
+
+    def __init__(self, outs):
+        self.outs, self.rows = outs, slice(None)
+
+    def eval(self):
+        return self
+
+    def __call__(self, x, output_vit_mid=True):
+        return tuple(o[self.rows].contiguous() for o in self.outs)
+
+
+def test_world_size_2_update_from_summed_half_batch_gradients_equals_the_full_batch_update(monkeypatch):
+    import gfe_hip.det_init as det
+    import gfe_hip.step as S
+    from gfe_hip.step import ClassifyStep, build_models
+    vol, kw = (32, 32, 32), dict(f_maps=(8, 16, 32), dim=64, depth=2, heads=8, vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), seed=5)
+    x, x_cat, x_num, y = [t.to(DEV) for t in det.det_inputs(4, vol, seed=9)]
+    gen, _, _ = build_models(vol=vol, **kw)
+    with torch.no_grad():
+        outs = gen(x, output_vit_mid=True)
+    fake = _FrozenOutputs(outs)
+
+    def make(world):
+        _, head, ft = build_models(vol=vol, **kw)
+        return ClassifyStep(fake, head, ft, world_size=world)
+
+    def drop_off(st):
+        for m in st.ft.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0                                                    # the GEGLU dropout mask depends on the batch layout
+
+    full, r0, r1 = make(1), make(2), make(2)
+    for st in (full, r0, r1):
+        drop_off(st)
+    other = {}
+
+    def fake_allreduce(flat_grad, world_size, group=None, force=False):      # rank 0's view of all_reduce(SUM) over two ranks
+        if world_size == 2:
+            flat_grad.add_(other["g"])
+        return S.dp_mean_scale(world_size)
+    monkeypatch.setattr(S, "allreduce_grads_", fake_allreduce)
+
+    for step in range(2):
+        fake.rows = slice(None)
+        l_full = full.train_step(x, x_cat, x_num, y)
+        # "rank 1": gradient of its shard only (forward + backward, no update)
+        fake.rows = slice(2, 4)
+        r1.head.train(); r1.ft.train()
+        r1.opt.zero_grad()
+        pred, _ = r1.forward(x[2:], x_cat[2:], x_num[2:])
+        l1 = S.bce_sigmoid(pred.squeeze(1), y[2:])
+        l1.backward()
+        other["g"] = r1.opt.flat_g.clone()
+        # "rank 0": its shard, then the (faked) all-reduce + clip + Adam with world_size = 2
+        fake.rows = slice(0, 2)
+        l0 = r0.train_step(x[:2], x_cat[:2], x_num[:2], y[:2])
+        assert abs(0.5 * (l0.item() + l1.item()) - l_full.item()) < 1e-5     # BCELoss is a batch mean (classify_mamba.py:67)
+        g_dp, g_full = 0.5 * r0.opt.flat_g, full.opt.flat_g                  # flat_g keeps the summed, unscaled gradient
+        e_g = ((g_dp - g_full).abs().max() / g_full.abs().max()).item()
+        dp = (r0.opt.flat_p - full.opt.flat_p).abs()
+        e_p, frac = dp.max().item(), (dp > 1e-6).float().mean().item()
+        print("step %d: DP(2) vs full batch: gradient rel err %.2e, parameters: max |d| %.2e, %.2e of the elements beyond 1e-6" % (step, e_g, e_p, frac))
+        assert e_g < 1e-5, e_g
+        # Adam divides by sqrt(v): an element whose gradient is rounding noise moves by up to lr in either direction (see the test above)
+        assert frac < 1e-3 and e_p <= (step + 1) * 2 * 1e-4 * 1.01, (frac, e_p)
+        # keep rank 1's replica in step with rank 0's (every rank applies the same update)
+        r1.opt.flat_p.copy_(r0.opt.flat_p); r1.opt.flat_p16.copy_(r0.opt.flat_p16)
