@@ -158,6 +158,57 @@ class ScanWorkload:
                 "sample": f"oracle/scan_ref.c, B=1 L=4096, {ch}/{self.ED} channels, forward only, scaled to ED={self.ED}"}
 
 
+class PscanWorkload:
+    """Operator boundary 1: the MATERIALISED drop-in `pscan(A, X)` of cross_atten/pscan.py:226 at config 2's shape,
+    (B, L, D, N) = (B, 4096, 1024, 16) bf16: A in (0.05, 0.95), X ~ N(0,1).  Algorithmic bytes: forward = read A, X + write
+    H = 3 B L D N s (403 MB at B = 1), backward = read A, H, gH + write gA, gX = 5 B L D N s (671 MB)."""
+    name = "pscan(A, X) fwd+bwd (materialised drop-in), L=4096 D=1024 N=16 bf16"
+
+    def __init__(self, batch, L=4096, D=1024, N=16):
+        g = torch.Generator().manual_seed(0)
+        self.B, self.L, self.D, self.N = batch, L, D, N
+        self.A = (torch.rand(batch, L, D, N, generator=g) * 0.9 + 0.05).to(torch.bfloat16).cuda().requires_grad_(True)
+        self.X = torch.randn(batch, L, D, N, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+        self.gH = torch.randn(batch, L, D, N, generator=g).to(torch.bfloat16).cuda()
+        self.units = batch * L
+        n = batch * L * D * N * 2
+        self.bytes_fwd, self.bytes_bwd = 3 * n, 5 * n
+
+    def fwd(self):
+        from cross_atten.pscan import pscan
+        return pscan(self.A, self.X)
+
+    def step(self):
+        H = self.fwd()
+        self.A.grad = self.X.grad = None
+        H.backward(self.gH)
+
+    def roofline(self, iters=20):
+        with torch.no_grad():
+            self.fwd()
+            t_f = time_region(self.fwd, iters)
+        self.step()
+        t_s = time_region(self.step, iters)
+        t_b = max(t_s - t_f, 1e-6)
+        gbs = (self.bytes_fwd + self.bytes_bwd) / (t_s * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "pscan_fwd + pscan_bwd (csrc/pscan.hip: streaming first-order recurrence over (B, L, D*N), no power-of-two padding)",
+                "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4), "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1),
+                "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1), "algorithmic_bytes": self.bytes_fwd + self.bytes_bwd}
+
+    def cpu_baseline(self):
+        """oracle.ref_ops.pscan + pscan_grads (torch CPU restatement of pscan.py:36-224) on a slab: B=1, L=4096, 64 of the 1024 channels."""
+        from oracle import ref_ops as O
+        ch = 64
+        A, X, gH = (t.detach()[:1, :, :ch].float().cpu() for t in (self.A, self.X, self.gH))
+        t0 = time.perf_counter()
+        H = O.pscan(A, X)
+        O.pscan_grads(A, H, gH)
+        dt = time.perf_counter() - t0
+        return {"value": round(self.L / (dt * self.D / ch), 1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle.ref_ops.pscan + pscan_grads, B=1 L=4096, {ch}/{self.D} channels, fp32 torch CPU, scaled to D={self.D}"}
+
+
 class Vit3dWorkload:
     """SURVEY 8-d "MFMA 3D-ViT attention row": vit_3d.ViT(image_size=96, image_patch_size=8, frames=96, frame_patch_size=8,
     channels=1, dim=512, depth=4, heads=8, dim_head=64, mlp_dim=2048, num_classes=1), B volumes of 96^3, bf16 GEMM/attention
@@ -366,14 +417,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "vit3d", "normalise", "gen128", "gentrain"])
+    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "pscan", "vit3d", "normalise", "gen128", "gentrain"])
+    ap.add_argument("--volume", default="96", choices=["96", "native"], help="step workload: 96 = 96^3 (BASELINE's metric); native = the reference's own 160x160x96 (config/classify_mamba_config.yaml:5-7; --batch 2 = its train_bc)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (volumes for `step`, sequences for `scan`; default 8, gen128: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="step workload: with --no-pipeline, replay the whole serial step (generator included) from one HIP graph; inside the default two-stream pipeline it replays the head from a graph (already the default for batches of 1-4 volumes and for --gpus N > 1; GFE_NO_AUTO_GRAPH=1 turns that off; DESIGN.md 6)")
     ap.add_argument("--no-pipeline", action="store_true", help="step workload: strictly serial step (generator, then head) on one stream")
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 2 if a.workload in ("gen128", "gentrain") else 8
+        a.batch = 2 if a.workload in ("gen128", "gentrain") else 1 if a.workload == "pscan" else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -414,6 +466,11 @@ def main():
         steps, warmup = a.steps or 50, a.warmup if a.warmup is not None else 10
         metric, unit, dtype = "selective-scan tokens/sec (L=4096 ED=1024 N=16 bf16) fwd+bwd", "tokens/s", "bf16"
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
+    elif a.workload == "pscan":
+        wl = PscanWorkload(a.batch)
+        steps, warmup = a.steps or 30, a.warmup if a.warmup is not None else 5
+        metric, unit, dtype = "pscan tokens/sec (L=4096 D=1024 N=16 bf16, materialised A/X) fwd+bwd [operator boundary 1]", "tokens/s", "bf16"
+        cfg = {"workload": wl.name, "batch_per_gpu": wl.B, "parallelism": f"replicas x{n_gpus}"}
     elif a.workload == "vit3d":
         wl = Vit3dWorkload(a.batch)
         steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 5
@@ -426,10 +483,11 @@ def main():
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
     else:
         from gfe_hip.step_bench import StepWorkload
-        wl = StepWorkload(a.batch, world=world, rank=rank, graph=a.graph, pipeline=not a.no_pipeline, distributed=distributed)
+        vol = (160, 160, 96) if a.volume == "native" else (96, 96, 96)
+        wl = StepWorkload(a.batch, world=world, rank=rank, vol=vol, graph=a.graph, pipeline=not a.no_pipeline, distributed=distributed)
         steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 10     # (a fresh box needs a few steps before clocks / page-ins settle)
-        metric, unit, dtype = "MRI volumes/sec (96^3 bf16) classify_mamba fwd+bwd", "volumes/s", "bf16"
-        cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "96x96x96",
+        metric, unit, dtype = "MRI volumes/sec (%s bf16) classify_mamba fwd+bwd" % ("96^3" if a.volume == "96" else "160x160x96"), "volumes/s", "bf16"
+        cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "x".join(map(str, vol)),
                "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
                "pipeline": ("generator(batch k+1) || head(batch k), 2 streams" + (", head replayed from a HIP graph" if getattr(wl, "graph_head", False) else "")) if wl.pipeline else "none"}
 

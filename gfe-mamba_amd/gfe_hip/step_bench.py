@@ -30,6 +30,8 @@ class StepWorkload:
 
     def __init__(self, batch, world=1, rank=0, vol=(96, 96, 96), graph=False, pipeline=True, distributed=None):
         self.batch, self.world, self.vol, self.graph, self.pipeline = batch, world, vol, graph, pipeline
+        self.vol_tag = "96^3" if tuple(vol) == (96, 96, 96) else "x".join(map(str, vol))
+        self.name = StepWorkload.name.replace("96^3", self.vol_tag)
         # The head (~450 launches: zero_grad, forward, loss, backward) can replay from a HIP graph inside the pipeline: host enqueue 8.5 ->
         # 3.8 ms per 11 ms step at B=8.  On one GPU at B=8 the eager head is 0.8 % faster (742-744 vs 734-739 volumes/s) and stays the
         # default; the graph is the default where the host is the risk: batches of 1-4 volumes (host-bound: 1.2-2.5x) and multi-rank runs
@@ -59,8 +61,10 @@ class StepWorkload:
             return self.step_obj.train_step_pipelined(*self.inputs, x_next=self.inputs[0])
         return self.step_obj.train_step(*self.inputs)
 
-    def roofline(self, iters=10):
-        """Dominant kernel = conv_igemm (3x3x3 convs of the generator): algorithmic FLOPs / its measured device time."""
+    def roofline(self, iters=50):
+        """Dominant kernel = conv_igemm (3x3x3 convs of the generator): algorithmic FLOPs / its measured device time, averaged over 50
+        back-to-back launches AFTER the timed steps have run (a warm chip at the clock it holds under matrix load: the figure the
+        rocprofv3 summary of the same command reproduces; a 10-launch burst on a cool chip read 8 % high in round 2)."""
         from . import nn_ops as K
         gen = self.step_obj.gen
         blk = gen.encoders[0].basic_module
@@ -88,9 +92,9 @@ class StepWorkload:
         flops = 2.0 * 27 * 64 * 64 * self.batch * self.vol[0] * self.vol[1] * self.vol[2]
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r02", "traffic_r02.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if self.batch == 8 else None,
-                "traffic_source": "profiles/r02/traffic_r02.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.batch == 8 else None,
-                "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @96^3, ReLU)", "launch_ms": round(ms, 4),
+                "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r02", "traffic_r02.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "traffic_source": "profiles/r02/traffic_r02.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @%s, ReLU)" % self.vol_tag, "launch_ms": round(ms, 4), "launches_timed": iters,
                 "algorithmic_flops": flops}
 
     def cpu_baseline(self):
@@ -111,7 +115,7 @@ class StepWorkload:
         loss.backward()
         dt = time.perf_counter() - t0
         return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "oracle/ref_ops.py (torch CPU fp32): generator fwd + head fwd/bwd on 1 volume of 96^3 (no optimiser)"}
+                "sample": "oracle/ref_ops.py (torch CPU fp32): generator fwd + head fwd/bwd on 1 volume of %s (no optimiser)" % self.vol_tag}
 
     def allreduce_stats(self, local=0, iters=10):
         """The step's only collective, timed alone on every rank (max over ranks): SUM all-reduce of the flat f32 gradient buffer.
@@ -135,4 +139,7 @@ class StepWorkload:
                 "busbw_GBs": round(2 * (n - 1) / n * nbytes / dt.item() / 1e9, 1), "ranks": n, "collective": "all_reduce(SUM) of the flat f32 gradient buffer, RCCL"}
 
     def extra(self):
+        if self.vol_tag != "96^3":         # conv FLOPs scale with the voxel count; the ViT / head GEMMs with d_cross and the patch size (not tabulated)
+            r = self.vol[0] * self.vol[1] * self.vol[2] / 96.0 ** 3
+            return {"generator_conv_gflop_per_volume": round(CONV_K3_GFLOP_PER_VOL * r, 1)}
         return {"generator_gflop_per_volume": GEN_GFLOP_PER_VOL, "head_gflop_per_sample": HEAD_GFLOP_PER_SAMPLE}

@@ -178,11 +178,11 @@ def _grad_and_update_errors(fx, names, params, opt):
     return worst
 
 
-def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag):
+def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag, models=None, batch=2):
     from gfe_hip import det_init as det
     from gfe_hip.step import ClassifyStep, build_models
-    gen, head, ft = build_models(vol=vol, dim=dim, depth=depth, heads=heads, seed=seed, **gen_kw)
-    x, x_cat, x_num, y = det.det_inputs(2, vol, seed=seed)
+    gen, head, ft = models if models is not None else build_models(vol=vol, dim=dim, depth=depth, heads=heads, seed=seed, **gen_kw)
+    x, x_cat, x_num, y = det.det_inputs(batch, vol, seed=seed)
     st = ClassifyStep(gen, head, ft)
     head.eval(); ft.eval()                          # fixtures were generated with dropout off
     st.opt.zero_grad()
@@ -227,6 +227,27 @@ def test_full_96_step_vs_reference_fixture():
     """T2 / BASELINE config 1: the full-size model on 2 volumes of 96^3 (reference run on CPU in the build container)."""
     fx = golden("t2_full96_step.npz")
     _check_step_fixture(fx, dict(f_maps=(64, 128, 256)), (96, 96, 96), 512, 6, 8, 21, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=8e-2, tag="T2 (config 1, 96^3)")
+
+
+def test_native_160x160x96_step_with_default_constructors_vs_reference_fixture():
+    """T7: the reference's OWN geometry (config/classify_mamba_config.yaml:5-7), the three modules built with exactly the constructor
+    calls of classify_mamba.py:36-56 -- no vol_size / in_features / d_cross: image (320,120) patch 40 (model.py:107-117), Linear(38 400, 4)
+    (classifier.py:327), d_cross 25 600 (mamba_transformer.py:84) -- the only geometry the authors' model.pt loads at.  20x20x12 conv tile
+    grids, LayerNorm(409 600), K = 409 600 skinny GEMMs, 25 600-wide K/V projections; one sample, reference run on CPU (tools/make_golden.py t7)."""
+    from classify.classifier import Combine_classfier_vit_mid
+    from cross_atten.mamba_transformer import Cross_mamba_both
+    from gfe_hip import det_init as det
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    fx = golden("t7_native_step.npz")
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(64, 128, 256))
+    head = Combine_classfier_vit_mid(seq_length=4)
+    ft = Cross_mamba_both(categories=(11, 2, 2, 4, 4, 3, 3), num_continuous=25, dim=512, dim_out=1, depth=6, heads=8, attn_dropout=0.1,
+                          ff_dropout=0.1, dim_head=512 // 8)
+    for m, pre in ((gen, "gen."), (head, "head."), (ft, "ft.")):
+        m.load_state_dict(det.det_state_dict(m.state_dict(), seed=71, prefix=pre))
+    models = (gen.to(DEV).eval(), head.to(DEV), ft.to(DEV))
+    _check_step_fixture(fx, None, (160, 160, 96), 512, 6, 8, 71, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=8e-2, tag="T7 (native 160x160x96)",
+                        models=models, batch=1)
 
 
 def test_head_alone_on_the_references_generator_outputs_meets_fp32_tolerance():

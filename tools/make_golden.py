@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -320,6 +320,29 @@ def t2(R, out):
     np.savez_compressed(os.path.join(out, "t2_full96_step.npz"), **fx)
 
 
+def t7(R, out):
+    """The reference's OWN geometry (config/classify_mamba_config.yaml:5-7: 160x160x96 volumes), the three modules built with exactly
+    the constructor calls of classify_mamba.py:36-56 -- nothing re-instantiated: image_size (320,120) / patch 40 (model.py:107-117),
+    Linear(320*120, 4) (classifier.py:327), d_cross = 160*160 (mamba_transformer.py:84) -- one sample, eval mode.  Also writes the
+    state-dict key -> shape listing of the three default-geometry modules (the layout the authors' checkpoints have)."""
+    import json
+    cards, n_cont, vol = (11, 2, 2, 4, 4, 3, 3), 25, (160, 160, 96)
+    gen = R.model.Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(64, 128, 256))
+    head = R.cls.Combine_classfier_vit_mid(seq_length=4)
+    ft = R.mt.Cross_mamba_both(categories=cards, num_continuous=n_cont, dim=512, dim_out=1, depth=6, heads=8, attn_dropout=0.1,
+                               ff_dropout=0.1, dim_head=512 // 8)
+    listing = {name: {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+               for name, m in (("gen", gen), ("head", head), ("ft", ft))}
+    with open(os.path.join(out, "t7_native_state_dict.json"), "w") as f:
+        json.dump(listing, f, indent=0, sort_keys=True)
+    load_det(gen, 71, "gen.")
+    load_det(head, 71, "head.")
+    load_det(ft, 71, "ft.")
+    fx = run_step(R, gen.eval(), head, ft, vol, 1, cards, n_cont, seed=71, full_grads=False)
+    fx["meta"] = np.array([160, 160, 96, 64, 128, 256, 512, 6, 8, 512, 4, 6, 64, 2048, 71])
+    np.savez_compressed(os.path.join(out, "t7_native_step.npz"), **fx)
+
+
 def t3(R, out):
     """Cross_mamba_ablation (cross_atten/mamba_transformer.py:254-385): the four forward variants + parameter gradients of each."""
     cards, n_cont, dim, depth, heads, vol, Bn = (5, 3, 2), 6, 64, 2, 8, (8, 12, 6), 3
@@ -432,7 +455,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
