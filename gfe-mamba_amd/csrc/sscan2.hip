@@ -141,114 +141,139 @@ __device__ __forceinline__ int xcd_paired_group(int x, int G) {
     return 2 * (xcd + 8 * (j >> 1)) + (j & 1);
 }
 
+// Wave-specialised block (round 3): 8 waves = 4 SCAN waves (0-3: the recurrence, one wave per SIMD as before) + 4 STAGING waves (4-7,
+// the SIMD partners of waves 0-3): fetch the next tile's rows, do the per-(t, channel) math (softplus, silu, products) once, park it in
+// the other LDS buffer, and write the previous tile's y rows out.  The scan waves' instruction stream loses a third of its issue slots'
+// worth of work (staging 30 + stores 12 of 128 cycles per step) to a partner that fills the slots the dependent h chain leaves idle,
+// and plain VALU instructions cost 2.7 instead of 6.5 cycles with two waves on a SIMD (profiles/r02/valu_rates.txt).  One barrier per tile.
 template <typename T, bool STATE_ONLY>
-__global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
+__global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     typedef typename Vec4<T>::type V4;
     __shared__ __attribute__((aligned(16))) Tile tiles[2];
     __shared__ __attribute__((aligned(16))) T ytile[2][TT * EPS];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
+    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
+    const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
+    const int nrows = t1 - t0;
+    // staging role of a thread: row sr of the tile, channels 4*sc .. 4*sc+3 of the block
+    const int sr = tid >> 3, sc = tid & 7;
+    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;
+
+    if (staging) {
+        const T* __restrict__ u = (const T*)p.u;
+        const T* __restrict__ dl = (const T*)p.delta;
+        const T* __restrict__ z = (const T*)p.z;
+        T* __restrict__ y = (T*)p.y;
+        const bool has_z = !STATE_ONLY && z != nullptr;
+        float sbias[4], sD[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
+            sD[k] = (!STATE_ONLY && p.D) ? p.D[e0 + 4 * sc + k] : 0.f;
+        }
+        // B / C role: threads 0-127 fetch B, 128-255 fetch C: row (tid & 127) >> 2 of the tile, floats 4q .. 4q+3
+        const int br = (tid & 127) >> 2, bq = tid & 3;
+        const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
+        V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero();
+        f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
+        // 64-bit bases once; per tile only a 32-bit row offset (rows past the chunk end: clamped here, masked in park)
+        const T* __restrict__ pu = u + rowbase;
+        const T* __restrict__ pd = dl + rowbase;
+        const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
+        const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
+        const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
+        const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
+        auto fetch = [&](int tb) {                                    // global -> registers, tile starting at step tb
+            const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
+            ru = *reinterpret_cast<const V4*>(pu + off);
+            rd = *reinterpret_cast<const V4*>(pd + off);
+            if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+            if (!STATE_ONLY || tid < 128) {
+                const int boff = min(tb - t0 + br, nrows - 1) * 16;
+                if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
+                else rbc = *reinterpret_cast<const f4*>(pbc + boff);
+            }
+        };
+        auto bc_rows = [&](int tb) -> f4 {                            // the fetched B / C quarter-row as f32 (zero past the end)
+            f4 v = rbc;
+            if (p.bc_bf16) {
+                const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
+                v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
+            }
+            return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto park = [&](Tile& tl, int tb) {                           // registers -> LDS (the per-(t, channel) math happens once, here)
+            float fu[4], fd[4], fz[4];
+            Vec4<T>::unpack(ru, fu); Vec4<T>::unpack(rd, fd);
+            if (has_z) Vec4<T>::unpack(rz, fz);
+            const bool valid = tb + sr < t1;
+            f4 vu, vg;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float raw = fd[k] + sbias[k];
+                float dt = p.softplus ? softplus_nb(raw) : raw;
+                if (!valid) dt = 0.f;                                 // a = exp2(0) = 1, dt*u = 0: steps past the end leave the state alone
+                tl.dt[dts_index(4 * sc + k, sr)] = dt;
+                tl.dtu[dts_index(4 * sc + k, sr)] = dt * fu[k];
+                vu[k] = sD[k] * fu[k];
+                vg[k] = has_z ? siluf_(fz[k]) : 1.f;
+            }
+            if (!STATE_ONLY) {
+                *reinterpret_cast<f4*>(&tl.epu[sr * EPS + 4 * sc]) = vu;
+                *reinterpret_cast<f4*>(&tl.epg[sr * EPS + 4 * sc]) = vg;
+            }
+            float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
+            if (!STATE_ONLY || tid < 128) {
+                const f4 v = bc_rows(tb);
+                *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
+                *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
+            }
+        };
+
+        fetch(t0);
+        park(tiles[0], t0);
+        if (t0 + TT < t1) fetch(t0 + TT);                             // the rows of tile k+1 are in flight while tile k-1's outputs go out
+        lds_barrier();
+        int cur = 0;
+        for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
+            const bool more = tb + TT < t1;
+            if (!STATE_ONLY && tb > t0) {                             // the previous tile's outputs: whole row segments, 4 channels per lane
+                const V4 yrow = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);
+                *reinterpret_cast<V4*>(y + rowbase + (size_t)(tb - TT - t0 + sr) * p.ED) = yrow;
+            }
+            if (more) {
+                park(tiles[cur ^ 1], tb + TT);
+                if (tb + 2 * TT < t1) fetch(tb + 2 * TT);
+            }
+            lds_barrier();
+        }
+        if (!STATE_ONLY) {
+            const int r = ((t1 - t0 - 1) / TT) * TT + sr;               // the last tile's outputs
+            if (r < nrows) *reinterpret_cast<V4*>(y + rowbase + (size_t)r * p.ED) = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);
+        }
+        return;
+    }
+
+    // ---- scan waves
+    __builtin_amdgcn_s_setprio(2);                                   // the dependent chain wins every issue arbitration against its staging partner
     const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
     const int cl = 8 * w + cw;                                   // channel within the block
-    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
     const int e = e0 + cl;
-    const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
-    const T* __restrict__ u = (const T*)p.u;
-    const T* __restrict__ dl = (const T*)p.delta;
-    const T* __restrict__ z = (const T*)p.z;
-    T* __restrict__ y = (T*)p.y;
-    const bool has_z = !STATE_ONLY && z != nullptr;
-
-    // staging role of this thread: row sr of the tile, channels 4*sc .. 4*sc+3 of the block
-    const int sr = tid >> 3, sc = tid & 7;
-    float sbias[4], sD[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
-        sD[k] = (!STATE_ONLY && p.D) ? p.D[e0 + 4 * sc + k] : 0.f;
-    }
-    // B / C role: threads 0-127 fetch B, 128-255 fetch C: row (tid & 127) >> 2 of the tile, floats 4q .. 4q+3
-    const int br = (tid & 127) >> 2, bq = tid & 3;
-    const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
-
     f2 A2 = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]} * GFE_LOG2E;
     f2 h = f2{0.f, 0.f};
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
     if (!STATE_ONLY && p.nchunks > 1) h = *reinterpret_cast<const f2*>(p.hstate + sbase);
     float sd = 0.f;
-
-    V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero();
-    f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
-    // 64-bit bases once; per tile only a 32-bit row offset (rows past the chunk end: clamped here, masked in park)
-    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;
-    const T* __restrict__ pu = u + rowbase;
-    const T* __restrict__ pd = dl + rowbase;
-    const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
-    const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
-    const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
-    const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
-    const int nrows = t1 - t0;
-    auto fetch = [&](int tb) {                                    // global -> registers, tile starting at step tb
-        const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
-        ru = *reinterpret_cast<const V4*>(pu + off);
-        rd = *reinterpret_cast<const V4*>(pd + off);
-        if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
-        if (!STATE_ONLY || tid < 128) {
-            const int boff = min(tb - t0 + br, nrows - 1) * 16;
-            if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
-            else rbc = *reinterpret_cast<const f4*>(pbc + boff);
-        }
-    };
-    auto bc_rows = [&](int tb) -> f4 {                            // the fetched B / C quarter-row as f32 (zero past the end)
-        f4 v = rbc;
-        if (p.bc_bf16) {
-            const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
-            v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
-        }
-        return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto park = [&](Tile& tl, int tb) {                           // registers -> LDS (the per-(t, channel) math happens once, here)
-        float fu[4], fd[4], fz[4];
-        Vec4<T>::unpack(ru, fu); Vec4<T>::unpack(rd, fd);
-        if (has_z) Vec4<T>::unpack(rz, fz);
-        const bool valid = tb + sr < t1;
-        f4 vu, vg;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float raw = fd[k] + sbias[k];
-            float dt = p.softplus ? softplus_nb(raw) : raw;
-            if (!valid) dt = 0.f;                                 // a = exp2(0) = 1, dt*u = 0: steps past the end leave the state alone
-            tl.dt[dts_index(4 * sc + k, sr)] = dt;
-            tl.dtu[dts_index(4 * sc + k, sr)] = dt * fu[k];
-            vu[k] = sD[k] * fu[k];
-            vg[k] = has_z ? siluf_(fz[k]) : 1.f;
-        }
-        if (!STATE_ONLY) {
-            *reinterpret_cast<f4*>(&tl.epu[sr * EPS + 4 * sc]) = vu;
-            *reinterpret_cast<f4*>(&tl.epg[sr * EPS + 4 * sc]) = vg;
-        }
-        float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
-        if (!STATE_ONLY || tid < 128) {
-            const f4 v = bc_rows(tb);
-            *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
-            *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
-        }
-    };
-
-    fetch(t0);
-    park(tiles[0], t0);
     lds_barrier();
     int cur = 0;
     S2_STAMP_DECL
     for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
-        const bool more = tb + TT < t1;
         S2_STAMP(0)
-        if (more) fetch(tb + TT);
-        V4 yrow = Vec4<T>::zero();
-        if (!STATE_ONLY && tb > t0) yrow = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);   // stored below, behind the first group's LDS reads
         if (!STATE_ONLY && p.ckpt)                                // every tile starts a segment (t0 is a multiple of SEG)
             *reinterpret_cast<f2*>(p.ckpt + ((((size_t)b * p.nseg + tb / SEG) * p.ED + e) * 16 + 2 * pr)) = h;
         const Tile& tl = tiles[cur];
-        // One wave per SIMD at B = 8: nothing hides an LDS round trip but the wave's own instruction stream, so the 14 reads of the
+        // Nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream, so the 14 reads of the
         // next 8-step group are issued before the current group's arithmetic (two register sets, pinned with sched_barrier).
         struct Grp { f4 dt4[2], du4[2], bc[8]; float epu, epg; };
         auto load_grp = [&](Grp& G, int g) {
@@ -284,8 +309,6 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
         Grp ga, gb;
         S2_STAMP(1)
         load_grp(ga, 0);
-        if (!STATE_ONLY && tb > t0)                               // the previous tile's outputs: whole row segments, 4 channels per lane
-            *reinterpret_cast<V4*>(y + rowbase + (size_t)(tb - TT - t0 + sr) * p.ED) = yrow;
 #pragma unroll
         for (int g = 0; g < TT / 8; g += 2) {
             load_grp(gb, g + 1);
@@ -298,8 +321,6 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         S2_STAMP(2)
-        if (more) park(tiles[cur ^ 1], tb + TT);
-        S2_STAMP(3)
         lds_barrier();
         S2_STAMP(4)
     }
@@ -307,9 +328,6 @@ __global__ __launch_bounds__(256) void sscan2_fwd_kernel(const S2Fwd p) {
     if (STATE_ONLY) {
         *reinterpret_cast<f2*>(p.hstate + sbase) = h;
         if (pr == 0) p.sdelta[((size_t)b * p.nchunks + c) * p.ED + e] = sd;
-    } else {
-        const int r = ((t1 - t0 - 1) / TT) * TT + sr;               // the last tile's outputs
-        if (r < nrows) *reinterpret_cast<V4*>(y + rowbase + (size_t)r * p.ED) = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);
     }
 }
 
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(256) void sscan2_carry_kernel(float* __restrict__ h
 
 template <typename T>
 int sscan2_fwd_launch(const S2Fwd& p, hipStream_t st) {
-    const dim3 blk(256), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
+    const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
     if (p.nchunks > 1) {
         hipLaunchKernelGGL((sscan2_fwd_kernel<T, true>), grid, blk, 0, st, p);
         hipLaunchKernelGGL((sscan2_carry_kernel<false>), dim3((unsigned)ceil_div((int64_t)16 * p.ED, 256), p.B), dim3(256), 0, st,
@@ -375,7 +393,7 @@ struct S2Bwd {
 };
 
 constexpr int RSL = TT * 32 + 8;   // slab stride: + 8 floats so that the four (channel & 3) slabs of one ds_write_b64 fall on disjoint banks
-struct BTile {
+struct BStage {                  // what the staging waves park for one 32-step segment (double-buffered)
     float dt[CB * TT];           // [channel][step] (dts_index)  softplus(delta + bias), 0 past the end
     float dtu[CB * TT];          //                              dt * u
     float g[CB * TT];            //                              dL/dy_scan = dy * silu(z) (dy without a gate), 0 past the end
@@ -385,7 +403,6 @@ struct BTile {
     float eg[TT * EPS];
     float egz[TT * EPS];         //   dy * d silu(z)/dz
     f4 bc[TT * 8];               // [step][pair] {B[2p], B[2p+1], C[2p], C[2p+1]}
-    float red[16 * RSL];         // [wave][channel & 3] slabs of [step][16 dB | 16 dC]: partial sums over the two channels of a wave that share (channel & 3)
 };
 
 // One block = 32 channels x one chunk, segments of 32 steps walked from the chunk's end to its start:
@@ -393,31 +410,156 @@ struct BTile {
 //   states: 128 registers), then run the adjoint over the same steps -- no exp beyond the recompute's.
 //   Sums over states (d(dt*u), d dt, and y for dz) go through the pair butterflies, sums over channels (dB, dC) through
 //   v_permlane32_swap + quad DPP adds into an LDS slab that the block folds over its waves and adds to memory two steps per atomic.
-// STATE_ONLY (K1' of the chunked plan): only the local adjoint carry q of the chunk from q = 0.
+// Wave-specialised like the forward (round 3): waves 0-3 run the recurrence and its adjoint, waves 4-7 (their SIMD partners) fetch and
+// stage the next segment into the other LDS buffer, write the previous segment's du / ddelta / dz rows out and fold + publish its dB / dC
+// rows.  Two barriers per segment: A (segment start: staging buffer ready, previous segment's outputs complete) and B (between recompute
+// and adjoint: the previous outputs have been drained, the adjoint may overwrite `red` / `otile`).
+// STATE_ONLY (K1' of the chunked plan): only the local adjoint carry q of the chunk from q = 0 (one barrier per segment).
 template <typename T, bool STATE_ONLY>
-__global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
+__global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     typedef typename Vec4<T>::type V4;
-    __shared__ __attribute__((aligned(16))) BTile tl;
+    __shared__ __attribute__((aligned(16))) BStage stg[2];
+    __shared__ __attribute__((aligned(16))) float red[STATE_ONLY ? 4 : 16 * RSL];   // [wave][channel & 3] slabs of [step][16 dB | 16 dC]
     __shared__ __attribute__((aligned(16))) T otile[3][TT * EPS];       // du, ddelta, dz rows on their way out
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
+    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
+    const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
+    const int nrows = t1 - t0;
+    const int nsegc = (t1 - t0 + TT - 1) / TT;
+    const bool has_z = p.z != nullptr;
+    const int sr = tid >> 3, sc = tid & 7;
+    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;      // 64-bit bases once; per segment only a 32-bit row offset
+
+    if (staging) {
+        const T* __restrict__ u = (const T*)p.u;
+        const T* __restrict__ dl = (const T*)p.delta;
+        const T* __restrict__ z = (const T*)p.z;
+        const T* __restrict__ dy = (const T*)p.dy;
+        float sbias[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
+        const int br = (tid & 127) >> 2, bq = tid & 3;
+        const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
+        V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero(), rg = Vec4<T>::zero();
+        f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
+        const T* __restrict__ pu = u + rowbase;
+        const T* __restrict__ pd = dl + rowbase;
+        const T* __restrict__ pg = dy + rowbase;
+        const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
+        const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
+        const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
+        const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
+        auto fetch = [&](int tb) {                                    // rows past the end: clamped here, masked in park
+            const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
+            if (!STATE_ONLY) ru = *reinterpret_cast<const V4*>(pu + off);
+            rd = *reinterpret_cast<const V4*>(pd + off);
+            rg = *reinterpret_cast<const V4*>(pg + off);
+            if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+            if (!STATE_ONLY || tid >= 128) {
+                const int boff = min(tb - t0 + br, nrows - 1) * 16;
+                if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
+                else rbc = *reinterpret_cast<const f4*>(pbc + boff);
+            }
+        };
+        auto bc_rows = [&](int tb) -> f4 {
+            f4 v = rbc;
+            if (p.bc_bf16) {
+                const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
+                v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
+            }
+            return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto park = [&](BStage& tl, int tb) {
+            float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4];
+            if (!STATE_ONLY) Vec4<T>::unpack(ru, fu);
+            Vec4<T>::unpack(rd, fd); Vec4<T>::unpack(rg, fg);
+            if (has_z) Vec4<T>::unpack(rz, fz);
+            const bool valid = tb + sr < t1;
+            f4 vu, vdt, vsg, vg, vgz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float raw = fd[k] + sbias[k];
+                float sg = 1.f;
+                float dt = softplus_nb(raw, &sg);
+                if (!p.softplus) { dt = raw; sg = 1.f; }
+                float gg = fg[k], gz = 0.f;
+                if (has_z) {
+                    const float sz = sigmoidf_(fz[k]);
+                    gz = fg[k] * sz * (1.f + fz[k] * (1.f - sz));          // dy * d/dz [z sigmoid(z)]
+                    gg = fg[k] * fz[k] * sz;
+                }
+                if (!valid) { dt = 0.f; sg = 0.f; gg = 0.f; gz = 0.f; }
+                const int ix = dts_index(4 * sc + k, sr);
+                tl.dt[ix] = dt;
+                if (!STATE_ONLY) tl.dtu[ix] = dt * fu[k];
+                tl.g[ix] = gg;
+                vu[k] = fu[k]; vdt[k] = dt; vsg[k] = sg; vg[k] = gg; vgz[k] = gz;
+            }
+            if (!STATE_ONLY) {
+                *reinterpret_cast<f4*>(&tl.eu[sr * EPS + 4 * sc]) = vu;
+                *reinterpret_cast<f4*>(&tl.edt[sr * EPS + 4 * sc]) = vdt;
+                *reinterpret_cast<f4*>(&tl.esg[sr * EPS + 4 * sc]) = vsg;
+                *reinterpret_cast<f4*>(&tl.eg[sr * EPS + 4 * sc]) = vg;
+                if (has_z) *reinterpret_cast<f4*>(&tl.egz[sr * EPS + 4 * sc]) = vgz;
+            }
+            float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
+            if (!STATE_ONLY || tid >= 128) {
+                const f4 v = bc_rows(tb);
+                *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
+                *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
+            }
+        };
+        // ---- rows out, and the block's dB / dC rows, of the segment that starts at step tb.  Wave w folds the 16 partial slabs for steps
+        // 8w .. 8w+7 with ds_read_b128, writes the sums back as rows of 32 (its own rows: no barrier, only its own lgkmcnt) and adds them to
+        // memory as contiguous 64-lane atomics -- two steps x (16 dB | 16 dC) per instruction, the access shape float atomics run at full rate on.
+        auto drain = [&](int tb) {
+            const int r = tb - t0 + sr;
+            if (r < nrows) {
+                const size_t off = rowbase + (size_t)r * p.ED;
+                *reinterpret_cast<V4*>((T*)p.du + off) = *reinterpret_cast<const V4*>(&otile[0][sr * EPS + 4 * sc]);
+                *reinterpret_cast<V4*>((T*)p.ddelta + off) = *reinterpret_cast<const V4*>(&otile[1][sr * EPS + 4 * sc]);
+                if (has_z) *reinterpret_cast<V4*>((T*)p.dz + off) = *reinterpret_cast<const V4*>(&otile[2][sr * EPS + 4 * sc]);
+            }
+            const int ts = 8 * w + (lane >> 3), jq = (lane & 7) * 4;
+            f4 acc = *reinterpret_cast<const f4*>(&red[ts * 32 + jq]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) acc += *reinterpret_cast<const f4*>(&red[k * RSL + ts * 32 + jq]);
+            *reinterpret_cast<f4*>(&red[ts * 32 + jq]) = acc;          // slab 0, this wave's rows only
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = lane + 64 * i, t2 = 8 * w + (v >> 5), j = v & 31;
+                const float sum = red[t2 * 32 + j];
+                if (tb + t2 < t1) atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * 16 + (j & 15), sum);
+            }
+        };
+
+        fetch(t0 + (nsegc - 1) * TT);
+        park(stg[0], t0 + (nsegc - 1) * TT);
+        if (nsegc > 1) fetch(t0 + (nsegc - 2) * TT);
+        lds_barrier();                                                   // A_0
+        for (int k = nsegc - 1, i = 0; k >= 0; --k, ++i) {
+            const int tb = t0 + k * TT;
+            if (!STATE_ONLY) {
+                if (i > 0) drain(tb + TT);
+                lds_barrier();                                           // B_i
+            }
+            if (k > 0) {
+                park(stg[(i + 1) & 1], tb - TT);
+                if (k > 1) fetch(tb - 2 * TT);
+            }
+            lds_barrier();                                               // A_{i+1}
+        }
+        if (!STATE_ONLY) drain(t0);
+        return;
+    }
+
+    // ---- scan waves
+    __builtin_amdgcn_s_setprio(2);
     const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
     const int cl = 8 * w + cw;
-    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
     const int e = e0 + cl;
-    const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
-    const T* __restrict__ u = (const T*)p.u;
-    const T* __restrict__ dl = (const T*)p.delta;
-    const T* __restrict__ z = (const T*)p.z;
-    const T* __restrict__ dy = (const T*)p.dy;
-    const bool has_z = z != nullptr;
-
-    const int sr = tid >> 3, sc = tid & 7;
-    float sbias[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
-    const int br = (tid & 127) >> 2, bq = tid & 3;
-    const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
-
     const f2 An = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
     const f2 A2 = An * GFE_LOG2E;
     const float Dv = p.D ? p.D[e] : 0.f;
@@ -426,100 +568,19 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
     if (!STATE_ONLY && p.nchunks > 1) q = *reinterpret_cast<const f2*>(p.qstate + sbase);
     f2 dAacc = f2{0.f, 0.f};
     float dDacc = 0.f, dbacc = 0.f;
-
-    V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero(), rg = Vec4<T>::zero();
-    f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
-    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;      // 64-bit bases once; per segment only a 32-bit row offset
-    const T* __restrict__ pu = u + rowbase;
-    const T* __restrict__ pd = dl + rowbase;
-    const T* __restrict__ pg = dy + rowbase;
-    const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
-    const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
-    const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
-    const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
-    const int nrows = t1 - t0;
-    auto fetch = [&](int tb) {                                    // rows past the end: clamped here, masked in park
-        const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
-        if (!STATE_ONLY) ru = *reinterpret_cast<const V4*>(pu + off);
-        rd = *reinterpret_cast<const V4*>(pd + off);
-        rg = *reinterpret_cast<const V4*>(pg + off);
-        if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
-        if (!STATE_ONLY || tid >= 128) {
-            const int boff = min(tb - t0 + br, nrows - 1) * 16;
-            if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
-            else rbc = *reinterpret_cast<const f4*>(pbc + boff);
-        }
-    };
-    auto bc_rows = [&](int tb) -> f4 {
-        f4 v = rbc;
-        if (p.bc_bf16) {
-            const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
-            v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
-        }
-        return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto park = [&](int tb) {
-        float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4];
-        if (!STATE_ONLY) Vec4<T>::unpack(ru, fu);
-        Vec4<T>::unpack(rd, fd); Vec4<T>::unpack(rg, fg);
-        if (has_z) Vec4<T>::unpack(rz, fz);
-        const bool valid = tb + sr < t1;
-        f4 vu, vdt, vsg, vg, vgz;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float raw = fd[k] + sbias[k];
-            float sg = 1.f;
-            float dt = softplus_nb(raw, &sg);
-            if (!p.softplus) { dt = raw; sg = 1.f; }
-            float gg = fg[k], gz = 0.f;
-            if (has_z) {
-                const float sz = sigmoidf_(fz[k]);
-                gz = fg[k] * sz * (1.f + fz[k] * (1.f - sz));          // dy * d/dz [z sigmoid(z)]
-                gg = fg[k] * fz[k] * sz;
-            }
-            if (!valid) { dt = 0.f; sg = 0.f; gg = 0.f; gz = 0.f; }
-            const int ix = dts_index(4 * sc + k, sr);
-            tl.dt[ix] = dt;
-            if (!STATE_ONLY) tl.dtu[ix] = dt * fu[k];
-            tl.g[ix] = gg;
-            vu[k] = fu[k]; vdt[k] = dt; vsg[k] = sg; vg[k] = gg; vgz[k] = gz;
-        }
-        if (!STATE_ONLY) {
-            *reinterpret_cast<f4*>(&tl.eu[sr * EPS + 4 * sc]) = vu;
-            *reinterpret_cast<f4*>(&tl.edt[sr * EPS + 4 * sc]) = vdt;
-            *reinterpret_cast<f4*>(&tl.esg[sr * EPS + 4 * sc]) = vsg;
-            *reinterpret_cast<f4*>(&tl.eg[sr * EPS + 4 * sc]) = vg;
-            if (has_z) *reinterpret_cast<f4*>(&tl.egz[sr * EPS + 4 * sc]) = vgz;
-        }
-        float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
-        if (!STATE_ONLY || tid >= 128) {
-            const f4 v = bc_rows(tb);
-            *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
-            *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
-        }
-    };
-
-    const int nsegc = (t1 - t0 + TT - 1) / TT;
-    fetch(t0 + (nsegc - 1) * TT);
-    // the segment's start state: fetched one segment ahead too (wanted by the very first instruction of phase 1: an HBM round trip there
+    // the segment's start state: fetched one segment ahead (wanted by the very first instruction of phase 1: an HBM round trip there
     // cost 1 300 cycles per segment)
     const float* __restrict__ pck = STATE_ONLY ? nullptr : p.ckpt + (((size_t)b * p.nseg + t0 / SEG) * p.ED + e) * 16 + 2 * pr;
     const size_t ckstride = (size_t)p.ED * 16;
     f2 hck_next = f2{0.f, 0.f};
     if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(nsegc - 1) * ckstride);
+    lds_barrier();                                                       // A_0
     S2_STAMP_DECL
-    for (int k = nsegc - 1; k >= 0; --k) {
-        const int tb = t0 + k * TT;
-        S2_STAMP(0)
-        park(tb);
-        S2_STAMP(1)
-        lds_barrier();
+    for (int k = nsegc - 1, i = 0; k >= 0; --k, ++i) {
+        const BStage& tl = stg[i & 1];
         S2_STAMP(2)
         const f2 hck = hck_next;
-        if (k > 0) {
-            fetch(tb - TT);
-            if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(k - 1) * ckstride);
-        }
+        if (k > 0 && !STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(k - 1) * ckstride);
         S2_STAMP(7)
 
         if (STATE_ONLY) {
@@ -535,13 +596,13 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
                     q = a * (f2{bc.z, bc.w} * g4[s] + q);
                 }
             }
-            lds_barrier();
+            lds_barrier();                                               // A_{i+1}
             continue;
         }
 
         // ---- phase 1: the segment's states, forward from the checkpoint; phase 2: the adjoint, last step first.
-        // Work unit = 4 steps.  As in the forward, the LDS reads of the NEXT unit are issued ahead of the current unit's arithmetic (one
-        // wave per SIMD: nothing else hides the round trip): two register sets X / Y by unit parity, pinned with sched_barrier.
+        // Work unit = 4 steps.  As in the forward, the LDS reads of the NEXT unit are issued ahead of the current unit's arithmetic:
+        // two register sets X / Y by unit parity, pinned with sched_barrier.
         f2 av[TT], hs[TT];
         float yred[TT / 8];
         struct H4 { f4 dt4, du4, g4, bc[4]; };
@@ -591,12 +652,12 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
                 dAacc += da * dtv;
                 ddt_p[4 * (qd & 1) + s] = fmaf(da.y, An.y, da.x * An.x);
                 // dB / dC sum over channels.  In the wave: v_permlane32_swap pairs dB with dC (lanes < 32 end up with the dB sum over lane
-                // bit 5, lanes >= 32 with the dC sum).  The remaining 4 (channel & 3) x 4 (wave) partials are folded by the block from LDS
-                // below: every lane stores, so there is no exec masking and no basic-block break inside the unrolled steps.
+                // bit 5, lanes >= 32 with the dC sum).  The remaining 4 (channel & 3) x 4 (wave) partials are folded by the staging waves from
+                // LDS: every lane stores, so there is no exec masking and no basic-block break inside the unrolled steps.
                 // (ds_add_f32 into one shared row instead was 15x slower: ~900 cycles per instruction with 4 lanes per address.)
                 const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.x), __float_as_uint(dC.x), false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.y), __float_as_uint(dC.y), false, false);
-                *reinterpret_cast<f2*>(&tl.red[(w * 4 + (lane & 3)) * RSL + t * 32 + (lane >> 5) * 16 + 2 * pr]) =
+                *reinterpret_cast<f2*>(&red[(w * 4 + (lane & 3)) * RSL + t * 32 + (lane >> 5) * 16 + 2 * pr]) =
                     f2{__uint_as_float(sx[0]) + __uint_as_float(sx[1]), __uint_as_float(sy[0]) + __uint_as_float(sy[1])};
             }
             if ((qd & 1) == 0) {                                           // group complete: the lane that owns (step r, channel cl) finishes it
@@ -626,6 +687,8 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
             load_u(Y, 7); load_g(Y, 7); SB; fwd_u(X, 6); SB;
             load_g(X, 6); load_own(oa, 3); SB; fwd_u(Y, 7); SB;
             S2_STAMP(3)
+            lds_barrier();                                               // B_i: the previous segment's red / otile have been drained
+            SB;
             bwd_u(Y, oa, 7); SB;
             load_u(Y, 5); load_g(Y, 5); SB; bwd_u(X, oa, 6); SB;
             load_u(X, 4); load_g(X, 4); load_own(ob, 2); SB; bwd_u(Y, ob, 5); SB;
@@ -638,34 +701,8 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
         }
 #undef SB
         S2_STAMP(4)
-        lds_barrier();
+        lds_barrier();                                                   // A_{i+1}
         S2_STAMP(5)
-        // ---- rows out, and the block's dB / dC rows.  Wave w folds the 16 partial slabs for steps 8w .. 8w+7 with ds_read_b128, writes
-        // the sums back as rows of 32 (its own rows: no barrier, only its own lgkmcnt) and adds them to memory as contiguous 64-lane
-        // atomics -- two steps x (16 dB | 16 dC) per instruction, the access shape float atomics run at full rate on.
-        {
-            const int r = tb - t0 + sr;
-            if (r < nrows) {
-                const size_t off = rowbase + (size_t)r * p.ED;
-                *reinterpret_cast<V4*>((T*)p.du + off) = *reinterpret_cast<const V4*>(&otile[0][sr * EPS + 4 * sc]);
-                *reinterpret_cast<V4*>((T*)p.ddelta + off) = *reinterpret_cast<const V4*>(&otile[1][sr * EPS + 4 * sc]);
-                if (has_z) *reinterpret_cast<V4*>((T*)p.dz + off) = *reinterpret_cast<const V4*>(&otile[2][sr * EPS + 4 * sc]);
-            }
-            const int ts = 8 * w + (lane >> 3), jq = (lane & 7) * 4;
-            f4 acc = *reinterpret_cast<const f4*>(&tl.red[ts * 32 + jq]);
-#pragma unroll
-            for (int k = 1; k < 16; ++k) acc += *reinterpret_cast<const f4*>(&tl.red[k * RSL + ts * 32 + jq]);
-            *reinterpret_cast<f4*>(&tl.red[ts * 32 + jq]) = acc;          // slab 0, this wave's rows only
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int v = lane + 64 * i, t2 = 8 * w + (v >> 5), j = v & 31;
-                const float sum = tl.red[t2 * 32 + j];
-                if (tb + t2 < t1) atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * 16 + (j & 15), sum);
-            }
-        }
-        // (the next park() only touches the staging arrays; its barrier orders these reads of otile / red before the next writes)
-        S2_STAMP(6)
     }
     S2_STAMP_FLUSH(16)
     if (STATE_ONLY) {
@@ -686,7 +723,7 @@ __global__ __launch_bounds__(256) void sscan2_bwd_kernel(const S2Bwd p) {
 
 template <typename T>
 int sscan2_bwd_launch(const S2Bwd& p, hipStream_t st) {
-    const dim3 blk(256), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
+    const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
     if (p.nchunks > 1) {
         hipLaunchKernelGGL((sscan2_bwd_kernel<T, true>), grid, blk, 0, st, p);
         hipLaunchKernelGGL((sscan2_carry_kernel<true>), dim3((unsigned)ceil_div((int64_t)16 * p.ED, 256), p.B), dim3(256), 0, st,
