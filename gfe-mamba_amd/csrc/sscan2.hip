@@ -41,6 +41,8 @@ struct S2Fwd {
     const void* u; const void* delta; const void* z; const void* Bm; const void* Cm;      // Bm / Cm: f32 or bf16 rows (bc_bf16)
     const float* A; const float* D; const float* dbias;
     void* y;
+    void* yscan;        // (B, L, ED) or NULL: the scan's output BEFORE the gate, hs.C + D*u (the backward's dz = dy * silu'(z) * yscan needs it;
+                        // saving it costs one more output row per step and spares the backward a sum over states per step)
     float* hstate;      // (B, nchunks, ED, 16): K1 writes local end states, K2 turns them into chunk-start states, K3 reads
     float* sdelta;      // (B, nchunks, ED): sum of dt over the chunk (the chunk's decay is exp(A * sum dt): no products)
     float* ckpt;        // (B, nseg, ED, 16) state at the START of every 32-step segment, or NULL (no backward wanted)
@@ -110,11 +112,15 @@ __device__ __forceinline__ float reduce_pairs8(const float (&v)[8]) {
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
     typedef f4 type;
+    static __device__ __forceinline__ type pack(const f4& v) { return v; }
     static __device__ __forceinline__ void unpack(const type& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
     static __device__ __forceinline__ type zero() { return type{0.f, 0.f, 0.f, 0.f}; }
 };
 template <> struct Vec4<bf16_t> {
     typedef uint2 type;
+    static __device__ __forceinline__ type pack(const f4& v) {
+        return make_uint2((uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16), (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16));
+    }
     static __device__ __forceinline__ void unpack(const type& v, float (&o)[4]) {
         o[0] = bf16lo_to_f32(v.x); o[1] = bf16hi_to_f32(v.x); o[2] = bf16lo_to_f32(v.y); o[3] = bf16hi_to_f32(v.y);
     }
@@ -150,7 +156,7 @@ template <typename T, bool STATE_ONLY>
 __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     typedef typename Vec4<T>::type V4;
     __shared__ __attribute__((aligned(16))) Tile tiles[2];
-    __shared__ __attribute__((aligned(16))) T ytile[2][TT * EPS];
+    __shared__ __attribute__((aligned(16))) float ytile[2][TT * EPS];           // hs.C + D*u of the tile (f32: gated and rounded once, on the way out)
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
     const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
     const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         const T* __restrict__ dl = (const T*)p.delta;
         const T* __restrict__ z = (const T*)p.z;
         T* __restrict__ y = (T*)p.y;
+        T* __restrict__ ysc = (T*)p.yscan;
         const bool has_z = !STATE_ONLY && z != nullptr;
         float sbias[4], sD[4];
 #pragma unroll
@@ -231,6 +238,16 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
             }
         };
 
+        // a finished tile's outputs: whole row segments, 4 channels per lane; the gate silu(z) of that tile is still in its staging buffer
+        auto rows_out = [&](int buf, int r) {
+            const f4 yb = *reinterpret_cast<const f4*>(&ytile[buf][sr * EPS + 4 * sc]);
+            const f4 g = *reinterpret_cast<const f4*>(&tiles[buf].epg[sr * EPS + 4 * sc]);
+            if (r < nrows) {
+                const size_t off = rowbase + (size_t)r * p.ED;
+                *reinterpret_cast<V4*>(y + off) = Vec4<T>::pack(yb * g);
+                if (ysc) *reinterpret_cast<V4*>(ysc + off) = Vec4<T>::pack(yb);
+            }
+        };
         fetch(t0);
         park(tiles[0], t0);
         if (t0 + TT < t1) fetch(t0 + TT);                             // the rows of tile k+1 are in flight while tile k-1's outputs go out
@@ -238,20 +255,14 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         int cur = 0;
         for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
             const bool more = tb + TT < t1;
-            if (!STATE_ONLY && tb > t0) {                             // the previous tile's outputs: whole row segments, 4 channels per lane
-                const V4 yrow = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);
-                *reinterpret_cast<V4*>(y + rowbase + (size_t)(tb - TT - t0 + sr) * p.ED) = yrow;
-            }
+            if (!STATE_ONLY && tb > t0) rows_out(cur ^ 1, tb - TT - t0 + sr);   // (before park() reuses that buffer)
             if (more) {
                 park(tiles[cur ^ 1], tb + TT);
                 if (tb + 2 * TT < t1) fetch(tb + 2 * TT);
             }
             lds_barrier();
         }
-        if (!STATE_ONLY) {
-            const int r = ((t1 - t0 - 1) / TT) * TT + sr;               // the last tile's outputs
-            if (r < nrows) *reinterpret_cast<V4*>(y + rowbase + (size_t)r * p.ED) = *reinterpret_cast<const V4*>(&ytile[cur ^ 1][sr * EPS + 4 * sc]);
-        }
+        if (!STATE_ONLY) rows_out(cur ^ 1, ((t1 - t0 - 1) / TT) * TT + sr);     // the last tile
         return;
     }
 
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         const Tile& tl = tiles[cur];
         // Nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream, so the 14 reads of the
         // next 8-step group are issued before the current group's arithmetic (two register sets, pinned with sched_barrier).
-        struct Grp { f4 dt4[2], du4[2], bc[8]; float epu, epg; };
+        struct Grp { f4 dt4[2], du4[2], bc[8]; float epu; };
         auto load_grp = [&](Grp& G, int g) {
 #pragma unroll
             for (int j4 = 0; j4 < 2; ++j4) {
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) G.bc[s] = tl.bc[(8 * g + s) * 8 + pr];
-            if (!STATE_ONLY) { G.epu = tl.epu[(8 * g + pr) * EPS + cl]; G.epg = tl.epg[(8 * g + pr) * EPS + cl]; }
+            if (!STATE_ONLY) G.epu = tl.epu[(8 * g + pr) * EPS + cl];
         };
         auto run_grp = [&](const Grp& G, int g) {
             float yv[8];
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
             }
             if (!STATE_ONLY) {
                 const float ys = reduce_pairs8(yv);                // this lane: step 8g + pr of channel cl
-                IO<T>::st(&ytile[cur][(8 * g + pr) * EPS + cl], (ys + G.epu) * G.epg);
+                ytile[cur][(8 * g + pr) * EPS + cl] = ys + G.epu;
             }
         };
         Grp ga, gb;
@@ -381,6 +392,7 @@ int sscan2_fwd_launch(const S2Fwd& p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 struct S2Bwd {
     const void* u; const void* delta; const void* z; const void* Bm; const void* Cm; const void* dy;
+    const void* yscan;                  // (B, L, ED): hs.C + D*u as left by the forward (needed with a gate: dz = dy * silu'(z) * yscan)
     const float* A; const float* D; const float* dbias;
     void* du; void* ddelta; void* dz;
     float* dAws;                        // (ED, 16) f32, zeroed, accumulated atomically (once per lane and chunk)
@@ -401,14 +413,14 @@ struct BStage {                  // what the staging waves park for one 32-step 
     float edt[TT * EPS];
     float esg[TT * EPS];         //   d softplus / d raw = sigmoid(raw) (1 without softplus), 0 past the end
     float eg[TT * EPS];
-    float egz[TT * EPS];         //   dy * d silu(z)/dz
     f4 bc[TT * 8];               // [step][pair] {B[2p], B[2p+1], C[2p], C[2p+1]}
 };
 
 // One block = 32 channels x one chunk, segments of 32 steps walked from the chunk's end to its start:
 //   recompute the segment forward from its checkpoint, keeping a_t = exp(dt_t A) and h_t of all 32 steps in registers (a lane owns two
 //   states: 128 registers), then run the adjoint over the same steps -- no exp beyond the recompute's.
-//   Sums over states (d(dt*u), d dt, and y for dz) go through the pair butterflies, sums over channels (dB, dC) through
+//   Sums over states (d(dt*u), d dt) go through the pair butterflies (dz needs the forward's pre-gate output, which the forward saved:
+//   it is finished by the staging waves, element-wise, on the way in), sums over channels (dB, dC) through
 //   v_permlane32_swap + quad DPP adds into an LDS slab that the block folds over its waves and adds to memory two steps per atomic.
 // Wave-specialised like the forward (round 3): waves 0-3 run the recurrence and its adjoint, waves 4-7 (their SIMD partners) fetch and
 // stage the next segment into the other LDS buffer, write the previous segment's du / ddelta / dz rows out and fold + publish its dB / dC
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     typedef typename Vec4<T>::type V4;
     __shared__ __attribute__((aligned(16))) BStage stg[2];
     __shared__ __attribute__((aligned(16))) float red[STATE_ONLY ? 4 : 16 * RSL];   // [wave][channel & 3] slabs of [step][16 dB | 16 dC]
-    __shared__ __attribute__((aligned(16))) T otile[3][TT * EPS];       // du, ddelta, dz rows on their way out
+    __shared__ __attribute__((aligned(16))) T otile[2][TT * EPS];       // du, ddelta rows on their way out
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
     const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
     const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
@@ -436,17 +448,19 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         const T* __restrict__ dl = (const T*)p.delta;
         const T* __restrict__ z = (const T*)p.z;
         const T* __restrict__ dy = (const T*)p.dy;
+        const T* __restrict__ ysc = (const T*)p.yscan;
         float sbias[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
         const int br = (tid & 127) >> 2, bq = tid & 3;
         const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
-        V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero(), rg = Vec4<T>::zero();
+        V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero(), rg = Vec4<T>::zero(), ry = Vec4<T>::zero();
         f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
         const T* __restrict__ pu = u + rowbase;
         const T* __restrict__ pd = dl + rowbase;
         const T* __restrict__ pg = dy + rowbase;
         const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
+        const T* __restrict__ py = (has_z && !STATE_ONLY) ? ysc + rowbase : nullptr;
         const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
         const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
         const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
@@ -456,6 +470,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
             rd = *reinterpret_cast<const V4*>(pd + off);
             rg = *reinterpret_cast<const V4*>(pg + off);
             if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+            if (has_z && !STATE_ONLY) ry = *reinterpret_cast<const V4*>(py + off);
             if (!STATE_ONLY || tid >= 128) {
                 const int boff = min(tb - t0 + br, nrows - 1) * 16;
                 if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
@@ -471,10 +486,11 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
             return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
         };
         auto park = [&](BStage& tl, int tb) {
-            float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4];
+            float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4], fy[4] = {0.f, 0.f, 0.f, 0.f};
             if (!STATE_ONLY) Vec4<T>::unpack(ru, fu);
             Vec4<T>::unpack(rd, fd); Vec4<T>::unpack(rg, fg);
             if (has_z) Vec4<T>::unpack(rz, fz);
+            if (has_z && !STATE_ONLY) Vec4<T>::unpack(ry, fy);
             const bool valid = tb + sr < t1;
             f4 vu, vdt, vsg, vg, vgz;
 #pragma unroll
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 float gg = fg[k], gz = 0.f;
                 if (has_z) {
                     const float sz = sigmoidf_(fz[k]);
-                    gz = fg[k] * sz * (1.f + fz[k] * (1.f - sz));          // dy * d/dz [z sigmoid(z)]
+                    gz = fg[k] * sz * (1.f + fz[k] * (1.f - sz)) * fy[k];  // dz = dy * d/dz [z sigmoid(z)] * (hs.C + D*u)
                     gg = fg[k] * fz[k] * sz;
                 }
                 if (!valid) { dt = 0.f; sg = 0.f; gg = 0.f; gz = 0.f; }
@@ -501,7 +517,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 *reinterpret_cast<f4*>(&tl.edt[sr * EPS + 4 * sc]) = vdt;
                 *reinterpret_cast<f4*>(&tl.esg[sr * EPS + 4 * sc]) = vsg;
                 *reinterpret_cast<f4*>(&tl.eg[sr * EPS + 4 * sc]) = vg;
-                if (has_z) *reinterpret_cast<f4*>(&tl.egz[sr * EPS + 4 * sc]) = vgz;
+                if (has_z && valid) *reinterpret_cast<V4*>((T*)p.dz + rowbase + (size_t)(tb - t0 + sr) * p.ED) = Vec4<T>::pack(vgz);   // finished here
             }
             float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
             if (!STATE_ONLY || tid >= 128) {
@@ -519,7 +535,6 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 const size_t off = rowbase + (size_t)r * p.ED;
                 *reinterpret_cast<V4*>((T*)p.du + off) = *reinterpret_cast<const V4*>(&otile[0][sr * EPS + 4 * sc]);
                 *reinterpret_cast<V4*>((T*)p.ddelta + off) = *reinterpret_cast<const V4*>(&otile[1][sr * EPS + 4 * sc]);
-                if (has_z) *reinterpret_cast<V4*>((T*)p.dz + off) = *reinterpret_cast<const V4*>(&otile[2][sr * EPS + 4 * sc]);
             }
             const int ts = 8 * w + (lane >> 3), jq = (lane & 7) * 4;
             f4 acc = *reinterpret_cast<const f4*>(&red[ts * 32 + jq]);
@@ -604,7 +619,6 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         // Work unit = 4 steps.  As in the forward, the LDS reads of the NEXT unit are issued ahead of the current unit's arithmetic:
         // two register sets X / Y by unit parity, pinned with sched_barrier.
         f2 av[TT], hs[TT];
-        float yred[TT / 8];
         struct H4 { f4 dt4, du4, g4, bc[4]; };
         auto load_u = [&](H4& H, int qd) {
             H.dt4 = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 4 * qd)]);
@@ -614,7 +628,6 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         };
         auto load_g = [&](H4& H, int qd) { H.g4 = *reinterpret_cast<const f4*>(&tl.g[dts_index(cl, 4 * qd)]); };
         f2 h = hck;
-        float yv[8];
         auto fwd_u = [&](const H4& H, int qd) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -624,15 +637,12 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 av[t] = f2{fast_exp2(x.x), fast_exp2(x.y)};
                 h = av[t] * h + f2{bc.x, bc.y} * H.du4[s];
                 hs[t] = h;
-                if (has_z) yv[4 * (qd & 1) + s] = fmaf(h.y, bc.w, h.x * bc.z);
             }
-            if (qd & 1) yred[qd >> 1] = has_z ? reduce_pairs8(yv) : 0.f;     // owner: step 8*(qd/2) + pr of channel cl
         };
-        struct Own { float u, dt, sg, g, gz; };
+        struct Own { float u, dt, sg, g; };
         auto load_own = [&](Own& O, int g8) {
             const int r = 8 * g8 + pr;
             O.u = tl.eu[r * EPS + cl]; O.dt = tl.edt[r * EPS + cl]; O.sg = tl.esg[r * EPS + cl]; O.g = tl.eg[r * EPS + cl];
-            O.gz = has_z ? tl.egz[r * EPS + cl] : 0.f;
         };
         float ddtu_p[8], ddt_p[8];
         auto bwd_u = [&](const H4& H, const Own& O, int qd) {
@@ -667,7 +677,6 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 const float dd = fmaf(ddtu, O.u, ddtA) * O.sg;
                 IO<T>::st(&otile[0][r * EPS + cl], fmaf(ddtu, O.dt, Dv * O.g));
                 IO<T>::st(&otile[1][r * EPS + cl], dd);
-                if (has_z) IO<T>::st(&otile[2][r * EPS + cl], O.gz * fmaf(Dv, O.u, yred[qd >> 1]));
                 dDacc = fmaf(O.g, O.u, dDacc);
                 dbacc += dd;
             }
@@ -757,14 +766,14 @@ int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out,
 }
 
 int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
-                   const float* D, const void* z, const float* delta_bias, void* y,
+                   const float* D, const void* z, const float* delta_bias, void* y, void* yscan,
                    float* hstate, float* sdelta, float* ckpt,
                    int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream) {
     GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && y, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
     S2Fwd p;
-    p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y;
+    p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y; p.yscan = yscan;
     p.hstate = hstate; p.sdelta = sdelta; p.ckpt = ckpt;
     p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
     p.nseg = (int)ceil_div(L, SEG); p.bc_bf16 = bc_dtype == GFE_BF16;
@@ -777,17 +786,17 @@ int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void*
 }
 
 int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
-                   const float* D, const void* z, const float* delta_bias, const void* dy,
+                   const float* D, const void* z, const float* delta_bias, const void* dy, const void* yscan,
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
                    const float* ckpt, float* qstate, const float* sdelta,
                    int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream) {
     GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && dy && du && ddelta && dA_ws && dB_ws && dC_ws && ckpt, GFE_ERR_NULL);
-    GFE_REQUIRE(!z || dz, GFE_ERR_NULL);
+    GFE_REQUIRE(!z || (dz && yscan), GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
     S2Bwd p;
-    p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.dy = dy; p.A = A; p.D = D; p.dbias = delta_bias;
+    p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.dy = dy; p.yscan = yscan; p.A = A; p.D = D; p.dbias = delta_bias;
     p.du = du; p.ddelta = ddelta; p.dz = dz; p.dAws = dA_ws; p.dBws = dB_ws; p.dCws = dC_ws; p.dDws = dD_ws; p.dbiasws = dbias_ws;
     p.ckpt = ckpt; p.qstate = qstate; p.sdelta = sdelta;
     p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;

@@ -67,16 +67,17 @@ class _SelectiveScan2(torch.autograd.Function):
             if need_grad:
                 ckpt = ck_
         y = torch.empty((Bsz, L, ED), device=dev, dtype=dt)
-        call("gfe_sscan2_fwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(y),
+        yscan = torch.empty_like(y) if (need_grad and z_ is not None) else None      # the pre-gate output, for dz in the backward
+        call("gfe_sscan2_fwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(y), ptr(yscan),
              ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, int(bool(delta_softplus)), dtype_code(dt), dtype_code(bcdt), stream())
-        ctx.save_for_backward(u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta)
+        ctx.save_for_backward(u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta, yscan)
         ctx.meta = (T, nc, bool(delta_softplus), dt,
                     tuple(None if t is None else t.dtype for t in (u, delta, A, Bm, Cm, D, z, delta_bias)))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta = ctx.saved_tensors
+        u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta, yscan = ctx.saved_tensors
         T, nc, softplus, dt, in_dtypes = ctx.meta
         Bsz, L, ED = u_.shape
         dev = u_.device
@@ -88,7 +89,7 @@ class _SelectiveScan2(torch.autograd.Function):
         slab = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
         dA_ws, dB_ws, dC_ws, dD_ws, db_ws = torch.split(slab, sizes)
         qstate = torch.empty((Bsz, nc, ED, 16), device=dev, dtype=torch.float32) if nc > 1 else None
-        call("gfe_sscan2_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_),
+        call("gfe_sscan2_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_), ptr(yscan),
              ptr(du), ptr(dd), ptr(dz), ptr(dA_ws), ptr(dB_ws), ptr(dC_ws),
              ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
              ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), stream())

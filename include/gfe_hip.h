@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 32
+#define GFE_ABI_VERSION 33
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -77,16 +77,18 @@ int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, con
  *   gfe_sscan2_plan: T = chunk length (a multiple of 32 when nchunks > 1; chunk_req <= 0: automatic), host only.
  *   hstate (B, nchunks, ED, 16), sdelta (B, nchunks, ED) f32: workspaces, required when nchunks > 1.
  *   ckpt (B, ceil(L/32), ED, 16) f32 or NULL: the forward leaves the state at the start of every 32-step segment there; the backward
- *   recomputes one segment at a time from it with the segment's states in registers. */
+ *   recomputes one segment at a time from it with the segment's states in registers.
+ *   yscan (B, L, ED) dtype or NULL: the forward also leaves its output BEFORE the gate (hs.C + D*u) there; the backward needs it when z
+ *   is given (dz = dy * silu'(z) * yscan) -- one more output row per step instead of a second sum over states per step in the backward. */
 int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out, int* nchunks_out);
 int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
-                   const float* D, const void* z, const float* delta_bias, void* y,
+                   const float* D, const void* z, const float* delta_bias, void* y, void* yscan,
                    float* hstate, float* sdelta, float* ckpt,
                    int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream);
 /*   dA_ws (ED, 16), dB_ws / dC_ws (B, L, 16), dD_ws / dbias_ws (ED) f32: zeroed, accumulated atomically; qstate: workspace like hstate
  *   (nchunks > 1); ckpt, sdelta: as left by gfe_sscan2_fwd with the same T. */
 int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
-                   const float* D, const void* z, const float* delta_bias, const void* dy,
+                   const float* D, const void* z, const float* delta_bias, const void* dy, const void* yscan,
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
                    const float* ckpt, float* qstate, const float* sdelta,
