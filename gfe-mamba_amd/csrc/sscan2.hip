@@ -43,7 +43,7 @@ struct S2Fwd {
     void* y;
     void* yscan;        // (B, L, ED) or NULL: the scan's output BEFORE the gate, hs.C + D*u (the backward's dz = dy * silu'(z) * yscan needs it;
                         // saving it costs one more output row per step and spares the backward a sum over states per step)
-    float* hstate;      // (B, nchunks, ED, 16): K1 writes local end states, K2 turns them into chunk-start states, K3 reads
+    float* hstate;      // (B, nchunks, ED, 16): the state pass writes every chunk's local end state, the full pass folds its predecessors' (chunk_carry)
     float* sdelta;      // (B, nchunks, ED): sum of dt over the chunk (the chunk's decay is exp(A * sum dt): no products)
     float* ckpt;        // (B, nseg, ED, 16) state at the START of every 32-step segment, or NULL (no backward wanted)
     int B, L, ED, T, nchunks, softplus, nseg, bc_bf16;
@@ -147,13 +147,44 @@ __device__ __forceinline__ int xcd_paired_group(int x, int G) {
     return 2 * (xcd + 8 * (j >> 1)) + (j & 1);
 }
 
+// The chunked plan's carry, folded into the full pass (round 3; it was a kernel of its own between the two passes: 5 us + two kernel
+// boundaries each way at B = 1): the state pass left every chunk's LOCAL end state (from h = 0) and its sum of dt; the state at the
+// start of chunk c is the fold of its predecessors' pairs, H <- exp(A * sum dt_j) * H + local_j, j = 0 .. c-1 (REVERSE: the adjoint
+// carry, j = nchunks-1 .. c+1) -- at most nchunks - 1 independent 8-byte loads and as many fma per lane.
+template <bool REVERSE>
+__device__ __forceinline__ f2 chunk_carry(const float* __restrict__ state, const float* __restrict__ sdelta, f2 A2, int b, int c, int e, int pr,
+                                          int nchunks, int ED) {
+    f2 H = f2{0.f, 0.f};
+    const int n = REVERSE ? nchunks - 1 - c : c;
+    constexpr int G = 8;
+    for (int k0 = 0; k0 < n; k0 += G) {
+        f2 loc[G];
+        float sdv[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int k = min(k0 + j, n - 1);
+            const int cj = REVERSE ? nchunks - 1 - k : k;
+            loc[j] = *reinterpret_cast<const f2*>(state + (((size_t)b * nchunks + cj) * ED + e) * 16 + 2 * pr);
+            sdv[j] = sdelta[((size_t)b * nchunks + cj) * ED + e];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (k0 + j < n) {
+                const f2 x = A2 * sdv[j];
+                H = f2{fast_exp2(x.x), fast_exp2(x.y)} * H + loc[j];
+            }
+        }
+    }
+    return H;
+}
+
 // Wave-specialised block (round 3): 8 waves = 4 SCAN waves (0-3: the recurrence, one wave per SIMD as before) + 4 STAGING waves (4-7,
 // the SIMD partners of waves 0-3): fetch the next tile's rows, do the per-(t, channel) math (softplus, silu, products) once, park it in
 // the other LDS buffer, and write the previous tile's y rows out.  The scan waves' instruction stream loses a third of its issue slots'
 // worth of work (staging 30 + stores 12 of 128 cycles per step) to a partner that fills the slots the dependent h chain leaves idle,
 // and plain VALU instructions cost 2.7 instead of 6.5 cycles with two waves on a SIMD (profiles/r02/valu_rates.txt).  One barrier per tile.
 template <typename T, bool STATE_ONLY>
-__global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
+__global__ __launch_bounds__(512, 4) void sscan2_fwd_kernel(const S2Fwd p) {      // <= 128 registers: two blocks per CU when the grid has them (chunked plans, B >= 16)
     typedef typename Vec4<T>::type V4;
     __shared__ __attribute__((aligned(16))) Tile tiles[2];
     __shared__ __attribute__((aligned(16))) float ytile[2][TT * EPS];           // hs.C + D*u of the tile (f32: gated and rounded once, on the way out)
@@ -274,7 +305,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     f2 A2 = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]} * GFE_LOG2E;
     f2 h = f2{0.f, 0.f};
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
-    if (!STATE_ONLY && p.nchunks > 1) h = *reinterpret_cast<const f2*>(p.hstate + sbase);
+    if (!STATE_ONLY && p.nchunks > 1) h = chunk_carry<false>(p.hstate, p.sdelta, A2, b, c, e, pr, p.nchunks, p.ED);
     float sd = 0.f;
     lds_barrier();
     int cur = 0;
@@ -284,34 +315,44 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         if (!STATE_ONLY && p.ckpt)                                // every tile starts a segment (t0 is a multiple of SEG)
             *reinterpret_cast<f2*>(p.ckpt + ((((size_t)b * p.nseg + tb / SEG) * p.ED + e) * 16 + 2 * pr)) = h;
         const Tile& tl = tiles[cur];
-        // Nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream, so the 14 reads of the
-        // next 8-step group are issued before the current group's arithmetic (two register sets, pinned with sched_barrier).
-        struct Grp { f4 dt4[2], du4[2], bc[8]; float epu; };
-        auto load_grp = [&](Grp& G, int g) {
+        // Nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream, so reads are issued half a group
+        // (4 steps) ahead of their use: a group's second-half B / C rows while its 16 decays are exponentiated, the next group's dt / dt*u
+        // quads and first-half rows between its two halves (two register sets for those, pinned with sched_barrier; <= 128 registers).
+        struct Grp { f4 dt4[2], du4[2], bc[4]; float epu; };
+        auto load_a = [&](Grp& G, int g) {
 #pragma unroll
             for (int j4 = 0; j4 < 2; ++j4) {
                 G.dt4[j4] = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 8 * g + 4 * j4)]);
                 G.du4[j4] = *reinterpret_cast<const f4*>(&tl.dtu[dts_index(cl, 8 * g + 4 * j4)]);
             }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) G.bc[s] = tl.bc[(8 * g + s) * 8 + pr];
+            for (int s = 0; s < 4; ++s) G.bc[s] = tl.bc[(8 * g + s) * 8 + pr];
             if (!STATE_ONLY) G.epu = tl.epu[(8 * g + pr) * EPS + cl];
         };
-        auto run_grp = [&](const Grp& G, int g) {
-            float yv[8];
-            f2 a[8];
+        f4 bcb[4];
+        auto load_b = [&](int g) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bcb[s] = tl.bc[(8 * g + 4 + s) * 8 + pr];
+        };
+        float yv[8];
+        f2 a[8];
+        auto exps = [&](const Grp& G) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                          // the decays do not depend on h: all 16 exp first, so that none of the
                 const f2 x = A2 * G.dt4[s >> 2][s & 3];            // transcendental results is wanted right behind its instruction
                 a[s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
                 if (STATE_ONLY) sd += G.dt4[s >> 2][s & 3];
             }
+        };
+        auto half = [&](const Grp& G, const f4 (&bc4)[4], int hf) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const f4 bc = G.bc[s];
-                h = a[s] * h + f2{bc.x, bc.y} * G.du4[s >> 2][s & 3];
-                if (!STATE_ONLY) yv[s] = fmaf(h.y, bc.w, h.x * bc.z);
+            for (int s = 0; s < 4; ++s) {
+                const f4 bc = bc4[s];
+                h = a[4 * hf + s] * h + f2{bc.x, bc.y} * G.du4[hf][s];
+                if (!STATE_ONLY) yv[4 * hf + s] = fmaf(h.y, bc.w, h.x * bc.z);
             }
+        };
+        auto finish = [&](const Grp& G, int g) {
             if (!STATE_ONLY) {
                 const float ys = reduce_pairs8(yv);                // this lane: step 8g + pr of channel cl
                 ytile[cur][(8 * g + pr) * EPS + cl] = ys + G.epu;
@@ -319,18 +360,21 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         };
         Grp ga, gb;
         S2_STAMP(1)
-        load_grp(ga, 0);
+        load_a(ga, 0);
+#define SB __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
         for (int g = 0; g < TT / 8; g += 2) {
-            load_grp(gb, g + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            run_grp(ga, g);
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < TT / 8) load_grp(ga, g + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            run_grp(gb, g + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            load_b(g); SB;
+            exps(ga); half(ga, ga.bc, 0); SB;
+            load_a(gb, g + 1); SB;
+            half(ga, bcb, 1); finish(ga, g); SB;
+            load_b(g + 1); SB;
+            exps(gb); half(gb, gb.bc, 0); SB;
+            if (g + 2 < TT / 8) load_a(ga, g + 2);
+            SB;
+            half(gb, bcb, 1); finish(gb, g + 1); SB;
         }
+#undef SB
         S2_STAMP(2)
         lds_barrier();
         S2_STAMP(4)
@@ -342,46 +386,10 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     }
 }
 
-// K2: hstate[b, c, e, n] (local end state of chunk c) -> state at the start of chunk c.  REVERSE: the adjoint carry (chunk c
-// receives from chunk c+1).  One lane per (e, n); loads of 8 chunks are batched ahead of the 8 dependent fma steps.
-template <bool REVERSE>
-__global__ __launch_bounds__(256) void sscan2_carry_kernel(float* __restrict__ hstate, const float* __restrict__ sdelta,
-                                                           const float* __restrict__ A, int ED, int nchunks) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // e*16 + n
-    const int b = blockIdx.y;
-    if (i >= 16 * ED) return;
-    const int e = i >> 4;
-    const float A2 = A[i] * GFE_LOG2E;
-    float H = 0.f;
-    constexpr int G = 8;
-    for (int k0 = 0; k0 < nchunks; k0 += G) {
-        float loc[G], sdv[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int k = min(k0 + j, nchunks - 1);
-            const int c = REVERSE ? nchunks - 1 - k : k;
-            loc[j] = hstate[((size_t)b * nchunks + c) * ED * 16 + i];
-            sdv[j] = sdelta[((size_t)b * nchunks + c) * ED + e];
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            if (k0 + j < nchunks) {
-                const int c = REVERSE ? nchunks - 1 - (k0 + j) : k0 + j;
-                hstate[((size_t)b * nchunks + c) * ED * 16 + i] = H;
-                H = fmaf(fast_exp2(A2 * sdv[j]), H, loc[j]);
-            }
-        }
-    }
-}
-
 template <typename T>
 int sscan2_fwd_launch(const S2Fwd& p, hipStream_t st) {
     const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
-    if (p.nchunks > 1) {
-        hipLaunchKernelGGL((sscan2_fwd_kernel<T, true>), grid, blk, 0, st, p);
-        hipLaunchKernelGGL((sscan2_carry_kernel<false>), dim3((unsigned)ceil_div((int64_t)16 * p.ED, 256), p.B), dim3(256), 0, st,
-                           p.hstate, p.sdelta, p.A, p.ED, p.nchunks);
-    }
+    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_fwd_kernel<T, true>), grid, blk, 0, st, p);      // local end states + sum dt of every chunk
     hipLaunchKernelGGL((sscan2_fwd_kernel<T, false>), grid, blk, 0, st, p);
     return gfe_launch_status();
 }
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     const float Dv = p.D ? p.D[e] : 0.f;
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
     f2 q = f2{0.f, 0.f};
-    if (!STATE_ONLY && p.nchunks > 1) q = *reinterpret_cast<const f2*>(p.qstate + sbase);
+    if (!STATE_ONLY && p.nchunks > 1) q = chunk_carry<true>(p.qstate, p.sdelta, A2, b, c, e, pr, p.nchunks, p.ED);
     f2 dAacc = f2{0.f, 0.f};
     float dDacc = 0.f, dbacc = 0.f;
     // the segment's start state: fetched one segment ahead (wanted by the very first instruction of phase 1: an HBM round trip there
@@ -733,11 +741,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
 template <typename T>
 int sscan2_bwd_launch(const S2Bwd& p, hipStream_t st) {
     const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
-    if (p.nchunks > 1) {
-        hipLaunchKernelGGL((sscan2_bwd_kernel<T, true>), grid, blk, 0, st, p);
-        hipLaunchKernelGGL((sscan2_carry_kernel<true>), dim3((unsigned)ceil_div((int64_t)16 * p.ED, 256), p.B), dim3(256), 0, st,
-                           p.qstate, p.sdelta, p.A, p.ED, p.nchunks);
-    }
+    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_bwd_kernel<T, true>), grid, blk, 0, st, p);      // local adjoint carries of every chunk
     hipLaunchKernelGGL((sscan2_bwd_kernel<T, false>), grid, blk, 0, st, p);
     return gfe_launch_status();
 }
