@@ -1,8 +1,10 @@
 // Flash-style fused attention forward for gfx950: O = softmax(Q K^T * scale) V per (batch, head), head dim 64, any sequence
 // length (vit_pytorch_diy/vit_3d.py:47-57; the 1729-token synthetic 3-D ViT of SURVEY 8-d).  bf16 MFMA 32x32x16, f32 softmax.
 //
-// Block = 8 waves, 256 query rows (32 per wave); K/V tiles of 64 keys stream through a 2-deep LDS ring filled by LDS-DMA (the pieces
-// of tile t+1 fly under the MFMAs of tile t), one barrier per tile; the softmax advances 32 keys at a time (16 score registers).
+// Block = 8 waves, 256 query rows (32 per wave); K/V tiles of 64 keys stream through a 3-deep LDS ring filled by LDS-DMA two tiles
+// ahead (issued from asm behind counted vmcnt waits), one barrier per tile; the softmax advances 32 keys at a time (16 score registers)
+// and costs ~60 instead of round 2's 122 vector instructions per block: no multiply by the scale (folded into Q), no subtraction of
+// the maximum (the S chain starts from -m), deferred rescale, scalar-side key masks.
 // Everything a lane owns belongs to ONE query row q = lane & 31 (both products are computed transposed):
 //   S^T = K Q^T : A = K tile rows (ds_read_b128 from the swizzled [key][d] image), B = Q fragments kept in registers.
 //                 C: lane (q, hi = lane >> 5) holds keys (r&3) + 8(r>>2) + 4hi of each 32-key block -> row max / row sum are
@@ -12,6 +14,7 @@
 //                 C: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi (+32) of ITS row -> the online-softmax rescale is a per-lane
 //                 scalar, no cross-lane traffic at all.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -24,8 +27,14 @@ namespace {
 constexpr int AD = 64;            // head dim
 constexpr int QW = 32;            // query rows per wave
 #ifndef GFE_ATTN_WAVES
-#define GFE_ATTN_WAVES 8
+#define GFE_ATTN_WAVES 8       // 256-row blocks, two per CU = four waves per SIMD at <= 128 registers: all 448 blocks of the bench shape resident at once
 #endif
+#ifndef GFE_ATTN_PREFETCH
+#define GFE_ATTN_PREFETCH 0    // 1: fragment reads a block ahead of their MFMAs (+20 registers; measured no gain at three or four waves per SIMD)
+#endif
+#ifndef GFE_ATTN_MINW
+#define GFE_ATTN_MINW 4        // waves per SIMD the register budget is set for (the LDS image is DYNAMIC shared memory: with a static 48 KB array hipcc
+#endif                         // derives a lower occupancy from the LDS size and quietly ignores the bound)
 constexpr int ANW = GFE_ATTN_WAVES;            // waves per block
 #ifndef GFE_ATTN_KT
 #define GFE_ATTN_KT 64
@@ -33,7 +42,7 @@ constexpr int ANW = GFE_ATTN_WAVES;            // waves per block
 constexpr int KT = GFE_ATTN_KT;   // keys per tile
 constexpr int TILE_BYTES = KT * AD * 2;     // 8 KiB
 #ifndef GFE_ATTN_RING
-#define GFE_ATTN_RING 2        // 3 (tile t+2 in flight, counted vmcnt waits) measured 104.6 vs 99-101 us: the DMA's cost is not its latency
+#define GFE_ATTN_RING 3        // tile t+2 in flight behind a counted vmcnt wait (possible since the DMA is issued from asm, see dma16)
 #endif
 constexpr int RING = GFE_ATTN_RING;         // K/V tiles in LDS: tile t+RING-1 is in flight while tile t is multiplied (2: one tile ahead)
 constexpr int PIECES_PER_WAVE = 2 * ((KT / 8) / ANW);   // LDS-DMA instructions one wave issues per tile (K + V)
@@ -42,27 +51,38 @@ struct AttnParams {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
     int64_t q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row;    // element strides
     int H, n;
+    int nqb, total;               // query blocks per (batch, head); blocks in the grid
     float c;                      // scale * log2(e): scores are kept in log2 units
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// K image: 128-B rows, 16-B chunk c of row r at slot c ^ (r & 7) (conflict-free ds_read_b128 of 32 rows x 2 chunks)
-__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) * 16); }
+// K image: 128-B rows (two rows per 64-bank line), 16-B chunk c of row r at slot c ^ ((r >> 1) & 7).  ds_read_b128 is served in four
+// 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) (MI355X_MICROARCH.md, LDS); a lane reads row = lane & 31, so a group's rows
+// are 8 even + 8 odd ones whose (r >> 1) & 7 are all different: 16 distinct (line half, slot) pairs = all 64 banks once.  (Round 2's
+// c ^ (r & 7) put rows 0 / 24, 1 / 25, ... of a group on the same banks: every K fragment read was 2-way conflicted:
+// SQ_LDS_BANK_CONFLICT 3.2e6 -> 0 of 6.4e6 LDS cycles, profiles/r03/attn_pmc.txt.)
+__device__ __forceinline__ int k_swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ k_swz(row)) * 16); }
 // V image: 128-B rows; chunk c of key-row r at slot c ^ (((r >> 1) & 1) << 2): the 4 key-rows x 64 B one half-wave gathers with
 // ds_read_b64_tr_b16 then cover 64 distinct banks
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) * 16); }
 
-// (HIP: the second __launch_bounds__ argument is the minimum number of waves per SIMD: 4 keeps the kernel at <= 128 VGPRs)
-__global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams p) {
+// (HIP: the second __launch_bounds__ argument is the minimum number of waves per SIMD: 3 keeps the kernel at <= 168 VGPRs)
+__global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer / LDS-DMA builtins)
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * RING * TILE_BYTES];      // K[RING], V[RING]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // 2 * RING * TILE_BYTES: K[RING], V[RING]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, hi = lane >> 5;
     // static issue priority for the younger half of the block (the arbitration loser of every SIMD pair, MI355X_MICROARCH.md): +1.2 %
-    if (wave >= ANW / 2) __builtin_amdgcn_s_setprio(1);
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * (ANW * QW) + wave * QW;
+    if (ANW == 8 && wave >= ANW / 2) __builtin_amdgcn_s_setprio(1);
+    // Workgroups are dealt to the 8 XCDs round-robin.  The query blocks of one (batch, head) stream the same K / V (442 KB at n = 1729): give
+    // each XCD a CONTIGUOUS range of (batch, head, query block) items, so that a head's blocks share one 4 MiB L2.
+    int item = blockIdx.x;
+    if ((p.total & 7) == 0) item = (item & 7) * (p.total >> 3) + (item >> 3);
+    const int bh = item / p.nqb, qb = item - bh * p.nqb;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qb * (ANW * QW) + wave * QW;
     const bf16_t* kb = p.k + (size_t)b * p.k_batch + h * AD;
     const bf16_t* vb = p.v + (size_t)b * p.v_batch + h * AD;
 
@@ -75,7 +95,11 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
         for (int ds = 0; ds < 4; ++ds) {
             uint4 t = *reinterpret_cast<const uint4*>(qp + 16 * ds);
             if (q >= p.n) t = make_uint4(0, 0, 0, 0);
-            qf[ds] = __builtin_bit_cast(bf16x8, t);
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};              // scale * log2(e) goes into Q ONCE: no multiply per score
+            uint32_t r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(bf16lo_to_f32(w[i]) * p.c, bf16hi_to_f32(w[i]) * p.c);
+            qf[ds] = __builtin_bit_cast(bf16x8, make_uint4(r[0], r[1], r[2], r[3]));
         }
     }
 
@@ -84,92 +108,154 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;          // running max (log2 units) and this lane's share of the row sum
+    // All 16 score registers of a lane belong to ONE query row, so the S chain can start from an accumulator that holds -m: the MFMA
+    // delivers S - m and p = exp2(that), no subtraction per score.  m starts at 0 (an arbitrary reference) and is moved at the first block
+    // and whenever a block's maximum exceeds it by more than 2^THR (deferred rescale: p <= 2^THR is harmless in f32 / bf16) -- a
+    // wave-uniform branch the steady state does not take.
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    float lsum = 0.f;                          // this lane's share of the row sum
+    constexpr float THR = 6.0f;
 
     const int ntile = (p.n + KT - 1) / KT;
     // K/V tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, no staging registers): lane L of a piece fills
     // LDS slot L&7 of row L>>3, so it fetches the source chunk that the image's swizzle assigns to that slot.  Keys >= n lie beyond
     // num_records of the descriptor -> the hardware writes zeros.
+    // The DMA is issued from inline asm: for the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc assumes that the transfer may alias
+    // ANY later LDS read and puts an s_waitcnt vmcnt(0) in front of the next ds_read, so every tile paid a full memory round trip (rounds 1-2:
+    // "37 % of the wave cycles parked at s_waitcnt").  Here the ordering is explicit: a tile is read only behind its counted vmcnt wait +
+    // the workgroup barrier at the bottom of the loop.
     const unsigned row_bytes_k = (unsigned)(p.k_row * 2), row_bytes_v = (unsigned)(p.v_row * 2);
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((unsigned)(p.n - 1) * row_bytes_k + AD * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((unsigned)(p.n - 1) * row_bytes_v + AD * 2), 0x00020000);
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [&](const bf16_t* base, unsigned row_bytes) {
+        const uint64_t a = (uint64_t)base;
+        v4i_t r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+        r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));          // stride 0
+        r.z = __builtin_amdgcn_readfirstlane((int)((unsigned)(p.n - 1) * row_bytes + AD * 2));   // num_records: keys >= n read as zeros
+        r.w = 0x00020000;
+        return r;
+    };
+    const v4i_t rs_k = make_rsrc(kb, row_bytes_k), rs_v = make_rsrc(vb, row_bytes_v);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    auto dma16 = [&](const v4i_t& rs, unsigned lds_base, unsigned voff) {     // 64 lanes x 16 B -> LDS [lds_base + 16 * lane]
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_base), "v"(voff), "s"(rs) : "m0");
+    };
     auto dma = [&](int t, int buf) {
-        // 16 pieces per tile pair (8 K + 8 V), 4 per wave: piece pc = wave + 4*i covers rows 8*pc .. 8*pc+7 of K (i < 2) or V
+        // 16 pieces per tile pair (8 K + 8 V), 2 per wave: piece pc covers rows 8*pc .. 8*pc+7 of K or V
 #pragma unroll
         for (int i = 0; i < (KT / 8) / ANW; ++i) {
             const int pc = wave + ANW * i, row = 8 * pc + (lane >> 3), slot = lane & 7;
             const unsigned key = (unsigned)(t * KT + row);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t)(smem + buf * TILE_BYTES + pc * 1024), 16,
-                                                     key * row_bytes_k + ((slot ^ (row & 7)) * 16), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t)(smem + (RING + buf) * TILE_BYTES + pc * 1024), 16,
-                                                     key * row_bytes_v + ((slot ^ (((row >> 1) & 1) << 2)) * 16), 0, 0, 0);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + pc * 1024);
+            dma16(rs_k, dst, key * row_bytes_k + ((slot ^ k_swz(row)) * 16));
+            dma16(rs_v, dst + RING * TILE_BYTES, key * row_bytes_v + ((slot ^ (((row >> 1) & 1) << 2)) * 16));
         }
     };
 
     dma(0, 0);
     if constexpr (RING > 2) { if (ntile > 1) dma(1, 1); }
     // vmcnt retires in order: leaving the newest tile's pieces outstanding is a COUNTED wait (a vmcnt(0) here would drain the prefetch)
-    if (RING > 2 && ntile > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (PIECES_PER_WAVE & 15) | ((PIECES_PER_WAVE >> 4) << 14));
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (RING > 2 && ntile > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");   // one tile's pieces stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    for (int t = 0; t < ntile; ++t) {
-        const uint8_t* sk = smem + (t % RING) * TILE_BYTES;
-        const uint8_t* sv = smem + (RING + (t % RING)) * TILE_BYTES;
+    // LDS fragment addresses = a lane-constant offset (computed once, here) + the ring slot and the block's place in the tile, which are
+    // compile-time constants because the tile loop is unrolled by RING -> they fold into the ds_read instructions' immediate offsets.
+    // (Round 2 recomputed swizzles and a t % RING base per read: 25 of its 122 vector instructions per block.)
+    int koff[4], voff[2][2];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) koff[ds] = k_off(ql, 2 * ds + hi);                 // (k_swz only looks at row bits 1-3: + 32 rows keep it)
+    {
+        // 16-lane group g = lane >> 4: d columns 32*db + 16*(g & 1) .. +15, keys 16*tt + 8*(g >> 1) + {0..3 | 4..7}
+        const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int chunk = 4 * db + 2 * (g & 1) + (pp >> 1);
+            voff[db][0] = v_off(8 * (g >> 1) + qq, chunk) + 8 * (pp & 1);              // (v_off's swizzle only looks at row bit 1: + 4 / + 16 rows keep it)
+            voff[db][1] = v_off(8 * (g >> 1) + qq + 4, chunk) + 8 * (pp & 1);
+        }
+    }
+    auto tile = [&](auto slot_c, const int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const uint8_t* sk = smem + SLOT * TILE_BYTES;
+        const uint8_t* sv = smem + (RING + SLOT) * TILE_BYTES;
         const bool ragged = t == ntile - 1 && (p.n & (KT - 1));
 
+        // Fragment reads are issued a block ahead of their MFMAs (their LDS round trip runs under the softmax's vector work instead of in
+        // front of every MFMA): K of block 0 at the top of the tile, then -- right behind a block's S chain -- V of that block and K of the next.
+        bf16x8 kf[4], vf[2][2];
+        auto load_k = [&](int kb2) {
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) kf[ds] = *reinterpret_cast<const bf16x8*>(sk + 32 * kb2 * 128 + koff[ds]);
+        };
+        auto load_v = [&](int kb2) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + (32 * kb2 + 16 * tt) * 128 + voff[db][0]));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + (32 * kb2 + 16 * tt) * 128 + voff[db][1]));
+                    union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+                    u.h.a = lo; u.h.b = hi4;
+                    vf[tt][db] = u.v;
+                }
+        };
+#if GFE_ATTN_PREFETCH
+        load_k(0);
+#endif
 #pragma unroll
         for (int kb2 = 0; kb2 < KT / 32; ++kb2) {
             // ---- S^T = K Q^T for a 32-key block: four 16-wide d steps
             f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            bf16x8 kf[4];
-#pragma unroll
-            for (int ds = 0; ds < 4; ++ds) kf[ds] = *reinterpret_cast<const bf16x8*>(sk + k_off(32 * kb2 + ql, 2 * ds + hi));
 #if !defined(GFE_ATTN_EXP_NODMA)     // NODMA: timing experiment only, K/V tiles are never restaged
-            // the next tile's DMA instructions go out behind the first K fragment reads (nobody reads that ring slot any more); it lands
-            // under the next tiles' MFMAs
-            if (kb2 == 0 && t + RING - 1 < ntile) dma(t + RING - 1, (t + RING - 1) % RING);
+            // the tile two ahead: its DMA instructions go out behind the first K fragment reads (nobody reads that ring slot any more)
+            if (kb2 == 0 && t + RING - 1 < ntile) dma(t + RING - 1, (SLOT + RING - 1) % RING);
 #endif
-#if defined(GFE_ATTN_PRIO)
-            __builtin_amdgcn_s_setprio(1);
+#if !GFE_ATTN_PREFETCH
+            load_k(kb2);
 #endif
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
 #pragma unroll
-            for (int ds = 0; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
-#if defined(GFE_ATTN_PRIO)
-            __builtin_amdgcn_s_setprio(0);
+            for (int ds = 1; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
+#if GFE_ATTN_PREFETCH
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(kb2);
+            if (kb2 + 1 < KT / 32) load_k(kb2 + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-            // ---- online softmax over the block's 32 keys (this lane: 16 of them, lane ^ 32: the others)
+            // ---- online softmax over the block's 32 keys (this lane: 16 of them, lane ^ 32: the others); s = S - m, log2 units
+            const int kidx = 2 * t + kb2;
             if (ragged) {                                                // keys >= n do not exist
+                const int lim = p.n - 32 * kidx, h4 = 4 * hi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (t * KT + 32 * kb2 + crow(r, hi) >= p.n) s[r] = -INFINITY;
+                    if (h4 >= lim - crow(r, 0)) s[r] = -INFINITY;        // key index crow(r, 0) + 4 hi >= lim
             }
-            float mx = s[0];
+            // (v_max3 from asm: fmaxf() on MFMA outputs makes hipcc canonicalise every operand with an extra v_max_f32 x, x, x first)
+            float mx;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
+            asm("v_max3_f32 %0, %1, %2, %2" : "=v"(mx) : "v"(mx), "v"(s[15]));
             {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
                 const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
+                asm("v_max3_f32 %0, %1, %2, %2" : "=v"(mx) : "v"(__uint_as_float(xm[0])), "v"(__uint_as_float(xm[1])));
             }
-            const float m_new = fmaxf(m, mx * p.c);                   // -inf only for an all-masked block (then every p is 0)
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = fast_exp2(m - m_use);
-            m = m_new;
-            float psum = 0.f;
+            if (kidx == 0 || __builtin_amdgcn_ballot_w64(mx > THR)) {   // move the maximum (mx = -inf, a fully masked block, moves nothing)
+                const float d = (kidx == 0) ? mx : fmaxf(mx, 0.f);       // per row: new m = m + d
+                const float alpha = fast_exp2(-d);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = fast_exp2(fmaf(s[r], p.c, -m_use));
-                s[r] = e; psum += e;
+                for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+                lsum *= alpha;
             }
-            lsum = fmaf(lsum, alpha, psum);
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {          // wave-uniform: once the row maxima settle nothing is rescaled
+            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            for (int r = 0; r < 16; r += 2) {
+                s[r] = fast_exp2(s[r]); s[r + 1] = fast_exp2(s[r + 1]);
+                ps0 += s[r]; ps1 += s[r + 1];
             }
+            lsum += ps0 + ps1;
             // ---- P -> bf16 B operands.  16-key slot tt of the block: lane hi=0 must hold keys 0..7 of the slot, hi=1 keys 8..15;
             // it owns {0..3, 8..11} + 4hi -> one v_permlane32_swap per word pair exchanges the misplaced halves.
             bf16x8 pb[2];
@@ -183,26 +269,26 @@ __global__ __launch_bounds__(ANW * 64, 4) void attn_fwd_kernel(const AttnParams 
                 pb[tt] = __builtin_bit_cast(bf16x8, u);
             }
             // ---- O^T += V^T P^T: two 32-wide d blocks x the block's two 16-key slots; A fragments by transposing reads of [key][d]
+#if !GFE_ATTN_PREFETCH
+            load_v(kb2);
+#endif
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    // 16-lane group g = lane >> 4: d columns 32*db + 16*(g & 1) .. +15, keys 16*ks + 8*(g >> 1) + {0..3 | 4..7}
-                    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-                    const int key0 = 32 * kb2 + 16 * tt + 8 * (g >> 1) + qq;
-                    const int chunk = 4 * db + 2 * (g & 1) + (pp >> 1);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0, chunk) + 8 * (pp & 1)));
-                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + v_off(key0 + 4, chunk) + 8 * (pp & 1)));
-                    union { struct { s16x4 a, b; } h; bf16x8 v; } u;
-                    u.h.a = lo; u.h.b = hi4;
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pb[tt], oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[tt][db], pb[tt], oacc[db], 0, 0, 0);
                 }
             }
         }
         // tile t+1 has landed (this wave's pieces; the barrier makes all of it visible) while tile t+2's pieces, issued above, stay in flight
-        if (RING > 2 && t + RING - 1 < ntile) __builtin_amdgcn_s_waitcnt(0x0f70 | (PIECES_PER_WAVE & 15) | ((PIECES_PER_WAVE >> 4) << 14));
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (RING > 2 && t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    static_assert(RING == 3, "the tile loop is unrolled by the ring depth");
+    for (int t = 0; t < ntile; t += 3) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntile) tile(std::integral_constant<int, 2>{}, t + 2);
     }
 
     // ---- normalise and store: lane (q, hi) holds d = 32*db + crow(r, hi) of its row
@@ -238,7 +324,11 @@ int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int6
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
     p.q_batch = q_batch; p.q_row = q_row; p.k_batch = k_batch; p.k_row = k_row; p.v_batch = v_batch; p.v_row = v_row;
     p.o_batch = o_batch; p.o_row = o_row; p.H = (int)H; p.n = (int)n; p.c = scale * GFE_LOG2E;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)ceil_div(n, ANW * QW), (unsigned)(B * H)), dim3(ANW * 64), 0, (hipStream_t)stream, p);
+    p.nqb = (int)ceil_div(n, ANW * QW);
+    const int64_t total = (int64_t)p.nqb * B * H;
+    GFE_REQUIRE(total <= 0x7fffffff, GFE_ERR_SHAPE);
+    p.total = (int)total;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)total), dim3(ANW * 64), 2 * RING * TILE_BYTES, (hipStream_t)stream, p);
     return gfe_launch_status();
 }
 
