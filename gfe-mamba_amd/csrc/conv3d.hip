@@ -690,8 +690,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 }
             }
             if constexpr (STATS) {
-                // flush when the next epilogue belongs to another (sample, channel group) or there is none: block-uniform
-                const bool flush = !next_unit || p.ngroups > 1 || nxt.b != cur.b;
+                // flush when the next epilogue belongs to another TILE (or channel group), or there is none: block-uniform.  One slot per
+                // tile of the sample (the parity classes of a transposed conv are the innermost work-list dimension: one slot for all 8),
+                // so that the grouping of the partial sums -- and with it every rounding of the statistics -- is a function of the
+                // sample alone: a volume comes out bit-identical whatever batch it rides in (round 2 flushed per run of a block's tiles,
+                // which depends on B: batch 8 differed from batch 1 by 1e-2 of the maximum after twelve layers of flipped bf16 roundings).
+                const bool flush = !next_unit || p.ngroups > 1 || nxt.b != cur.b || nxt.td != cur.td || nxt.th != cur.th || nxt.tw != cur.tw;
                 if (flush) {
                     // 16 voxel lanes of a DPP row -> one value; 8 d-plane waves -> LDS; one plain store per (slot, channel, stat)
 #pragma unroll
@@ -718,11 +722,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #pragma unroll
                         for (int wv_ = 0; wv_ < NWAVES; ++wv_) t += sRed[wv_ * 2 * WROWS_TAP + tid];
                         const int st = tid / WROWS_TAP, c = group * WROWS_TAP + (tid - st * WROWS_TAP);
-                        // the slot of the LAST tile that went into the sums: unique per flush; slots never written stay zero (caller-zeroed)
-                        // one channel group: a block leaves a sample at most once -> slot = block index (a 256-slot table);
-                        // several groups flush per (tile, group) -> slot = tile index inside the sample
+                        // slot = tile index inside the sample (x class for the multi-group transposed conv, which flushes per class)
                         const int tix = (cur.td * p.nth + cur.th) * p.ntw + cur.tw;
-                        const int slot = p.stats_slot0 + (p.ngroups == 1 ? vb : (MC ? tix * p.ncls + cur.cls : tix));
+                        const int slot = p.stats_slot0 + (p.ngroups == 1 ? tix : (MC ? tix * p.ncls + cur.cls : tix));
                         if (c < p.Cout) p.stats[(((size_t)b * p.stats_nblk + slot) * 2 + st) * p.Cout + c] = t;
                     }
                 }
@@ -827,19 +829,16 @@ extern "C" {
 int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W) { return (int)(ceil_div(D, TD) * ceil_div(H, TH) * ceil_div(W, TW)); }
 
 int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout) {
-    const int64_t tps = gfe_conv3d_tiles(D, H, W), tiles = B * tps;
-    if (gfe_conv3d_cout_pad(Cout) > 64) return (int)tps;                    // several channel groups: one slot per tile
-    const int64_t tpb = ceil_div(tiles, NBLK);
-    return (int)ceil_div(tiles, tpb);                                        // one slot per persistent block
+    (void)B; (void)Cout;
+    return gfe_conv3d_tiles(D, H, W);                                        // one slot per tile of a sample, whatever the batch
 }
 
 int gfe_convt3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout) {
-    const int64_t tps = gfe_conv3d_tiles(D, H, W), items = B * tps * 8;
+    (void)B;
+    const int64_t tps = gfe_conv3d_tiles(D, H, W);
     if (gfe_conv3d_cout_pad(Cout) > 64) return (int)(tps * 8);                // (tile, class) slots
-    const int64_t ipb = ceil_div(items, NBLK);
-    const int slots = (int)ceil_div(items, ipb);                             // one slot per persistent block
-    const int slots_res = convt_resident_grid(B, D, H, W, nullptr);          // ... of either kernel (the dispatch depends on Cin)
-    return slots > slots_res ? slots : slots_res;
+    const int slots_res = convt_resident_tiles(D, H, W);                      // one slot per tile of a sample, of either kernel's
+    return (int)tps > slots_res ? (int)tps : slots_res;                       // tile grid (the dispatch depends on Cin)
 }
 
 #if defined(GFE_EXP_STAMP)

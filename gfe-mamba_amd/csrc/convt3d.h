@@ -18,4 +18,5 @@ struct ConvTParams {
 
 bool convt_resident_fits(int64_t Cin, int64_t Cout);
 int convt_resident_grid(int64_t B, int64_t D, int64_t H, int64_t W, int* tiles_per_block);
+int convt_resident_tiles(int64_t D, int64_t H, int64_t W);      // tiles (= GroupNorm partial slots) per sample
 int convt_resident_launch(ConvTParams& p, hipStream_t st);

@@ -287,8 +287,9 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
                 }
             }
         }
-        // ---- GroupNorm partials: flush when the block's run leaves the sample or ends (block-uniform); slot = block index
-        if (p.stats && (!next_tile || nxt.b != cur.b)) {
+        // ---- GroupNorm partials: one flush and one slot per tile of the sample (block-uniform), so that the grouping of the partial sums
+        // does not depend on the batch the sample rides in (see conv3d.hip)
+        if (p.stats) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) { gs[i] = row16_sum(gs[i]); gq[i] = row16_sum(gq[i]); }
             if (lr == 0 && !w_prod) {
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
 #pragma unroll
                 for (int wv_ = 0; wv_ < NWAVES; ++wv_) t += sRed[wv_ * 128 + tid];
                 const int st = tid >> 6, c = tid & 63;
-                if (c < p.Cout) p.stats[(((size_t)cur.b * p.stats_nblk + vb) * 2 + st) * p.Cout + c] = t;
+                const int tix = (cur.td * p.nth + cur.th) * p.ntw + cur.tw;
+                if (c < p.Cout) p.stats[(((size_t)cur.b * p.stats_nblk + tix) * 2 + st) * p.Cout + c] = t;
             }
             __syncthreads();
         }
@@ -319,6 +321,8 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
 }  // namespace
 
 bool convt_resident_fits(int64_t Cin, int64_t Cout) { return Cin % 32 == 0 && Cin / 32 <= CONVT_MAX_SLABS && Cout == 64; }
+
+int convt_resident_tiles(int64_t D, int64_t H, int64_t W) { return (int)(ceil_div(D, TD) * ceil_div(H, TH) * ceil_div(W, TW)); }
 
 int convt_resident_grid(int64_t B, int64_t D, int64_t H, int64_t W, int* tiles_per_block) {
     const int64_t tiles = B * ceil_div(D, TD) * ceil_div(H, TH) * ceil_div(W, TW);

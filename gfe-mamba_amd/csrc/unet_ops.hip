@@ -480,8 +480,9 @@ int gfe_conv_in1_stats(const void* x, const float* w, const float* bias, void* y
 }
 
 int gfe_conv3d_c1_k3_nblk(int64_t B, int64_t D, int64_t H, int64_t W) {
+    (void)B;      // the block count PER SAMPLE must not depend on the batch: a block's voxels are one GroupNorm partial (batch-invariant statistics)
     const int64_t tiles = ceil_div(D, 8) * ceil_div(H, 8) * ceil_div(W, 8);
-    const int64_t want = B > 0 ? (512 + B - 1) / B : 1;           // ~512 eight-wave blocks in all
+    const int64_t want = 64;                                      // 512 eight-wave blocks at the bench's 8 volumes per GPU
     return (int)(tiles < want ? tiles : want);
 }
 

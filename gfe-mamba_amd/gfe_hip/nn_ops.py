@@ -342,8 +342,13 @@ def fold_mid(x, md1=8, inverse=False, shape=None):
 
 # ---- GEMM / ViT ops ---------------------------------------------------------------------------------------------------
 def _auto_split_k(M, N, K):
-    """few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (partials + a fixed-order sum)"""
-    bm = 64 if (M <= 64 or (M % 128 != 0 and M % 128 <= 64 and M < 1024)) else 128
+    """few output tiles and a long K: the launch would occupy a fraction of the 256 CUs -> cut K across blocks (partials + a fixed-order sum).
+    Up to 512 rows the cut is a function of (N, K) ALONE: the K partition decides how a row's sum is rounded, and a sample's rows must come
+    out the same whatever batch they ride in (the generator's ViT runs 25 rows per volume: batch 1 .. 20 share one partition)."""
+    if M <= 512:
+        blocks = -(-N // 128)
+        return max(1, min(K // 128, 128 // blocks)) if blocks < 64 else 1
+    bm = 64 if (M % 128 != 0 and M % 128 <= 64 and M < 1024) else 128
     blocks = -(-M // bm) * -(-N // 128)
     return max(1, min(K // 128, 256 // blocks)) if blocks < 128 else 1
 

@@ -117,15 +117,15 @@ def test_config4_generator_128_cubed_batch2_vs_oracle():
     e = (rel_err(mi, omi), rel_err(mo, omo), rel_err(pet, opet), rel_err(pet_only, opet))
     print("config-4 rel errors (mid_input, mid_output, pet, pet via output_vit_mid=False): %.2e %.2e %.2e %.2e" % e)
     assert tuple(pet.shape) == (2, 1, 128, 128, 128) and tuple(mi.shape) == (2, 256, 256, 128)
-    assert e[0] < 2e-2 and e[1] < 3e-2 and e[2] < 3e-2 and e[3] < 3e-2, e
+    assert max(e) < 1.2e-2, e          # full-tensor maxima of 2 x 128^3 volumes (the T2 / T7 fixtures compare strided slices): measured 7e-3 .. 1e-2
 
 
 def test_batch8_at_96_cubed_equals_eight_batch1_runs():
-    """Config 3 / 5's per-GPU share: the persistent kernels' tile ranges and GroupNorm statistic slots depend on B.  Every sample of
-    a batch of 8 must come out as in a batch of one.  Not bit-equal: the GroupNorm partial sums are grouped by tile range (which
-    depends on B) and the fold accumulates with f32 atomics, so single bf16 roundings flip and propagate through twelve conv layers
-    (measured 1.0e-2 / 1.1e-2 / 6.7e-3 of the tensor maximum = one to two bf16 ulps of the largest values) -- but any mix-up of samples,
-    tiles or statistic slots would show as O(1)."""
+    """Config 3 / 5's per-GPU share.  Every sample of a batch of 8 must come out BIT FOR BIT as in a batch of one: the persistent conv
+    kernels' tile ranges depend on B, but the GroupNorm partial sums are kept per tile of the sample (one slot per tile, summed in slot
+    order in f64), the first block's one-channel conv runs a fixed number of blocks per sample, and split-K GEMMs cut K as a function of
+    (N, K) alone up to 512 rows -- so nothing a sample's values are rounded through knows about the batch.  (Round 2: per-block partial
+    slots, 1.0e-2 / 1.1e-2 / 6.7e-3 of the tensor maximum apart after twelve layers of flipped bf16 roundings.)"""
     from gfe_hip.step import build_models
     import gfe_hip.det_init as det
     gen, head, ft = build_models(vol=(96, 96, 96), seed=0)
@@ -140,7 +140,7 @@ def test_batch8_at_96_cubed_equals_eight_batch1_runs():
             for j, (a, r) in enumerate(((mi8[b:b + 1], mi), (mo8[b:b + 1], mo), (pet8[b:b + 1], pet))):
                 worst[j] = max(worst[j], rel_err(a, r))
     print("batch-8 vs batch-1 rel differences (mid_input, mid_output, pet): %.2e %.2e %.2e" % tuple(worst))
-    assert worst[0] < 2e-2 and worst[1] < 2e-2 and worst[2] < 2e-2, worst
+    assert worst == [0.0, 0.0, 0.0], worst
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -178,7 +178,7 @@ def _grad_and_update_errors(fx, names, params, opt):
     return worst
 
 
-def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag, models=None, batch=2):
+def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag, models=None, batch=2, tol_gen=1e-2):
     from gfe_hip import det_init as det
     from gfe_hip.step import ClassifyStep, build_models
     gen, head, ft = models if models is not None else build_models(vol=vol, dim=dim, depth=depth, heads=heads, seed=seed, **gen_kw)
@@ -192,7 +192,9 @@ def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_g
         ref_abs = float(fx[name + "_abssum"])
         assert abs(t.double().abs().sum().item() - ref_abs) / ref_abs < 1e-2, name
         meas[name] = rel_err(_slices(t.contiguous()), tt(fx[name + "_slice"]))
-        assert meas[name] < 2e-2, (name, meas[name])          # frozen generator: bf16 activations through 12 conv layers + the ViT
+        # frozen generator: bf16 activations through 12 conv layers + the ViT.  tests/test_ladder_gpu.py attributes the budget: every stage
+        # adds 4-6e-3 (a bf16 output rounding alone is up to 3.9e-3 of the maximum), 6-8e-3 at the end of the full-width chain
+        assert meas[name] < tol_gen, (name, meas[name])
     meas["pred"] = rel_err(pred, tt(fx["pred"]))
     loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.to(DEV).float())
     meas["loss"] = abs(loss.item() - float(fx["loss"])) / max(1.0, float(fx["loss"]))
@@ -220,13 +222,14 @@ def test_reduced_step_vs_reference_fixture():
     parameter gradient ELEMENT-wise (fixture gslice.*), one clipped Adam step element-wise (dslice.*).  bf16 generator -> 2e-2."""
     fx = golden("t1_reduced_step.npz")
     _check_step_fixture(fx, dict(f_maps=(8, 16, 32), vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128)),
-                        (32, 32, 32), 64, 2, 8, 11, tol_fwd=1e-2, tol_grad=2e-2, tol_sens=8e-2, tag="T1 (reduced, 32^3)")
+                        (32, 32, 32), 64, 2, 8, 11, tol_fwd=1e-2, tol_grad=2e-2, tol_sens=5e-2, tag="T1 (reduced, 32^3)",
+                        tol_gen=2e-2)        # 8 / 16 / 32 channels: fewer terms per sum to average the roundings out (measured 1.2e-2)
 
 
 def test_full_96_step_vs_reference_fixture():
     """T2 / BASELINE config 1: the full-size model on 2 volumes of 96^3 (reference run on CPU in the build container)."""
     fx = golden("t2_full96_step.npz")
-    _check_step_fixture(fx, dict(f_maps=(64, 128, 256)), (96, 96, 96), 512, 6, 8, 21, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=8e-2, tag="T2 (config 1, 96^3)")
+    _check_step_fixture(fx, dict(f_maps=(64, 128, 256)), (96, 96, 96), 512, 6, 8, 21, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=6e-2, tag="T2 (config 1, 96^3)")
 
 
 def test_native_160x160x96_step_with_default_constructors_vs_reference_fixture():
@@ -246,7 +249,7 @@ def test_native_160x160x96_step_with_default_constructors_vs_reference_fixture()
     for m, pre in ((gen, "gen."), (head, "head."), (ft, "ft.")):
         m.load_state_dict(det.det_state_dict(m.state_dict(), seed=71, prefix=pre))
     models = (gen.to(DEV).eval(), head.to(DEV), ft.to(DEV))
-    _check_step_fixture(fx, None, (160, 160, 96), 512, 6, 8, 71, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=8e-2, tag="T7 (native 160x160x96)",
+    _check_step_fixture(fx, None, (160, 160, 96), 512, 6, 8, 71, tol_fwd=5e-3, tol_grad=2e-2, tol_sens=3e-2, tag="T7 (native 160x160x96)",
                         models=models, batch=1)
 
 
