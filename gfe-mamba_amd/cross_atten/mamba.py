@@ -8,6 +8,7 @@ plug-in (mamba.py:243-252): softplus(delta + dt_proj.bias), the scan, D*x and th
 Projections run on the bf16 MFMA GEMM.  `config.pscan` / `config.use_cuda` are accepted and ignored (one path).
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Union
 
@@ -16,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from gfe_hip.scan_ops import selective_scan_fn, selective_scan_tm
+from gfe_hip import mamba_block as _fused
 from gfe_hip.train_ops import Linear, dwconv1d_silu, rmsnorm
 
 
@@ -128,6 +130,8 @@ class MambaBlock(nn.Module):
 
     def forward(self, x):
         # x : (B, L, D) -> (B, L, D)                               mamba.py:197-225
+        if _fused.usable(self, x) and os.environ.get("GFE_MAMBA_UNFUSED") != "1":
+            return _fused.mamba_block(self, x)                   # the whole block as one autograd node (gfe_hip/mamba_block.py)
         xz = self.in_proj(x)
         xs, z = xz.chunk(2, dim=-1)
         xs = self._conv_silu(xs)

@@ -66,15 +66,16 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 // ---- depthwise causal conv1d (kernel KS, left padding KS-1) + bias + SiLU on (B, L, ED); lane = channel --------------------
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int L, int ED) {
-    // one thread per (sample, step, channel): the KS-wide window is re-read (L1 hits) instead of carried through a sequential loop
+                                                              float* __restrict__ y, int L, int ED, int ldx) {
+    // one thread per (sample, step, channel): the KS-wide window is re-read (L1 hits) instead of carried through a sequential loop.
+    // ldx: row stride of x in floats (ED for a contiguous tensor; 2 ED when x is the first half of the in_proj output, read in place)
     const int e = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, b = blockIdx.z;
     if (e >= ED) return;
     float pre = bias ? bias[e] : 0.f;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
         const int tt = t + k - (KS - 1);
-        if (tt >= 0) pre = fmaf(w[e * KS + k], x[((size_t)b * L + tt) * ED + e], pre);
+        if (tt >= 0) pre = fmaf(w[e * KS + k], x[((size_t)b * L + tt) * ldx + e], pre);
     }
     y[((size_t)b * L + t) * ED + e] = pre * sigmoidf_(pre);
 }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const float* __res
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
-                                                              float* __restrict__ db, int L, int ED) {
+                                                              float* __restrict__ db, int L, int ED, int ldx, int lddx) {
     extern __shared__ float sp[];                       // [L + KS - 1][64] dpre (zero tail), then [4][KS + 1][64] partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane, b = blockIdx.y;
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __res
     for (int k = 0; k < KS; ++k) { wk[k] = live ? w[e * KS + k] : 0.f; dwacc[k] = 0.f; }
     const float bv = (bias && live) ? bias[e] : 0.f;
     float dbacc = 0.f;
-    const float* xb = x + (size_t)b * L * ED + e;
+    const float* xb = x + (size_t)b * L * ldx + e;
     for (int t = wave; t < L + KS - 1; t += 4) {
         float d = 0.f;
         if (t < L && live) {
             float win[KS];
 #pragma unroll
-            for (int k = 0; k < KS; ++k) { const int tt = t + k - (KS - 1); win[k] = tt >= 0 ? xb[(size_t)tt * ED] : 0.f; }
+            for (int k = 0; k < KS; ++k) { const int tt = t + k - (KS - 1); win[k] = tt >= 0 ? xb[(size_t)tt * ldx] : 0.f; }
             float pre = bv;
 #pragma unroll
             for (int k = 0; k < KS; ++k) pre = fmaf(wk[k], win[k], pre);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __res
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], sp[(t + (KS - 1) - k) * 64 + lane], acc);
-            dx[((size_t)b * L + t) * ED + e] = acc;
+            dx[((size_t)b * L + t) * lddx + e] = acc;
         }
     }
     __syncthreads();
@@ -160,21 +161,21 @@ int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const flo
     return gfe_launch_status();
 }
 
-int gfe_dwconv1d_silu_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
+int gfe_dwconv1d_silu_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
     GFE_REQUIRE(x && w && y, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && L <= 65535 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL((dwconv_silu_fwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)L, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (int)L, (int)ED);
+    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && L <= 65535 && ED > 0 && KS == 4 && ldx >= ED && ldx <= 0x7fffffff, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((dwconv_silu_fwd_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)L, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (int)L, (int)ED, (int)ldx);
     return gfe_launch_status();
 }
 
-int gfe_dwconv1d_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw_zeroed, float* db_zeroed,
+int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_zeroed, float* db_zeroed,
                           int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
     GFE_REQUIRE(x && w && dy && dx && dw_zeroed, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4, GFE_ERR_SHAPE);
+    GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4 && ldx >= ED && lddx >= ED && ldx <= 0x7fffffff && lddx <= 0x7fffffff, GFE_ERR_SHAPE);
     const size_t rows = (size_t)L + 3 > 20 ? (size_t)L + 3 : 20;          // dpre rows, reused for the 4 x 5 partial rows
     GFE_REQUIRE(rows * 64 * sizeof(float) <= 64 * 1024, GFE_ERR_SHAPE);
     hipLaunchKernelGGL((dwconv_silu_bwd_kernel<4>), dim3((unsigned)ceil_div(ED, 64), (unsigned)B), dim3(256), rows * 64 * sizeof(float), (hipStream_t)stream,
-                       x, w, bias, dy, dx, dw_zeroed, db_zeroed, (int)L, (int)ED);
+                       x, w, bias, dy, dx, dw_zeroed, db_zeroed, (int)L, (int)ED, (int)ldx, (int)lddx);
     return gfe_launch_status();
 }
 

@@ -47,6 +47,9 @@ struct S2Fwd {
     float* sdelta;      // (B, nchunks, ED): sum of dt over the chunk (the chunk's decay is exp(A * sum dt): no products)
     float* ckpt;        // (B, nseg, ED, 16) state at the START of every 32-step segment, or NULL (no backward wanted)
     int B, L, ED, T, nchunks, softplus, nseg, bc_bf16;
+    int ld_z, ld_bc;    // row strides (elements) of z and of the B / C rows: the fused Mamba block reads them in place out of the in_proj /
+                        // x_proj outputs (z = xz[:, ED:], B = dBC[:, R:R+16], C = dBC[:, R+16:]) instead of from contiguous copies
+    int a_log;          // A holds A_log (the parameter, mamba.py:160-162): the kernel uses A = -exp(A_log) (mamba.py:232)
 };
 
 // Diagnostic build only (-DGFE_S2_STAMPS, tools/scan_stamps.py): wave 0 of block 0 accumulates s_memtime deltas per phase.
@@ -218,17 +221,18 @@ __global__ __launch_bounds__(512, 4) void sscan2_fwd_kernel(const S2Fwd p) {    
         // 64-bit bases once; per tile only a 32-bit row offset (rows past the chunk end: clamped here, masked in park)
         const T* __restrict__ pu = u + rowbase;
         const T* __restrict__ pd = dl + rowbase;
-        const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
-        const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
+        const T* __restrict__ pz = has_z ? z + ((size_t)b * p.L + t0) * p.ld_z + e0 + 4 * sc : nullptr;
+        const size_t bcbase = ((size_t)b * p.L + t0) * p.ld_bc + 4 * bq;
         const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
         const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
         auto fetch = [&](int tb) {                                    // global -> registers, tile starting at step tb
-            const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
+            const int row = min(tb - t0 + sr, nrows - 1);
+            const int off = row * p.ED;
             ru = *reinterpret_cast<const V4*>(pu + off);
             rd = *reinterpret_cast<const V4*>(pd + off);
-            if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+            if (has_z) rz = *reinterpret_cast<const V4*>(pz + row * p.ld_z);
             if (!STATE_ONLY || tid < 128) {
-                const int boff = min(tb - t0 + br, nrows - 1) * 16;
+                const int boff = min(tb - t0 + br, nrows - 1) * p.ld_bc;
                 if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
                 else rbc = *reinterpret_cast<const f4*>(pbc + boff);
             }
@@ -302,7 +306,9 @@ __global__ __launch_bounds__(512, 4) void sscan2_fwd_kernel(const S2Fwd p) {    
     const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
     const int cl = 8 * w + cw;                                   // channel within the block
     const int e = e0 + cl;
-    f2 A2 = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]} * GFE_LOG2E;
+    f2 A2 = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
+    if (p.a_log) A2 = f2{-fast_exp2(A2.x * GFE_LOG2E), -fast_exp2(A2.y * GFE_LOG2E)};       // A = -exp(A_log)
+    A2 *= GFE_LOG2E;
     f2 h = f2{0.f, 0.f};
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
     if (!STATE_ONLY && p.nchunks > 1) h = chunk_carry<false>(p.hstate, p.sdelta, A2, b, c, e, pr, p.nchunks, p.ED);
@@ -410,6 +416,8 @@ struct S2Bwd {
     float* qstate;                      // (B, nchunks, ED, 16) adjoint carry (chunked plan only)
     const float* sdelta;                // (B, nchunks, ED)
     int B, L, ED, T, nchunks, softplus, nseg, bc_bf16;
+    int ld_z, ld_bc, ld_dbc;            // row strides of z / dz, of the B / C rows, and of the dB / dC accumulation rows (see S2Fwd)
+    int a_log;                          // A holds A_log: A = -exp(A_log), and dA_ws receives the gradient w.r.t. A_log (= dA * A)
 };
 
 constexpr int RSL = TT * 32 + 8;   // slab stride: + 8 floats so that the four (channel & 3) slabs of one ds_write_b64 fall on disjoint banks
@@ -467,20 +475,22 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         const T* __restrict__ pu = u + rowbase;
         const T* __restrict__ pd = dl + rowbase;
         const T* __restrict__ pg = dy + rowbase;
-        const T* __restrict__ pz = has_z ? z + rowbase : nullptr;
+        const size_t zbase = ((size_t)b * p.L + t0) * p.ld_z + e0 + 4 * sc;
+        const T* __restrict__ pz = has_z ? z + zbase : nullptr;
         const T* __restrict__ py = (has_z && !STATE_ONLY) ? ysc + rowbase : nullptr;
-        const size_t bcbase = ((size_t)b * p.L + t0) * 16 + 4 * bq;
+        const size_t bcbase = ((size_t)b * p.L + t0) * p.ld_bc + 4 * bq;
         const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
         const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
         auto fetch = [&](int tb) {                                    // rows past the end: clamped here, masked in park
-            const int off = min(tb - t0 + sr, nrows - 1) * p.ED;
+            const int row = min(tb - t0 + sr, nrows - 1);
+            const int off = row * p.ED;
             if (!STATE_ONLY) ru = *reinterpret_cast<const V4*>(pu + off);
             rd = *reinterpret_cast<const V4*>(pd + off);
             rg = *reinterpret_cast<const V4*>(pg + off);
-            if (has_z) rz = *reinterpret_cast<const V4*>(pz + off);
+            if (has_z) rz = *reinterpret_cast<const V4*>(pz + row * p.ld_z);
             if (has_z && !STATE_ONLY) ry = *reinterpret_cast<const V4*>(py + off);
             if (!STATE_ONLY || tid >= 128) {
-                const int boff = min(tb - t0 + br, nrows - 1) * 16;
+                const int boff = min(tb - t0 + br, nrows - 1) * p.ld_bc;
                 if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
                 else rbc = *reinterpret_cast<const f4*>(pbc + boff);
             }
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 *reinterpret_cast<f4*>(&tl.edt[sr * EPS + 4 * sc]) = vdt;
                 *reinterpret_cast<f4*>(&tl.esg[sr * EPS + 4 * sc]) = vsg;
                 *reinterpret_cast<f4*>(&tl.eg[sr * EPS + 4 * sc]) = vg;
-                if (has_z && valid) *reinterpret_cast<V4*>((T*)p.dz + rowbase + (size_t)(tb - t0 + sr) * p.ED) = Vec4<T>::pack(vgz);   // finished here
+                if (has_z && valid) *reinterpret_cast<V4*>((T*)p.dz + zbase + (size_t)(tb - t0 + sr) * p.ld_z) = Vec4<T>::pack(vgz);   // finished here
             }
             float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
             if (!STATE_ONLY || tid >= 128) {
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
             for (int i = 0; i < 4; ++i) {
                 const int v = lane + 64 * i, t2 = 8 * w + (v >> 5), j = v & 31;
                 const float sum = red[t2 * 32 + j];
-                if (tb + t2 < t1) atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * 16 + (j & 15), sum);
+                if (tb + t2 < t1) atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * p.ld_dbc + (j & 15), sum);
             }
         };
 
@@ -583,7 +593,8 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     const int pr = (lane >> 2) & 7, cw = (lane & 3) | ((lane >> 5) << 2);
     const int cl = 8 * w + cw;
     const int e = e0 + cl;
-    const f2 An = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
+    f2 An = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
+    if (p.a_log) An = f2{-fast_exp2(An.x * GFE_LOG2E), -fast_exp2(An.y * GFE_LOG2E)};       // A = -exp(A_log)
     const f2 A2 = An * GFE_LOG2E;
     const float Dv = p.D ? p.D[e] : 0.f;
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
@@ -726,6 +737,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         *reinterpret_cast<f2*>(p.qstate + sbase) = q;
         return;
     }
+    if (p.a_log) dAacc *= An;                                            // d/dA_log = dA * dA/dA_log = dA * A
     atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr, dAacc.x);
     atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr + 1, dAacc.y);
     // dD / dbias: the 8 owner lanes of a channel (pair bits 2, 3, 4) hold partial sums over their steps
@@ -772,15 +784,20 @@ int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out,
 int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, void* y, void* yscan,
                    float* hstate, float* sdelta, float* ckpt,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream) {
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
+                   int64_t ld_z, int64_t ld_bc, int a_is_log, void* stream) {
     GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && y, GFE_ERR_NULL);
+    if (ld_z <= 0) ld_z = ED;
+    if (ld_bc <= 0) ld_bc = 16;
+    GFE_REQUIRE(ld_z >= ED && ld_z % 4 == 0 && ld_bc >= 16 && ld_bc % 4 == 0 && ld_z <= 0x7fffffff && ld_bc <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
     S2Fwd p;
     p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y; p.yscan = yscan;
     p.hstate = hstate; p.sdelta = sdelta; p.ckpt = ckpt;
     p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
     p.nseg = (int)ceil_div(L, SEG); p.bc_bf16 = bc_dtype == GFE_BF16;
+    p.ld_z = (int)ld_z; p.ld_bc = (int)ld_bc; p.a_log = a_is_log != 0;
     GFE_REQUIRE(p.nchunks <= 65535, GFE_ERR_SHAPE);
     GFE_REQUIRE(p.nchunks == 1 || (hstate && sdelta && T % SEG == 0), GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;
@@ -794,8 +811,13 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void*
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
                    const float* ckpt, float* qstate, const float* sdelta,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream) {
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
+                   int64_t ld_z, int64_t ld_bc, int64_t ld_dbc, int a_is_log, void* stream) {
     GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
+    if (ld_z <= 0) ld_z = ED;
+    if (ld_bc <= 0) ld_bc = 16;
+    if (ld_dbc <= 0) ld_dbc = 16;
+    GFE_REQUIRE(ld_z >= ED && ld_z % 4 == 0 && ld_bc >= 16 && ld_bc % 4 == 0 && ld_dbc >= 16 && ld_z <= 0x7fffffff && ld_bc <= 0x7fffffff && ld_dbc <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && dy && du && ddelta && dA_ws && dB_ws && dC_ws && ckpt, GFE_ERR_NULL);
     GFE_REQUIRE(!z || (dz && yscan), GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
@@ -805,6 +827,7 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void*
     p.ckpt = ckpt; p.qstate = qstate; p.sdelta = sdelta;
     p.B = (int)B; p.L = (int)L; p.ED = (int)ED; p.T = T; p.nchunks = (int)ceil_div(L, T); p.softplus = delta_softplus;
     p.nseg = (int)ceil_div(L, SEG); p.bc_bf16 = bc_dtype == GFE_BF16;
+    p.ld_z = (int)ld_z; p.ld_bc = (int)ld_bc; p.ld_dbc = (int)ld_dbc; p.a_log = a_is_log != 0;
     GFE_REQUIRE(p.nchunks <= 65535, GFE_ERR_SHAPE);
     GFE_REQUIRE(p.nchunks == 1 || (qstate && sdelta && T % SEG == 0), GFE_ERR_SHAPE);
     hipStream_t st = (hipStream_t)stream;

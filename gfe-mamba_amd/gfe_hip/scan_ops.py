@@ -69,7 +69,7 @@ class _SelectiveScan2(torch.autograd.Function):
         y = torch.empty((Bsz, L, ED), device=dev, dtype=dt)
         yscan = torch.empty_like(y) if (need_grad and z_ is not None) else None      # the pre-gate output, for dz in the backward
         call("gfe_sscan2_fwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(y), ptr(yscan),
-             ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, int(bool(delta_softplus)), dtype_code(dt), dtype_code(bcdt), stream())
+             ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, int(bool(delta_softplus)), dtype_code(dt), dtype_code(bcdt), 0, 0, 0, stream())
         ctx.save_for_backward(u_, d_, A_, B_, C_, D_, z_, b_, ckpt, sdelta, yscan)
         ctx.meta = (T, nc, bool(delta_softplus), dt,
                     tuple(None if t is None else t.dtype for t in (u, delta, A, Bm, Cm, D, z, delta_bias)))
@@ -92,7 +92,7 @@ class _SelectiveScan2(torch.autograd.Function):
         call("gfe_sscan2_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_), ptr(yscan),
              ptr(du), ptr(dd), ptr(dz), ptr(dA_ws), ptr(dB_ws), ptr(dC_ws),
              ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
-             ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), stream())
+             ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), 0, 0, 0, 0, stream())
         to = lambda g, i: None if in_dtypes[i] is None else g.to(in_dtypes[i])
         return (to(du, 0), to(dd, 1), to(dA_ws.view(ED, 16), 2), to(dB_ws.view(Bsz, L, 16), 3), to(dC_ws.view(Bsz, L, 16), 4),
                 to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,

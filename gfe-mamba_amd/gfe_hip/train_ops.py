@@ -214,7 +214,7 @@ class _DwConvSiluFn(torch.autograd.Function):
         w_ = w.detach().float().contiguous()
         b_ = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x_)
-        call("gfe_dwconv1d_silu_fwd", ptr(x_), ptr(w_), ptr(b_), ptr(y), B, L, ED, w_.shape[-1], stream())
+        call("gfe_dwconv1d_silu_fwd", ptr(x_), ED, ptr(w_), ptr(b_), ptr(y), B, L, ED, w_.shape[-1], stream())
         ctx.save_for_backward(x_, w_, b_)
         ctx.w_ref, ctx.b_ref = w, bias
         return y
@@ -228,7 +228,7 @@ class _DwConvSiluFn(torch.autograd.Function):
         sw, sb = _grad_slot(ctx.w_ref), (None if b_ is None else _grad_slot(ctx.b_ref))
         dw = sw if sw is not None else torch.zeros_like(w_)
         db = None if b_ is None else (sb if sb is not None else torch.zeros_like(b_))
-        call("gfe_dwconv1d_silu_bwd", ptr(x_), ptr(w_), ptr(b_), ptr(d), ptr(dx), ptr(dw), ptr(db), B, L, ED, w_.shape[-1], stream())
+        call("gfe_dwconv1d_silu_bwd", ptr(x_), ED, ptr(w_), ptr(b_), ptr(d), ptr(dx), ED, ptr(dw), ptr(db), B, L, ED, w_.shape[-1], stream())
         return dx, (None if sw is not None else dw), (None if sb is not None or b_ is None else db)
 
 

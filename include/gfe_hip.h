@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 33
+#define GFE_ABI_VERSION 34
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -78,13 +78,18 @@ int gfe_selective_scan_bwd(const void* u, const void* delta, const float* A, con
  *   hstate (B, nchunks, ED, 16), sdelta (B, nchunks, ED) f32: workspaces, required when nchunks > 1.
  *   ckpt (B, ceil(L/32), ED, 16) f32 or NULL: the forward leaves the state at the start of every 32-step segment there; the backward
  *   recomputes one segment at a time from it with the segment's states in registers.
+ *   ld_z, ld_bc (forward and backward), ld_dbc (backward): row strides in elements of z / dz, of the Bm / Cm rows and of the dB_ws / dC_ws rows
+ *   (0 = contiguous: ED, 16, 16) -- the fused Mamba block (gfe_hip/mamba_block.py) hands the kernel z, B and C IN PLACE inside the
+ *   in_proj / x_proj outputs (mamba.py:204-207, 235-236) and lets it write dz / dB / dC straight into the gradients of those outputs.
+ *   a_is_log != 0: `A` holds the parameter A_log; the kernels use A = -exp(A_log) (mamba.py:232) and dA_ws receives d/dA_log.
  *   yscan (B, L, ED) dtype or NULL: the forward also leaves its output BEFORE the gate (hs.C + D*u) there; the backward needs it when z
  *   is given (dz = dy * silu'(z) * yscan) -- one more output row per step instead of a second sum over states per step in the backward. */
 int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out, int* nchunks_out);
 int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, void* y, void* yscan,
                    float* hstate, float* sdelta, float* ckpt,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream);
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
+                   int64_t ld_z, int64_t ld_bc, int a_is_log, void* stream);
 /*   dA_ws (ED, 16), dB_ws / dC_ws (B, L, 16), dD_ws / dbias_ws (ED) f32: zeroed, accumulated atomically; qstate: workspace like hstate
  *   (nchunks > 1); ckpt, sdelta: as left by gfe_sscan2_fwd with the same T. */
 int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
@@ -92,7 +97,8 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void*
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
                    const float* ckpt, float* qstate, const float* sdelta,
-                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype, void* stream);
+                   int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
+                   int64_t ld_z, int64_t ld_bc, int64_t ld_dbc, int a_is_log, void* stream);
 
 /* Materialised scan H[t] = A[t]*H[t-1] + X[t] (H[-1] = 0) over dim 1 of (B, L, DN) tensors, DN = D*N flattened.
  * Drop-in for cross_atten/pscan.py:226 `pscan(A, X)` (PScan.forward, pscan.py:151-186); inputs are not modified.
@@ -395,8 +401,8 @@ int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const flo
 
 /* Depthwise causal Conv1d(k = 4, padding = 3, [:L]) + bias + SiLU on (B, L, ED) f32 (cross_atten/mamba.py:128-131, 208-212);
  * w: (ED, 1, 4) as nn.Conv1d.weight, bias (ED) or NULL.  Backward: dx, and dw_zeroed / db_zeroed accumulated over the batch. */
-int gfe_dwconv1d_silu_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
-int gfe_dwconv1d_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw_zeroed, float* db_zeroed,
+int gfe_dwconv1d_silu_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
+int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_zeroed, float* db_zeroed,
                           int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
 
 /* out[n] (+)= sum_m x[m][n] for a row-major (M, N) f32 matrix (accumulate != 0: added to what out holds) with row stride ld: the bias gradient of every nn.Linear. */
