@@ -772,31 +772,44 @@ __global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict
 }
 
 // bias_tab[b][cls][channel] = sum over the taps that stay inside the volume for boundary class cls of T[b][tap][row(channel)]
-// One thread per packed row: its <= 27 tap values (summed over the slabs in a fixed order) are read ONCE into registers, then all 64
-// classes are formed from them -- the earlier one-thread-per-(class, row) form re-read the 27 x nslab partials 64 times (20 us a launch).
-__global__ __launch_bounds__(64) void fold_bias_kernel(const float* __restrict__ T, float* __restrict__ tab, const int8_t* __restrict__ taps,
-                                                       int ntaps, int CoutPad, int NT, int nslab) {
-    const int b = blockIdx.y;
-    const int rho = blockIdx.x * 64 + threadIdx.x;           // packed row
-    if (rho >= CoutPad) return;
-    float tv[27];
-    int need[27];      // class bits (1 d == 0, 2 d == D-1, 4 h == 0, 8 h == H-1, 16 w == 0, 32 w == W-1) of the faces the tap steps over:
-                       // the tap leaves the volume for boundary class cls iff cls & need
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        tv[t] = 0.f; need[t] = 63;
-        if (t < ntaps) {
-            float a = 0.f;
+// Block = 64 packed rows x 4 class quarters: the <= 27 tap values of a row (summed over the slabs in a fixed order) are formed ONCE, by the
+// four quarters together, and parked in LDS; every thread then builds 16 of the row's 64 classes from them.  (Round 2 ran one 64-thread
+// block per sample with 27 x nslab dependent loads and 64 x 27 adds per thread: 53 us a launch, nine launches per step on the critical
+// stream; same sums in the same order here, so the tables are bit-identical.)
+__global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict__ T, float* __restrict__ tab, const int8_t* __restrict__ taps,
+                                                        int ntaps, int CoutPad, int NT, int nslab) {
+    __shared__ float stv[27][64];
+    __shared__ int sneed[27];
+    const int b = blockIdx.y, rl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int rho = blockIdx.x * 64 + rl;                    // packed row
+    const bool live = rho < CoutPad;
+    for (int t = q; t < 27; t += 4) {
+        float a = 0.f;
+        if (t < ntaps && live)
             for (int sl = 0; sl < nslab; ++sl) a += T[(((size_t)b * nslab + sl) * ntaps + t) * CoutPad + rho];
-            tv[t] = a;
-            const int dd = taps[3 * t], dh = taps[3 * t + 1], dw = taps[3 * t + 2];
-            need[t] = (dd < 0 ? 1 : dd > 0 ? 2 : 0) | (dh < 0 ? 4 : dh > 0 ? 8 : 0) | (dw < 0 ? 16 : dw > 0 ? 32 : 0);
-        }
+        stv[t][rl] = a;
     }
+    if (threadIdx.x < 27) {
+        // class bits (1 d == 0, 2 d == D-1, 4 h == 0, 8 h == H-1, 16 w == 0, 32 w == W-1) of the faces the tap steps over: the tap leaves
+        // the volume for boundary class cls iff cls & need
+        const int t = threadIdx.x;
+        int need = 63;
+        if (t < ntaps) {
+            const int dd = taps[3 * t], dh = taps[3 * t + 1], dw = taps[3 * t + 2];
+            need = (dd < 0 ? 1 : dd > 0 ? 2 : 0) | (dh < 0 ? 4 : dh > 0 ? 8 : 0) | (dw < 0 ? 16 : dw > 0 ? 32 : 0);
+        }
+        sneed[t] = need;
+    }
+    __syncthreads();
+    if (!live) return;
+    float tv[27];
+    int need[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) { tv[t] = stv[t][rl]; need[t] = sneed[t]; }
     // packed row -> channel (same permutation as the weight packing)
     const int g = rho / (NT * 16), r = rho - g * (NT * 16);
     const int ch = g * NT * 16 + ((r >> 2) & 3) * 4 * NT + (r >> 4) * 4 + (r & 3);
-    for (int cls = 0; cls < 64; ++cls) {
+    for (int cls = 16 * q; cls < 16 * q + 16; ++cls) {
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
@@ -860,7 +873,7 @@ int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)nslab * ntaps * cp * 4, 256), (unsigned)B), dim3(256), 0, st,
                        w_packed_f32, gn_scale, gn_shift, (bf16_t*)w_out, T_ws, nslab, ntaps, cp, (int)Cin);
-    hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)cp, 64), (unsigned)B), dim3(64), 0, st,
+    hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)cp, 64), (unsigned)B), dim3(256), 0, st,
                        T_ws, bias_tab, tap_offsets_dev, ntaps, cp, NT, nslab);
     return gfe_launch_status();
 }
