@@ -116,17 +116,9 @@ class MambaBlock(nn.Module):
 
     def _conv_silu(self, x):
         """Depthwise causal conv1d (k = d_conv, left padding) + bias + SiLU on (B, L, ED)  (mamba.py:208-212)."""
-        if x.is_cuda and self.config.d_conv == 4:
-            return dwconv1d_silu(x, self.conv1d.weight, self.conv1d.bias)      # one fused kernel each way
-        L, k = x.shape[1], self.config.d_conv
-        w = self.conv1d.weight                                   # (ED, 1, k)
-        xp = F.pad(x, (0, 0, k - 1, 0))
-        y = xp[:, 0:L] * w[:, 0, 0]
-        for j in range(1, k):
-            y = y + xp[:, j:j + L] * w[:, 0, j]
-        if self.conv1d.bias is not None:
-            y = y + self.conv1d.bias
-        return F.silu(y)
+        if not x.is_cuda or self.config.d_conv != 4:
+            raise RuntimeError("MambaBlock runs on the GPU only, d_conv = 4 (no CPU fallback)")
+        return dwconv1d_silu(x, self.conv1d.weight, self.conv1d.bias)      # one fused kernel each way
 
     def forward(self, x):
         # x : (B, L, D) -> (B, L, D)                               mamba.py:197-225
@@ -167,34 +159,57 @@ class MambaBlock(nn.Module):
         """The reference's sequential definition (mamba.py:288-318) -- the same function of its inputs, same kernel."""
         return selective_scan_tm(x, delta, A, B, C, D)
 
-    # ---- single-token inference (mamba.py:342-405); not on the classify path, plain torch ops --------------------------
+    # ---- single-token inference (mamba.py:342-405): the projections on the exact-f32 GEMM, the conv / state update on two small kernels ----
     def step(self, x, cache):
+        """x: (B, D); cache = (h (B, ED, N) or None, inputs (B, ED, d_conv - 1)) -> (output (B, D), new cache).  Inference only."""
+        if not x.is_cuda:
+            raise RuntimeError("MambaBlock.step runs on the GPU only (no CPU fallback)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("MambaBlock.step is an inference path: call it under torch.no_grad()")
+        from gfe_hip import call, ptr, stream
+        from gfe_hip.train_ops import linear
+        cfg = self.config
         h, inputs = cache
-        xz = F.linear(x, self.in_proj.weight, self.in_proj.bias)
-        x, z = xz.chunk(2, dim=1)
-        x_cache = x.unsqueeze(2)
-        x = F.conv1d(torch.cat([inputs, x_cache], dim=2), self.conv1d.weight, self.conv1d.bias,
-                     groups=self.config.d_inner)[:, :, 0]
-        x = F.silu(x)
-        y, h = self.ssm_step(x, h)
-        output = F.linear(y * F.silu(z), self.out_proj.weight, self.out_proj.bias)
-        inputs = torch.cat([inputs[:, :, 1:], x_cache], dim=2)
-        return output, (h, inputs)
+        B, ED, N, R = x.shape[0], cfg.d_inner, cfg.d_state, cfg.dt_rank
+        xz = linear(x.float(), self.in_proj.weight, self.in_proj.bias)                       # (B, 2 ED) = [x | z]      mamba.py:351-352
+        inputs = inputs.float().contiguous()
+        xc, new_inputs = torch.empty((B, ED), dtype=torch.float32, device=x.device), torch.empty_like(inputs)
+        call("gfe_mamba_step_conv", ptr(xz), 2 * ED, ptr(inputs), ptr(new_inputs), ptr(self.conv1d.weight.detach().float().contiguous()),
+             ptr(None if self.conv1d.bias is None else self.conv1d.bias.detach().float().contiguous()), ptr(xc), B, ED, cfg.d_conv, stream())
+        dbc = linear(xc, self.x_proj.weight, None)                                            # (B, R + 2N)               :380
+        if self.dt_layernorm is not None:                                                     # Jamba's inner RMSNorms      :384
+            d_, b_, c_ = self._apply_layernorms(*torch.split(dbc, [R, N, N], dim=-1))
+            dbc = torch.cat([d_, b_, c_], dim=-1).contiguous()
+        delta = linear(dbc[:, :R], self.dt_proj.weight, None)                                 # the bias is added with the softplus
+        h_new = torch.empty((B, ED, N), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, ED), dtype=torch.float32, device=x.device)
+        call("gfe_mamba_step_ssm", ptr(xc), ptr(delta), ptr(self.A_log.detach().float().contiguous()), dbc.data_ptr() + 4 * R, dbc.data_ptr() + 4 * (R + N),
+             R + 2 * N, ptr(self.D.detach().float().contiguous()), ptr(self.dt_proj.bias.detach().float().contiguous()), xz.data_ptr() + 4 * ED, 2 * ED,
+             ptr(None if h is None else h.float().contiguous()), ptr(h_new), ptr(y), B, ED, N, stream())
+        output = linear(y, self.out_proj.weight, self.out_proj.bias)                          # :366-368
+        return output, (h_new, new_inputs)
 
     def ssm_step(self, x, h):
-        A = -torch.exp(self.A_log.float())
-        D = self.D.float()
-        deltaBC = F.linear(x, self.x_proj.weight)
-        delta, B, C = torch.split(deltaBC, [self.config.dt_rank, self.config.d_state, self.config.d_state], dim=-1)
-        delta, B, C = self._apply_layernorms(delta, B, C)
-        delta = F.softplus(F.linear(delta, self.dt_proj.weight, self.dt_proj.bias))
-        deltaA = torch.exp(delta.unsqueeze(-1) * A)
-        BX = delta.unsqueeze(-1) * B.unsqueeze(1) * x.unsqueeze(-1)
-        if h is None:
-            h = torch.zeros(x.size(0), self.config.d_inner, self.config.d_state, device=deltaA.device)
-        h = deltaA * h + BX
-        y = (h @ C.unsqueeze(-1)).squeeze(2) + D * x
-        return y, h
+        """mamba.py:374-405: x (B, ED) the conv output, h (B, ED, N) or None -> (y (B, ED) before the gate, new h)."""
+        if not x.is_cuda:
+            raise RuntimeError("MambaBlock.ssm_step runs on the GPU only (no CPU fallback)")
+        from gfe_hip import call, ptr, stream
+        from gfe_hip.train_ops import linear
+        cfg = self.config
+        B, ED, N, R = x.shape[0], cfg.d_inner, cfg.d_state, cfg.dt_rank
+        with torch.no_grad():
+            xc = x.float().contiguous()
+            dbc = linear(xc, self.x_proj.weight, None)
+            if self.dt_layernorm is not None:
+                d_, b_, c_ = self._apply_layernorms(*torch.split(dbc, [R, N, N], dim=-1))
+                dbc = torch.cat([d_, b_, c_], dim=-1).contiguous()
+            delta = linear(dbc[:, :R], self.dt_proj.weight, None)
+            h_new = torch.empty((B, ED, N), dtype=torch.float32, device=x.device)
+            y = torch.empty((B, ED), dtype=torch.float32, device=x.device)
+            call("gfe_mamba_step_ssm", ptr(xc), ptr(delta), ptr(self.A_log.detach().float().contiguous()), dbc.data_ptr() + 4 * R,
+                 dbc.data_ptr() + 4 * (R + N), R + 2 * N, ptr(self.D.detach().float().contiguous()), ptr(self.dt_proj.bias.detach().float().contiguous()),
+                 None, 0, ptr(None if h is None else h.float().contiguous()), ptr(h_new), ptr(y), B, ED, N, stream())
+        return y, h_new
 
 
 def _dt_linear(delta, dt_proj):
@@ -210,6 +225,6 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(d_model))
 
     def forward(self, x):
-        if x.is_cuda:
-            return rmsnorm(x, self.weight, self.eps)
-        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight   # mamba.py:415-416 (step() on CPU)
+        if not x.is_cuda:
+            raise RuntimeError("RMSNorm runs on the GPU only (no CPU fallback)")
+        return rmsnorm(x, self.weight, self.eps)                                 # mamba.py:415-416, one kernel each way

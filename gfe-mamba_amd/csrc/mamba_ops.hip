@@ -142,7 +142,68 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __res
 
 }  // namespace
 
+// ---- single-token inference (cross_atten/mamba.py:342-405): one thread per (sample, channel) ----------------------------------------------
+// conv step: the window is the cached last KS-1 conv inputs + this token's; the cache shifts by one (mamba.py:354-361, 371-372)
+template <int KS>
+__global__ __launch_bounds__(256) void step_conv_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ cin, float* __restrict__ cout,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ xc, int ED) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= ED) return;
+    float win[KS];
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) win[k] = cin[((size_t)b * ED + e) * (KS - 1) + k];
+    win[KS - 1] = x[(size_t)b * ldx + e];
+    float pre = bias ? bias[e] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) pre = fmaf(w[e * KS + k], win[k], pre);
+    xc[(size_t)b * ED + e] = pre * sigmoidf_(pre);
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) cout[((size_t)b * ED + e) * (KS - 1) + k] = win[k + 1];
+}
+
+// ssm step (mamba.py:374-405): h <- exp(dt A) h + dt B x;  y = (h . C + D x) * silu(z), dt = softplus(delta + bias), A = -exp(A_log)
+__global__ __launch_bounds__(256) void step_ssm_kernel(const float* __restrict__ xc, const float* __restrict__ delta, const float* __restrict__ A_log,
+                                                       const float* __restrict__ Bm, const float* __restrict__ Cm, int ld_bc,
+                                                       const float* __restrict__ D, const float* __restrict__ dbias, const float* __restrict__ z, int ld_z,
+                                                       const float* __restrict__ hin, float* __restrict__ hout, float* __restrict__ y, int ED, int N) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= ED) return;
+    const float xv = xc[(size_t)b * ED + e];
+    const float dt = softplusf_(delta[(size_t)b * ED + e] + (dbias ? dbias[e] : 0.f));
+    const float dtx = dt * xv;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float a = fast_exp(dt * -fast_exp(A_log[(size_t)e * N + n]));
+        const size_t hi = ((size_t)b * ED + e) * N + n;
+        const float h = fmaf(a, hin ? hin[hi] : 0.f, dtx * Bm[(size_t)b * ld_bc + n]);
+        hout[hi] = h;
+        acc = fmaf(h, Cm[(size_t)b * ld_bc + n], acc);
+    }
+    acc = fmaf(D ? D[e] : 0.f, xv, acc);
+    if (z) { const float zv = z[(size_t)b * ld_z + e]; acc *= siluf_(zv); }
+    y[(size_t)b * ED + e] = acc;
+}
+
 extern "C" {
+
+int gfe_mamba_step_conv(const float* x, int64_t ldx, const float* cache_in, float* cache_out, const float* w, const float* bias, float* xc,
+                        int64_t B, int64_t ED, int64_t KS, void* stream) {
+    GFE_REQUIRE(x && cache_in && cache_out && w && xc, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && ED > 0 && KS == 4 && ldx >= ED && ldx <= 0x7fffffff, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL((step_conv_kernel<4>), dim3((unsigned)ceil_div(ED, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       x, (int)ldx, cache_in, cache_out, w, bias, xc, (int)ED);
+    return gfe_launch_status();
+}
+
+int gfe_mamba_step_ssm(const float* xc, const float* delta, const float* A_log, const float* Bm, const float* Cm, int64_t ld_bc,
+                       const float* D, const float* delta_bias, const float* z, int64_t ld_z, const float* h_in, float* h_out, float* y,
+                       int64_t B, int64_t ED, int64_t N, void* stream) {
+    GFE_REQUIRE(xc && delta && A_log && Bm && Cm && h_out && y, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && B <= 65535 && ED > 0 && N > 0 && N <= 256 && ld_bc >= N && (!z || ld_z >= ED) && ld_bc <= 0x7fffffff && ld_z <= 0x7fffffff, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(step_ssm_kernel, dim3((unsigned)ceil_div(ED, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       xc, delta, A_log, Bm, Cm, (int)ld_bc, D, delta_bias, z, (int)ld_z, h_in, h_out, y, (int)ED, (int)N);
+    return gfe_launch_status();
+}
 
 int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t rows, int64_t dim, float eps, void* stream) {
     GFE_REQUIRE(x && w && y && rstd, GFE_ERR_NULL);

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 34
+#define GFE_ABI_VERSION 35
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -404,6 +404,17 @@ int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const flo
 int gfe_dwconv1d_silu_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
 int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_zeroed, float* db_zeroed,
                           int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
+
+/* Single-token inference, cross_atten/mamba.py:342-405 (MambaBlock.step / ssm_step), f32:
+ *   gfe_mamba_step_conv: xc = silu(conv1d over [cache (B, ED, 3) | x] + bias), cache_out = the window shifted by one (mamba.py:354-361, 371);
+ *     x has row stride ldx (it is the first half of the in_proj output).
+ *   gfe_mamba_step_ssm:  h_out = exp(dt A) h_in + dt B x, y = (h_out . C + D x) * silu(z) with dt = softplus(delta + delta_bias),
+ *     A = -exp(A_log) (mamba.py:374-405); h_in NULL = zero state; Bm / Cm rows with stride ld_bc, z (NULL = no gate) with stride ld_z. */
+int gfe_mamba_step_conv(const float* x, int64_t ldx, const float* cache_in, float* cache_out, const float* w, const float* bias, float* xc,
+                        int64_t B, int64_t ED, int64_t KS, void* stream);
+int gfe_mamba_step_ssm(const float* xc, const float* delta, const float* A_log, const float* Bm, const float* Cm, int64_t ld_bc,
+                       const float* D, const float* delta_bias, const float* z, int64_t ld_z, const float* h_in, float* h_out, float* y,
+                       int64_t B, int64_t ED, int64_t N, void* stream);
 
 /* out[n] (+)= sum_m x[m][n] for a row-major (M, N) f32 matrix (accumulate != 0: added to what out holds) with row stride ld: the bias gradient of every nn.Linear. */
 int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream);

@@ -35,6 +35,42 @@ def test_mamba_stack_vs_reference_fixture():
     assert e_block < TOL and e_y < TOL and e_gx < TOL and e_g[kw] < TOL
 
 
+def test_token_by_token_step_reproduces_the_references_forward():
+    """Row A11: Mamba.step / MambaBlock.step / ssm_step (cross_atten/mamba.py:342-405) on the kernels (gfe_mamba_step_conv / _ssm + the
+    exact-f32 GEMM).  Fed one token at a time the stack must reproduce, position by position, the full-sequence forward that the REFERENCE
+    computed (fixture t0_mamba.npz `y`) -- the known-answer relation SURVEY section 4 names for ssm_step -- and agree with our own fused
+    full-sequence path."""
+    from cross_atten.mamba import Mamba, MambaConfig
+    fx = golden("t0_mamba.npz")
+    cfg = MambaConfig(d_model=32, n_layers=2)
+    m = Mamba(cfg)
+    m.load_state_dict(sub_sd(fx, "sd."))
+    m = m.to(DEV)
+    x, y_ref = tt(fx["x"], device=DEV), tt(fx["y"])
+    B, L, _ = x.shape
+    # caches as the reference builds them for inference (mamba.py:330-340): (h = None, the last d_conv - 1 conv inputs = zeros)
+    caches = [(None, torch.zeros(B, cfg.d_inner, cfg.d_conv - 1, device=DEV)) for _ in range(cfg.n_layers)]
+    outs = []
+    with torch.no_grad():
+        for t in range(L):
+            o, caches = m.step(x[:, t].contiguous(), caches)
+            outs.append(o)
+        y = torch.stack(outs, 1)
+        y_full = m(x)
+    e_ref, e_full = rel_err(y, y_ref), rel_err(y, y_full)
+    print("token-by-token step vs the reference's forward %.2e, vs the fused full-sequence path %.2e" % (e_ref, e_full))
+    assert e_ref < 1e-5 and e_full < 1e-5
+    # the state the steps leave behind is the scan's final state: one more token must continue the sequence, not restart it
+    with torch.no_grad():
+        o2, caches2 = m.step(x[:, 0].contiguous(), caches)
+        y1, h1 = m.layers[0].mixer.ssm_step(torch.ones(B, cfg.d_inner, device=DEV), None)
+        y2, h2 = m.layers[0].mixer.ssm_step(torch.ones(B, cfg.d_inner, device=DEV), h1)
+    assert not torch.allclose(o2, outs[0]) and caches2[0][0].shape == (B, cfg.d_inner, cfg.d_state)
+    assert torch.isfinite(y2).all() and not torch.allclose(y1, y2)
+    with pytest.raises(RuntimeError):                    # an inference path: refuses to run where autograd would have to record it
+        m.step(x[:, 0].contiguous(), caches)
+
+
 def test_cross_attention_ff_embedder_vs_reference_fixture():
     from cross_atten.corss_ft_transformer import FeedForward, NumericalEmbedder
     from cross_atten.sd_cross_atten import CrossAttention

@@ -1,13 +1,8 @@
-"""Host-side pieces of the Mamba API that need no GPU:
-
-  * npo2 / pad_npo2 (cross_atten/pscan.py:13-33) -- kept for callers of the reference, checked against its semantics and against the
-    sequence lengths the reference pads (37 -> 64, 4096 -> 4096);
-  * the single-token inference path Mamba.step / MambaBlock.step / ssm_step (cross_atten/mamba.py:342-405): fed one token at a time it
-    must reproduce, position by position, the full-sequence forward that the REFERENCE computed (fixture t0_mamba.npz `y`) -- the
-    known-answer relation SURVEY section 4 names for ssm_step."""
+"""Host-side pieces of the Mamba API that need no GPU: npo2 / pad_npo2 (cross_atten/pscan.py:13-33) -- kept for
+callers of the reference, checked against its semantics and against the sequence lengths the reference pads (37 -> 64, 4096 -> 4096).
+(Row A11, the single-token step, runs on the kernels since round 3: tests/test_head_gpu.py.)  The modules themselves refuse CPU tensors."""
+import pytest
 import torch
-
-from conftest import golden, rel_err, sub_sd, tt
 
 
 def test_npo2_and_pad_npo2():
@@ -22,24 +17,13 @@ def test_npo2_and_pad_npo2():
         assert X.shape[1] == L                                                   # the input is not modified
 
 
-def test_token_by_token_step_reproduces_the_references_forward():
-    from cross_atten.mamba import Mamba, MambaConfig
-    fx = golden("t0_mamba.npz")
-    cfg = MambaConfig(d_model=32, n_layers=2)
-    m = Mamba(cfg)
-    m.load_state_dict(sub_sd(fx, "sd."))
-    x, y_ref = tt(fx["x"]), tt(fx["y"])
-    B, L, _ = x.shape
-    # caches as the reference builds them for inference (mamba.py:330-340): (h = None, the last d_conv - 1 conv inputs = zeros)
-    caches = [(None, torch.zeros(B, cfg.d_inner, cfg.d_conv - 1)) for _ in range(cfg.n_layers)]
-    outs = []
-    with torch.no_grad():
-        for t in range(L):
-            o, caches = m.step(x[:, t], caches)
-            outs.append(o)
-    y = torch.stack(outs, 1)
-    assert rel_err(y, y_ref) < 1e-5
-    # the state the steps leave behind is the scan's final state: one more token must continue the sequence, not restart it
-    with torch.no_grad():
-        o2, _ = m.step(x[:, 0], caches)
-    assert not torch.allclose(o2, outs[0])
+def test_modules_refuse_cpu_tensors():
+    """there is no CPU fallback -- a CPU tensor raises instead of silently taking a slow path."""
+    from cross_atten.mamba import Mamba, MambaConfig, RMSNorm
+    m = Mamba(MambaConfig(d_model=32, n_layers=1))
+    with pytest.raises(RuntimeError):
+        RMSNorm(32)(torch.zeros(2, 3, 32))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 3, 32))
+    with pytest.raises(RuntimeError), torch.no_grad():
+        m.step(torch.zeros(2, 32), [(None, torch.zeros(2, 64, 3))])
