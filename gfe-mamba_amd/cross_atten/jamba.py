@@ -125,14 +125,13 @@ class AttentionSDPA(nn.Module):
 
     def forward(self, x, cache=None):
         assert cache is None, "KV-cache decoding is not part of the classification path"
-        if self.training and self.attention_dropout > 0:
-            raise NotImplementedError("attention dropout (Cross_jamba_both passes attn_dropout = 0)")
+        p_drop = self.attention_dropout if self.training else 0.0                 # dropout_p of F.scaled_dot_product_attention (jamba.py:390-392)
         B, L, _ = x.shape
         q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
         if self.num_key_value_groups > 1:                                        # GQA: repeat_kv (jamba.py:558-567) on the projection layout
             rep = lambda t: t.view(B, L, self.num_key_value_heads, 1, self.head_dim).expand(-1, -1, -1, self.num_key_value_groups, -1).reshape(B, L, -1)
             k, v = rep(k), rep(v)
-        o = sdpa_small(q, k, v, self.num_heads, causal=True)                     # F.scaled_dot_product_attention(..., is_causal=True) (:390-392)
+        o = sdpa_small(q, k, v, self.num_heads, causal=True, dropout_p=p_drop)   # F.scaled_dot_product_attention(..., is_causal=True) (:390-392)
         return self.o_proj(o), None
 
 

@@ -173,10 +173,23 @@ __global__ __launch_bounds__(256) void cross_attn_q1_bwd_kernel(const float* __r
 }
 
 
+// counter-based uniform in [0, 1): one 32-bit hash of (seed, element index) -- reproducible from (seed, index) alone, so the backward
+// needs no stored mask and every rank / step draws its own stream by changing the seed
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
 // ---- small self-attention (Jamba's AttentionSDPA, cross_atten/jamba.py:342-398: F.scaled_dot_product_attention, is_causal) ---------
 // block = (head, sample); q, k, v rows of one head staged in LDS (L <= 64, dh <= 64); probs (B, H, L, L) kept for the backward.
+// p_drop > 0: dropout on the attention probabilities (the generator's ViT in training: `attn = self.dropout(attn)`, vit_pytorch_diy/vit.py:59) --
+// the kept probabilities are scaled by 1 / (1 - p); the mask is a counter-based hash of (seed, element), regenerated in the backward; `probs`
+// keeps the UNdropped softmax (what the softmax backward needs).
 __global__ __launch_bounds__(256) void sdpa_small_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                             float* __restrict__ out, float* __restrict__ probs, int H, int L, int dh, float scale, int causal) {
+                                                             float* __restrict__ out, float* __restrict__ probs, int H, int L, int dh, float scale, int causal,
+                                                             float p_drop, uint64_t seed) {
     extern __shared__ float sm[];
     float* sq = sm; float* sk = sq + L * dh; float* sv = sk + L * dh; float* sp = sv + L * dh;      // sp: [L][L]
     const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
@@ -203,7 +216,14 @@ __global__ __launch_bounds__(256) void sdpa_small_fwd_kernel(const float* __rest
         float sum = 0.f;
         for (int c = 0; c < L; ++c) { const float e = __expf(sp[r * L + c] - mx); sp[r * L + c] = e; sum += e; }
         const float inv = 1.0f / sum;
-        for (int c = 0; c < L; ++c) { const float pv = sp[r * L + c] * inv; sp[r * L + c] = pv; probs[(((size_t)b * H + h) * L + r) * L + c] = pv; }
+        const float keep = 1.0f / (1.0f - p_drop);
+        for (int c = 0; c < L; ++c) {
+            const size_t gi = (((size_t)b * H + h) * L + r) * L + c;
+            float pv = sp[r * L + c] * inv;
+            probs[gi] = pv;
+            if (p_drop > 0.f) pv = hash_uniform(seed, (uint32_t)gi) < p_drop ? 0.f : pv * keep;
+            sp[r * L + c] = pv;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < L * dh; i += 256) {
@@ -216,22 +236,27 @@ __global__ __launch_bounds__(256) void sdpa_small_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void sdpa_small_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                              const float* __restrict__ probs, const float* __restrict__ dout,
                                                              float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
-                                                             int H, int L, int dh, float scale) {
+                                                             int H, int L, int dh, float scale, float p_drop, uint64_t seed) {
     extern __shared__ float sm[];
     float* sq = sm; float* sk = sq + L * dh; float* sv = sk + L * dh; float* so = sv + L * dh; float* sp = so + L * dh; float* sd = sp + L * L;
+    float* smk = sd + L * L;                                         // dropout factor per probability: 0 or 1 / (1 - p) (1 without dropout)
     const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
     for (int i = threadIdx.x; i < L * dh; i += 256) {
         const int t = i / dh, d = i - t * dh;
         const size_t o = ((size_t)b * L + t) * dim + h * dh + d;
         sq[i] = q[o]; sk[i] = k[o]; sv[i] = v[o]; so[i] = dout[o];
     }
-    for (int i = threadIdx.x; i < L * L; i += 256) sp[i] = probs[((size_t)b * H + h) * L * L + i];
+    for (int i = threadIdx.x; i < L * L; i += 256) {
+        const size_t gi = ((size_t)b * H + h) * L * L + i;
+        sp[i] = probs[gi];
+        smk[i] = p_drop > 0.f ? (hash_uniform(seed, (uint32_t)gi) < p_drop ? 0.f : 1.0f / (1.0f - p_drop)) : 1.f;
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < L * L; i += 256) {                 // dP = dO V^T
+    for (int i = threadIdx.x; i < L * L; i += 256) {                 // dP = (dO V^T) * dropout factor
         const int r = i / L, c = i - r * L;
         float s = 0.f;
         for (int d = 0; d < dh; ++d) s = fmaf(so[r * dh + d], sv[c * dh + d], s);
-        sd[i] = s;
+        sd[i] = s * smk[i];
     }
     __syncthreads();
     for (int r = threadIdx.x; r < L; r += 256) {                     // dS = P (dP - sum_c P dP) * scale
@@ -246,7 +271,7 @@ __global__ __launch_bounds__(256) void sdpa_small_bwd_kernel(const float* __rest
         for (int c = 0; c < L; ++c) {
             gq = fmaf(sd[t * L + c], sk[c * dh + d], gq);            // dQ_t = sum_c dS[t][c] K_c
             gk = fmaf(sd[c * L + t], sq[c * dh + d], gk);            // dK_t = sum_r dS[r][t] Q_r
-            gv = fmaf(sp[c * L + t], so[c * dh + d], gv);            // dV_t = sum_r P[r][t] dO_r
+            gv = fmaf(sp[c * L + t] * smk[c * L + t], so[c * dh + d], gv);   // dV_t = sum_r dropped P[r][t] dO_r
         }
         const size_t o = ((size_t)b * L + t) * dim + h * dh + d;
         dq[o] = gq; dk[o] = gk; dv[o] = gv;
@@ -373,15 +398,6 @@ __device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + 
 __device__ __forceinline__ float gelu_erf_grad_(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
-// counter-based uniform in [0, 1): one 32-bit hash of (seed, element index) -- reproducible from (seed, index) alone, so the backward
-// needs no stored mask and every rank / step draws its own stream by changing the seed
-__device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t i) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
-}
 // seed_step: NULL, or a device counter added (times an odd constant) to the seed -- a HIP graph bakes the by-value seed into the node,
 // so a replayed step draws a fresh mask only through memory (the captured step increments the counter once, before its forward)
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int F, float p_drop, uint64_t seed,
@@ -488,21 +504,21 @@ int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const 
 }
 
 int gfe_sdpa_small_fwd(const float* q, const float* k, const float* v, float* out, float* probs,
-                       int64_t B, int64_t H, int64_t L, int64_t dh, float scale, int causal, void* stream) {
+                       int64_t B, int64_t H, int64_t L, int64_t dh, float scale, int causal, float p_drop, int64_t seed, void* stream) {
     GFE_REQUIRE(q && k && v && out && probs, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && L > 0 && L <= 64 && dh > 0 && dh <= 64, GFE_ERR_SHAPE);
+    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && L > 0 && L <= 64 && dh > 0 && dh <= 64 && p_drop >= 0.f && p_drop < 1.f && B * H * L * L <= 0x7fffffff, GFE_ERR_SHAPE);
     hipLaunchKernelGGL(sdpa_small_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(3 * L * dh + L * L) * sizeof(float), (hipStream_t)stream,
-                       q, k, v, out, probs, (int)H, (int)L, (int)dh, scale, causal);
+                       q, k, v, out, probs, (int)H, (int)L, (int)dh, scale, causal, p_drop, (uint64_t)seed);
     return gfe_launch_status();
 }
 int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
-                       float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, void* stream) {
+                       float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, float p_drop, int64_t seed, void* stream) {
     GFE_REQUIRE(q && k && v && probs && dout && dq && dk && dv, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && L > 0 && L <= 64 && dh > 0 && dh <= 64, GFE_ERR_SHAPE);
+    GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && L > 0 && L <= 64 && dh > 0 && dh <= 64 && p_drop >= 0.f && p_drop < 1.f && B * H * L * L <= 0x7fffffff, GFE_ERR_SHAPE);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)sdpa_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304); attr = true; }
-    hipLaunchKernelGGL(sdpa_small_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(4 * L * dh + 2 * L * L) * sizeof(float), (hipStream_t)stream,
-                       q, k, v, probs, dout, dq, dk, dv, (int)H, (int)L, (int)dh, scale);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)sdpa_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+    hipLaunchKernelGGL(sdpa_small_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(4 * L * dh + 3 * L * L) * sizeof(float), (hipStream_t)stream,
+                       q, k, v, probs, dout, dq, dk, dv, (int)H, (int)L, (int)dh, scale, p_drop, (uint64_t)seed);
     return gfe_launch_status();
 }
 

@@ -269,6 +269,20 @@ class _UpJoinFn(torch.autograd.Function):
         return dy, dx, dw, None
 
 
+_HOST_SCALARS = {}
+
+
+def _host_scalar(p):
+    """float(p) for a one-element parameter without a device-to-host sync per step: read once per parameter VALUE (keyed on the storage
+    address, the version counter and the optimizer's update counter, which FlatAdam bumps when its kernel rewrites the storage)."""
+    key = (p.data_ptr(), p._version, getattr(p, "_gfe_epoch", (0,))[0])
+    hit = _HOST_SCALARS.get(id(p))
+    if hit is None or hit[0] != key:
+        hit = (key, float(p.detach().float().item()))
+        _HOST_SCALARS[id(p)] = hit
+    return hit[1]
+
+
 class _Out1Fn(torch.autograd.Function):
     """final_conv: 1x1x1, C -> 1, bias; f32 (B, 1, D, H, W) output (model.py:123, 162)."""
 
@@ -277,7 +291,7 @@ class _Out1Fn(torch.autograd.Function):
         w = weight.detach().float().view(-1).contiguous()
         ctx.save_for_backward(x.detach(), w)
         ctx.wshape = weight.shape
-        return K.conv_out1(x.detach(), w, float(bias.detach().float().item()))
+        return K.conv_out1(x.detach(), w, _host_scalar(bias))
 
     @staticmethod
     def backward(ctx, dy):
@@ -331,8 +345,8 @@ def vit_forward_train(vit, img):
     for attn, ff in vit.transformer.layers:                                           # vit.py:76-79
         h = layernorm_rows(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
         q, k, v = linear(h, attn.to_qkv.weight, None).chunk(3, dim=-1)
-        assert attn.dropout.p == 0 or not attn.training or True                      # (attention-probability dropout is not applied here)
-        o = sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), attn.heads, causal=False)
+        p_attn = attn.dropout.p if (attn.training and attn.dropout.training) else 0.0  # `attn = self.dropout(attn)` (vit.py:59): inside the kernel
+        o = sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), attn.heads, causal=False, dropout_p=p_attn)
         x = _dropout(linear(o, attn.to_out[0].weight, attn.to_out[0].bias), attn.to_out[1]) + x
         h = layernorm_rows(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
         h = _dropout(F.gelu(linear(h, ff.net[1].weight, ff.net[1].bias)), ff.net[3])

@@ -120,33 +120,35 @@ def cross_attn_q1(q, k, v, n_heads):
 
 class _SdpaSmall(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, n_heads, causal):
+    def forward(ctx, q, k, v, n_heads, causal, p_drop):
         B, L, dim = q.shape
         dh = dim // n_heads
         q_, k_, v_ = _f(q), _f(k), _f(v)
         out = torch.empty_like(q_)
         probs = torch.empty((B, n_heads, L, L), dtype=torch.float32, device=q.device)
         scale = dh ** -0.5
-        call("gfe_sdpa_small_fwd", ptr(q_), ptr(k_), ptr(v_), ptr(out), ptr(probs), B, n_heads, L, dh, scale, int(bool(causal)), stream())
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0       # host-side draw from torch's CPU generator: no device sync
+        call("gfe_sdpa_small_fwd", ptr(q_), ptr(k_), ptr(v_), ptr(out), ptr(probs), B, n_heads, L, dh, scale, int(bool(causal)), float(p_drop), seed, stream())
         ctx.save_for_backward(q_, k_, v_, probs)
-        ctx.meta = (B, n_heads, L, dh, scale)
+        ctx.meta = (B, n_heads, L, dh, scale, float(p_drop), seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q_, k_, v_, probs = ctx.saved_tensors
-        B, H, L, dh, scale = ctx.meta
+        B, H, L, dh, scale, p_drop, seed = ctx.meta
         d = dout.float().contiguous()
         dq, dk, dv = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
-        call("gfe_sdpa_small_bwd", ptr(q_), ptr(k_), ptr(v_), ptr(probs), ptr(d), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh, scale, stream())
-        return dq, dk, dv, None, None
+        call("gfe_sdpa_small_bwd", ptr(q_), ptr(k_), ptr(v_), ptr(probs), ptr(d), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh, scale, p_drop, seed, stream())
+        return dq, dk, dv, None, None, None
 
 
-def sdpa_small(q, k, v, n_heads, causal=True):
+def sdpa_small(q, k, v, n_heads, causal=True, dropout_p=0.0):
     """F.scaled_dot_product_attention over (B, L, H*dh) projections with equal query / key-value head counts, L <= 64, head dim <= 64
-    (Jamba's attention layer at the classifier's 37 tokens: cross_atten/jamba.py:385-392)."""
+    (Jamba's attention layer at the classifier's 37 tokens: cross_atten/jamba.py:385-392; the generator's ViT in training, where
+    dropout_p is the attention-probability dropout of vit_pytorch_diy/vit.py:59)."""
     _need_cuda(q, "sdpa_small")
-    return _SdpaSmall.apply(q, k, v, n_heads, causal)
+    return _SdpaSmall.apply(q, k, v, n_heads, causal, float(dropout_p))
 
 
 class _LayerNormRows(torch.autograd.Function):

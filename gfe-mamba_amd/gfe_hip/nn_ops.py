@@ -259,7 +259,9 @@ def lift_groupnorm_affine(x, w1, b1, gamma, beta, groups, eps=1e-5):
 def conv3_lift_residual(x, w_packed, tab, cout, vol, lift_w, lift_b, relu=True, pool=True):
     """27-tap conv of x (B, D, H, W, Cin) bf16 with per-sample folded weights + bias table, plus the residual w[c] * vol + b[c]
     recomputed in the epilogue from the one-channel volume (gfe_conv3d_k3_lift_residual).  pool: the epilogue also writes
-    MaxPool3d(2) of the result (attached as `out.pooled2`; the next Encoder takes it instead of re-reading the tensor)."""
+    MaxPool3d(2) of the result (attached as `out.pooled2 = (tensor, out._version)`; the next Encoder takes it instead of re-reading the
+    tensor, provided `out` has not been written since -- an in-place edit bumps the version and the pooling is redone; a re-wrapped tensor
+    has no attribute and is pooled the ordinary way)."""
     B, D, H, W, cin = x.shape
     assert x.dtype == BF16 and x.is_contiguous() and vol.dtype == torch.float32 and vol.is_contiguous() and w_packed.dim() == 5
     out = torch.empty((B, D, H, W, cout), dtype=BF16, device=x.device)
@@ -269,7 +271,7 @@ def conv3_lift_residual(x, w_packed, tab, cout, vol, lift_w, lift_b, relu=True, 
     call("gfe_conv3d_k3_lift_residual", ptr(x), ptr(w_packed), w_packed.stride(0), ptr(tab), ptr(out), B, D, H, W, cin, cout, tptr, int(relu),
          ptr(vol), ptr(lift_w), ptr(lift_b), ptr(pooled), stream())
     if pooled is not None:
-        out.pooled2 = pooled
+        out.pooled2 = (pooled, out._version)      # valid only for THIS content of `out`: the consumer checks the version counter
     return out
 
 

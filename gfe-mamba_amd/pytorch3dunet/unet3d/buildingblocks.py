@@ -168,8 +168,8 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         if self.pooling is not None:
-            pooled = getattr(x, "pooled2", None)          # the producing conv already pooled its result in the epilogue (first block)
-            x = pooled if pooled is not None else K.maxpool2(x)
+            tag = getattr(x, "pooled2", None)             # the producing conv already pooled its result in the epilogue (first block)
+            x = tag[0] if (tag is not None and tag[1] == x._version) else K.maxpool2(x)
         return self.basic_module(x)
 
 

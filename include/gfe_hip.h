@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 35
+#define GFE_ABI_VERSION 36
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -358,11 +358,13 @@ int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const 
                           float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
 
 /* Small multi-head self-attention for Jamba's AttentionSDPA (cross_atten/jamba.py:342-398: F.scaled_dot_product_attention, is_causal
- * when no cache is passed): q, k, v, out (B, L, H*dh) f32, L <= 64, dh <= 64; probs (B, H, L, L) kept for the backward. */
+ * when no cache is passed): q, k, v, out (B, L, H*dh) f32, L <= 64, dh <= 64; probs (B, H, L, L) kept for the backward.
+ * p_drop > 0: dropout on the attention probabilities (the generator's ViT in training, vit_pytorch_diy/vit.py:59), mask = hash of
+ * (seed, element), the same (p_drop, seed) must be given to the backward; probs holds the softmax before the dropout. */
 int gfe_sdpa_small_fwd(const float* q, const float* k, const float* v, float* out, float* probs,
-                       int64_t B, int64_t H, int64_t L, int64_t dh, float scale, int causal, void* stream);
+                       int64_t B, int64_t H, int64_t L, int64_t dh, float scale, int causal, float p_drop, int64_t seed, void* stream);
 int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
-                       float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, void* stream);
+                       float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t L, int64_t dh, float scale, float p_drop, int64_t seed, void* stream);
 
 /* nn.LayerNorm(dim) over (rows, dim) f32 (mamba_transformer.py:79-82, corss_ft_transformer.py:16); mean / rstd (rows) kept for the
  * backward, which ACCUMULATES dgamma / dbeta (f32 atomics) and writes dx.  ws: NULL, or rows * 128 floats of scratch -- with it, rows of

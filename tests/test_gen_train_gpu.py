@@ -160,21 +160,26 @@ def test_transposed_conv_join_backward_vs_torch(cin, cout, shape, full):
     assert e["denc"] == 0.0 and e["dx"] < 1e-2 and e["dw"] < 1e-2, e
 
 
-def test_generator_training_gradients_vs_oracle_autograd():
-    """Reduced-width generator (f_maps 8/16/32, ViT 64x2x2) on 32^3: L1 loss and every parameter gradient against torch autograd through
-    the oracle's generator (CPU fp32) on the same deterministic weights, at the same activation pattern."""
+@pytest.mark.parametrize("tag,vol,f_maps,vit,batch", [
+    ("reduced width 32^3", (32, 32, 32), (8, 16, 32), dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), 2),
+    ("FULL width 64^3", (64, 64, 64), (64, 128, 256), None, 1),
+])
+def test_generator_training_gradients_vs_oracle_autograd(tag, vol, f_maps, vit, batch):
+    """L1 loss and every parameter gradient of the generator training path against torch autograd through the oracle's generator (CPU fp32;
+    its backward is pinned to the reference's own autograd by fixture t9, tests/test_oracle_golden.py) on the same deterministic weights,
+    at the same activation pattern: the reduced-width model on 32^3 (the shape of t9) and the FULL-width model (64 / 128 / 256 channels,
+    ViT 512 x 4 x 6: every channel count of the benchmarked training step) on 64^3."""
     import gfe_hip.det_init as det
     import gfe_hip.gen_train as GT
     from gfe_hip.gen_train import generator_forward_train
     from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
-    vol = (32, 32, 32)
-    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(8, 16, 32), vol_size=vol,
-                                  vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128))
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=f_maps, vol_size=vol, vit_kwargs=vit)
+    vh, vd = (vit or {}).get("heads", 6), (vit or {}).get("depth", 4)
     sd = det.det_state_dict(gen.state_dict(), seed=51, prefix="gtrain.")
     gen.load_state_dict(sd)
     gen = gen.to(DEV).eval()                                      # eval: dropout off on both sides; gradients still flow
-    x = det.det_inputs(2, vol, seed=51)[0]
-    target = torch.tanh(torch.randn(2, 1, *vol, generator=torch.Generator().manual_seed(52)))
+    x = det.det_inputs(batch, vol, seed=51)[0]
+    target = torch.tanh(torch.randn(batch, 1, *vol, generator=torch.Generator().manual_seed(52)))
     tr = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
     GT.PATTERN_LOG = []
     try:
@@ -183,9 +188,9 @@ def test_generator_training_gradients_vs_oracle_autograd():
         pattern, GT.PATTERN_LOG = [_nc(m).cpu() for m in GT.PATTERN_LOG], None
     loss = F.l1_loss(pet, target.to(DEV))
     loss.backward()
-    pet_plain = O.generator(x, {k: v.float() for k, v in sd.items()}, vit_heads=2, vit_depth=2)[2]
+    pet_plain = O.generator(x, {k: v.float() for k, v in sd.items()}, vit_heads=vh, vit_depth=vd)[2]
     with O.activation_pattern(pattern):                            # same ReLU / max-pool pattern (see the block test)
-        _, _, pet_ref = O.generator(x, tr, vit_heads=2, vit_depth=2)
+        _, _, pet_ref = O.generator(x, tr, vit_heads=vh, vit_depth=vd)
     loss_ref = F.l1_loss(pet_ref, target)
     # L1's gradient sign(pet - target) / N is one more piecewise-constant factor: the cotangent is taken at our output's signs
     cot = torch.sign(pet.detach().float().cpu() - target) / target.numel()
@@ -204,8 +209,8 @@ def test_generator_training_gradients_vs_oracle_autograd():
     worst = sorted(((v[0], k) for k, v in errs.items()), reverse=True)[:5]
     med = sorted(v[0] for v in errs.values())[len(errs) // 2]
     wn = max(v[1] for v in errs.values())
-    print("generator training step vs oracle autograd: pet %.2e, L1 loss %.2e; gradient elements: median %.2e, worst %s; worst norm error %.2e"
-          % (e_pet, e_loss, med, [("%.1e" % e, k) for e, k in worst], wn))
+    print("generator training step (%s) vs oracle autograd: pet %.2e, L1 loss %.2e; gradient elements: median %.2e, worst %s; worst norm error %.2e"
+          % (tag, e_pet, e_loss, med, [("%.1e" % e, k) for e, k in worst], wn))
     assert e_pet < 3e-2 and e_loss < 1e-2
     assert med < 2e-2 and worst[0][0] < 6e-2 and wn < 3e-2              # measured 9.5e-3 / 3.2e-2 / 8.9e-3
 

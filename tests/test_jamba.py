@@ -96,3 +96,38 @@ def test_sdpa_small_causal_vs_torch():
         (o * w.cuda()).sum().backward(); (ro * w.double()).sum().backward()
         for a, b in ((gq, cq), (gk, ck), (gv, cv)):
             assert rel_err(a.grad, b.grad) < 1e-5
+
+
+@pytest.mark.gpu
+def test_sdpa_small_attention_probability_dropout():
+    """`attn = self.dropout(softmax(...))` of the generator's ViT in training (vit_pytorch_diy/vit.py:59; ADVICE r02: it used to be dropped
+    silently): the mask lives inside the kernel (a hash of (seed, element), regenerated in the backward).  Recover it with V = identity
+    (the output rows ARE the dropped probabilities), then check output and gradients of a second call with the same seed against torch
+    autograd with that mask, and the keep rate against p."""
+    from gfe_hip.head_ops import sdpa_small
+    g = torch.Generator().manual_seed(9)
+    B, H, L, dh, p = 3, 4, 16, 16, 0.25
+    q, k, v, w = (torch.randn(B, L, H * dh, generator=g) for _ in range(4))
+    eye = torch.eye(L).view(1, L, 1, dh).expand(B, L, H, dh).reshape(B, L, H * dh).contiguous()
+    torch.manual_seed(1234)
+    dropped = sdpa_small(q.cuda(), k.cuda(), eye.cuda(), H, causal=False, dropout_p=p)          # (B, L, H*dh): row r of head h = dropped P[r, :]
+    sp = lambda t: t.view(B, L, H, dh).transpose(1, 2)
+    P = torch.softmax(sp(q.double()) @ sp(k.double()).transpose(-1, -2) * dh ** -0.5, dim=-1)
+    mask = (sp(dropped.cpu()) != 0).double()
+    assert rel_err(sp(dropped.cpu()), P * mask / (1 - p)) < 1e-5
+    keep = mask.mean().item()
+    assert abs(keep - (1 - p)) < 0.03, keep                                                       # 3072 draws: 3 sigma = 0.023
+    gq, gk, gv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    cq, ck, cv = (t.double().requires_grad_(True) for t in (q, k, v))
+    torch.manual_seed(1234)                                                                       # the same seed -> the same mask
+    o = sdpa_small(gq, gk, gv, H, causal=False, dropout_p=p)
+    Pc = torch.softmax(sp(cq) @ sp(ck).transpose(-1, -2) * dh ** -0.5, dim=-1) * mask / (1 - p)
+    ro = (Pc @ sp(cv)).transpose(1, 2).reshape(B, L, H * dh)
+    assert rel_err(o, ro) < 1e-5
+    (o * w.cuda()).sum().backward(); (ro * w.double()).sum().backward()
+    for a, b in ((gq, cq), (gk, ck), (gv, cv)):
+        assert rel_err(a.grad, b.grad) < 1e-5
+    torch.manual_seed(99)                                                                         # another seed -> another mask; p = 0 -> none
+    o2 = sdpa_small(q.cuda(), k.cuda(), eye.cuda(), H, causal=False, dropout_p=p)
+    assert not torch.equal(o2 != 0, dropped != 0)
+    assert (sdpa_small(q.cuda(), k.cuda(), eye.cuda(), H, causal=False) != 0).all()

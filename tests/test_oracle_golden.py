@@ -231,3 +231,48 @@ def test_activation_pattern_replay_reproduces_the_plain_generator():
     for k, v in params.items():
         assert torch.allclose(v.grad, g0[k], atol=1e-5, rtol=1e-5), k
     assert O._PATTERN is None
+
+
+def test_oracle_generator_backward_vs_reference_autograd():
+    """Fixture t9 = the REFERENCE's own autograd through Residual_mid_UNet3D_vit with an L1 loss (main_gan_vit.py:68-82 minus the third-party
+    losses; reduced width, 32^3, eval mode): autograd through the oracle's generator restatement must give the same loss and the same
+    parameter gradients -- what pins the backward that tests/test_gen_train_gpu.py compares the HIP training path with (row f-1)."""
+    import importlib.util
+    import os
+    import torch.nn.functional as F
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("det_init", os.path.join(ROOT, "gfe-mamba_amd", "gfe_hip", "det_init.py"))
+    det = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(det)
+    fx = golden("t9_generator_grads.npz")
+    keys = [k[len("gnorm."):] for k in fx if k.startswith("gnorm.")]
+    nograd = [k[len("nograd."):] for k in fx if k.startswith("nograd.")]
+    vol = (32, 32, 32)
+    # the parameter shapes follow from the fixture's key list + the reduced geometry; regenerate the deterministic weights
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    with torch.device("meta"):
+        tmpl = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(8, 16, 32), vol_size=vol,
+                                       vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128))
+    shapes = {k: tuple(v.shape) for k, v in tmpl.state_dict().items()}
+    sd = det.det_state_dict(shapes, seed=51, prefix="gtrain.")
+    tr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = det.det_inputs(2, vol, seed=51)[0]
+    target = torch.tanh(torch.randn(2, 1, *vol, generator=torch.Generator().manual_seed(52)))
+    _, _, pet = O.generator(x, tr, vit_heads=2, vit_depth=2)
+    loss = F.l1_loss(pet, target)
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) < 1e-6 * max(1.0, float(fx["loss"]))
+    sl = lambda t, n: t.detach().reshape(-1)[::max(1, t.numel() // n)][:n].double()
+    assert rel_err(sl(pet, 256), tt(fx["pet_slice"])) < 2e-5
+    assert set(keys) | set(nograd) == {k for k, v in sd.items() if v.dtype.is_floating_point}
+    worst = 0.0
+    for k in keys:
+        g = tr[k].grad
+        assert g is not None, k
+        e_n = abs(g.double().norm().item() - float(fx["gnorm." + k])) / max(float(fx["gnorm." + k]), 1e-12)
+        e_s = rel_err(sl(g, 64), tt(fx["gslice." + k]))
+        worst = max(worst, e_n, e_s)
+        assert e_n < 1e-4 and e_s < 1e-3, (k, e_n, e_s)
+    for k in nograd:                                       # the reference's dead parameter (model.py:119 mid_linear): no gradient on either side
+        assert tr[k].grad is None, k
+    print("oracle generator backward vs the reference's autograd: worst relative error %.2e over %d tensors" % (worst, len(keys)))

@@ -491,4 +491,6 @@ def test_fused_maxpool_in_the_first_block_epilogue_is_bit_identical(shape):
     assert getattr(y, "pooled2", None) is not None
     y2 = K.conv3_lift_residual(x, w, tab, 64, vol, lw, lb, relu=True, pool=False)
     assert getattr(y2, "pooled2", None) is None and torch.equal(y, y2)
-    assert torch.equal(y.pooled2, K.maxpool2(y2))
+    assert torch.equal(y.pooled2[0], K.maxpool2(y2)) and y.pooled2[1] == y._version
+    y.add_(0)                                                       # an in-place write invalidates the fused pooling: the consumer re-pools
+    assert y.pooled2[1] != y._version

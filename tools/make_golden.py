@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t9] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -343,6 +343,32 @@ def t7(R, out):
     np.savez_compressed(os.path.join(out, "t7_native_step.npz"), **fx)
 
 
+def t9(R, out):
+    """The reference's OWN autograd through its generator (main_gan_vit.py:68-82 minus the third-party losses): L1(model(mri), pet) backward
+    through Residual_mid_UNet3D_vit at reduced width (f_maps 8/16/32, ViT 64 x 2 x 2) on 32^3, eval mode (dropout off).  Pins the BACKWARD of
+    the oracle's generator restatement (whose forward t1 / t2 pin): loss, pet slices, and per-parameter gradient norms + slices."""
+    import torch.nn.functional as F
+    vol = (32, 32, 32)
+    gen = R.model.Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=(8, 16, 32))
+    H, W, p = (vol[1] // 4) * 8, (vol[0] // 32) * (vol[2] // 4), vol[1] // 4
+    gen.mid = R.vit.ViT(image_size=(H, W), patch_size=p, dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128, dropout=0.1, emb_dropout=0.1, channels=32)
+    load_det(gen, 51, "gtrain.")
+    gen.eval()
+    x = det.det_inputs(2, vol, seed=51)[0]
+    target = torch.tanh(torch.randn(2, 1, *vol, generator=torch.Generator().manual_seed(52)))
+    pet = gen(x)
+    loss = F.l1_loss(pet, target)
+    loss.backward()
+    fx = dict(loss=npy(loss.double()), pet_slice=slices(pet), pet_abssum=npy(pet.double().abs().sum()))
+    for k, prm in gen.named_parameters():
+        if prm.grad is None:
+            fx["nograd." + k] = np.zeros(1)
+            continue
+        fx["gnorm." + k] = npy(prm.grad.double().norm())
+        fx["gslice." + k] = slices(prm.grad, 64)
+    np.savez_compressed(os.path.join(out, "t9_generator_grads.npz"), **fx)
+
+
 def t3(R, out):
     """Cross_mamba_ablation (cross_atten/mamba_transformer.py:254-385): the four forward variants + parameter gradients of each."""
     cards, n_cont, dim, depth, heads, vol, Bn = (5, 3, 2), 6, 64, 2, 8, (8, 12, 6), 3
@@ -455,7 +481,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t9", t9)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
