@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from cross_atten.mamba import MambaBlock, MambaConfig, RMSNorm
+from gfe_hip.moe_ops import moe_mlp
 from gfe_hip.head_ops import sdpa_small
 from gfe_hip.train_ops import Linear
 
@@ -166,20 +167,10 @@ class SparseMoEBlock(nn.Module):
         B, L, D = x.shape
         if self.num_experts == 1:                                                # no routing (jamba.py:470-478)
             return self.experts[0](x), torch.ones((B * L, 1), device=x.device, dtype=x.dtype, requires_grad=x.requires_grad)
-        x = x.reshape(-1, D)
-        router_logits = self.router(x)                                           # (B*L, n_experts)
-        routing_weights = F.softmax(router_logits, dim=1, dtype=torch.float)
-        routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
-        routing_weights = routing_weights.to(x.dtype)
-        out = torch.zeros((B * L, D), dtype=x.dtype, device=x.device)
-        expert_mask = F.one_hot(selected_experts, num_classes=self.num_experts).permute(2, 1, 0)      # :493
-        hit = expert_mask.sum((1, 2)).tolist()                                   # one host read for all experts (the reference reads per expert)
-        for e in range(self.num_experts):
-            if hit[e] == 0:
-                continue
-            idx, top_x = torch.where(expert_mask[e])
-            cur = self.experts[e](x[top_x]) * routing_weights[top_x, idx, None]  # :508-509
-            out.index_add_(0, top_x, cur.to(x.dtype))                            # :513
+        # routing, expert sort, the three grouped projections and the weighted combine: gfe_hip/moe_ops.py over csrc/moe.hip (one launch per
+        # projection for ALL experts, no host synchronisation); the router logits are returned as the reference does (:517)
+        out, router_logits = moe_mlp(x.reshape(-1, D), self.top_k, self.router.weight, [e.gate_proj.weight for e in self.experts],
+                                     [e.up_proj.weight for e in self.experts], [e.down_proj.weight for e in self.experts])
         return out.reshape(B, L, D), router_logits
 
 
@@ -197,11 +188,12 @@ class MLP(nn.Module):
 
 
 def load_balancing_loss(router_logits, num_experts, num_experts_per_tok):
-    """jamba.py:537-556 (not used by the classification scripts; kept for API completeness)."""
-    router_logits = torch.cat([r for r in router_logits if r.shape[1] > 1], dim=0)
-    routing_weights = F.softmax(router_logits, dim=-1)
-    _, selected_experts = torch.topk(routing_weights, num_experts_per_tok, dim=-1)
-    expert_mask = F.one_hot(selected_experts, num_experts)
-    tokens_per_expert = torch.mean(expert_mask.float(), dim=0)
-    router_prob_per_expert = torch.mean(routing_weights, dim=0)
-    return torch.sum(tokens_per_expert * router_prob_per_expert.unsqueeze(0)) * num_experts
+    """The auxiliary balance term of jamba.py:537-556 (not used by the classification scripts; kept because callers of the reference can
+    import it): num_experts * sum over (top-k slot, expert) of [fraction of tokens whose slot picked the expert] * [mean router probability of
+    the expert], over the layers that route (more than one expert)."""
+    logits = torch.cat([r for r in router_logits if r.shape[1] > 1], dim=0)
+    probs = logits.softmax(dim=-1)                                                     # (tokens, E)
+    chosen = probs.topk(num_experts_per_tok, dim=-1).indices                           # (tokens, k)
+    picked = torch.zeros((num_experts_per_tok, num_experts), dtype=probs.dtype, device=probs.device)
+    picked.scatter_add_(1, chosen.t(), torch.ones_like(chosen.t(), dtype=probs.dtype))     # tokens per (slot, expert)
+    return num_experts * (picked / logits.shape[0] * probs.mean(dim=0)).sum()

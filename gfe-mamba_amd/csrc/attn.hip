@@ -140,7 +140,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
     const v4i_t rs_k = make_rsrc(kb, row_bytes_k), rs_v = make_rsrc(vb, row_bytes_v);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     auto dma16 = [&](const v4i_t& rs, unsigned lds_base, unsigned voff) {     // 64 lanes x 16 B -> LDS [lds_base + 16 * lane]
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_base), "v"(voff), "s"(rs) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_base), "v"(voff), "s"(rs));      // (m0 is a reserved register for hipcc: it sets it right before each of its own uses, and cannot be named as a clobber)
     };
     auto dma = [&](int t, int buf) {
         // 16 pieces per tile pair (8 K + 8 V), 2 per wave: piece pc covers rows 8*pc .. 8*pc+7 of K or V

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 36
+#define GFE_ABI_VERSION 37
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -406,6 +406,30 @@ int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const flo
 int gfe_dwconv1d_silu_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
 int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_zeroed, float* db_zeroed,
                           int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
+
+/* Sparse mixture-of-experts MLP, cross_atten/jamba.py:441-535 (SparseMoEBlock: router -> softmax -> top-k -> per-expert
+ * down(silu(gate(x)) * up(x)) -> weighted sum), row f-2.  csrc/moe.hip: the (token, expert) pairs are sorted by expert on the device
+ * (stable counting sort, no host sync), every projection of ALL experts is one grouped exact-f32 GEMM, the combine is a gather.  f32.
+ *   gfe_moe_route: logits (T, E) -> rw (T, K) routing probabilities, sel (T, K) expert ids (descending probability), tok_sorted (T*K)
+ *     token of every pair in expert order, pos (T, K) position of pair (t, k) in that order, seg (E + 1) expert offsets.  E <= 64.
+ *   gfe_moe_route_bwd: d logits from d rw (softmax over all E, gathered at sel; jamba.py:487-489).
+ *   gfe_moe_gemm_rows: C[seg[e] + r][n] (+)= sum_k A[row][k] W_e(n, k) with row = gather ? gather[seg[e] + r] : seg[e] + r and
+ *     W_e = w_table[e] K-major (a Linear's forward) or, w_tr != 0, reduction-major (its dgrad).  P = T*K rows in all.
+ *   gfe_moe_gemm_wgrad: dW_e[n][k] (+)= sum_{r in segment e} dY[seg[e] + r][n] X[row][k], dW_e = dw_table[e].
+ *   gfe_moe_act_fwd / _bwd: h = silu(g) * u and its adjoint.  gfe_moe_combine: out[t] (+)= sum_k w[t][k] rows[pos[t][k]] (w NULL: 1).
+ *   gfe_moe_combine_bwd: d_rows[pos[t][k]] = w[t][k] dout[t], dw[t][k] = <dout[t], o[pos[t][k]]>. */
+int gfe_moe_route(const float* logits, int64_t T, int64_t E, int64_t K, float* rw, int32_t* sel, int32_t* tok_sorted, int32_t* pos, int32_t* seg,
+                  void* stream);
+int gfe_moe_route_bwd(const float* logits, const int32_t* sel, const float* drw, float* dlogits, int64_t T, int64_t E, int64_t K, void* stream);
+int gfe_moe_gemm_rows(const float* A, int64_t lda, const int32_t* gather, const float* const* w_table, int64_t ldw, int w_tr, float* C, int64_t ldc,
+                      const int32_t* seg, int64_t E, int64_t P, int64_t N, int64_t K, int accumulate, void* stream);
+int gfe_moe_gemm_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx, const int32_t* gather, float* const* dw_table, int64_t lddw,
+                       const int32_t* seg, int64_t E, int64_t N, int64_t K, int accumulate, void* stream);
+int gfe_moe_act_fwd(const float* g, const float* u, float* h, int64_t n, void* stream);
+int gfe_moe_act_bwd(const float* g, const float* u, const float* dh, float* dg, float* du, int64_t n, void* stream);
+int gfe_moe_combine(const float* rows, const float* w, const int32_t* pos, float* out, int64_t T, int64_t K, int64_t D, int accumulate, void* stream);
+int gfe_moe_combine_bwd(const float* dout, const float* o, const float* w, const int32_t* pos, float* d_rows, float* dw, int64_t T, int64_t K, int64_t D,
+                        void* stream);
 
 /* Single-token inference, cross_atten/mamba.py:342-405 (MambaBlock.step / ssm_step), f32:
  *   gfe_mamba_step_conv: xc = silu(conv1d over [cache (B, ED, 3) | x] + bias), cache_out = the window shifted by one (mamba.py:354-361, 371);

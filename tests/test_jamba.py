@@ -131,3 +131,88 @@ def test_sdpa_small_attention_probability_dropout():
     o2 = sdpa_small(q.cuda(), k.cuda(), eye.cuda(), H, causal=False, dropout_p=p)
     assert not torch.equal(o2 != 0, dropped != 0)
     assert (sdpa_small(q.cuda(), k.cuda(), eye.cuda(), H, causal=False) != 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,Fd,E,K", [(111, 64, 128, 16, 2), (7, 32, 48, 4, 1), (300, 64, 96, 16, 3), (37, 24, 40, 5, 2)])
+def test_moe_mlp_vs_the_references_expert_loop(T, D, Fd, E, K):
+    """gfe_hip.moe_ops.moe_mlp (device routing + expert sort, grouped GEMMs, gather combine) against the reference's algorithm written out in
+    torch f64 -- softmax -> topk -> per-expert down(silu(gate x) * up x) * routing weight -> index_add (jamba.py:484-517) -- output, router
+    logits and every gradient (x, router, all 3 E expert matrices; experts that receive no token get a zero gradient), ragged sizes included."""
+    from gfe_hip.moe_ops import moe_mlp
+    g = torch.Generator().manual_seed(T + E)
+    x = torch.randn(T, D, generator=g)
+    wr = torch.randn(E, D, generator=g) * 0.5
+    wg = [torch.randn(Fd, D, generator=g) / D ** 0.5 for _ in range(E)]
+    wu = [torch.randn(Fd, D, generator=g) / D ** 0.5 for _ in range(E)]
+    wd = [torch.randn(D, Fd, generator=g) / Fd ** 0.5 for _ in range(E)]
+    w = torch.randn(T, D, generator=g)
+    if E == 5:
+        wr[4] = -10.0 * wr[0].abs() - 5                          # an expert nobody is routed to (its logit is always far below)
+        x = x.abs()
+    dev = lambda t: t.clone().to("cuda").requires_grad_(True)
+    gx, gwr, gwg, gwu, gwd = dev(x), dev(wr), [dev(t) for t in wg], [dev(t) for t in wu], [dev(t) for t in wd]
+    out, logits = moe_mlp(gx, K, gwr, gwg, gwu, gwd)
+    (out * w.cuda()).sum().backward()
+    dd = lambda t: t.clone().double().requires_grad_(True)
+    cx, cwr, cwg, cwu, cwd = dd(x), dd(wr), [dd(t) for t in wg], [dd(t) for t in wu], [dd(t) for t in wd]
+    rl = cx @ cwr.t()
+    rw, sel = torch.topk(F.softmax(rl, dim=1), K, dim=-1)
+    ref = torch.zeros(T, D, dtype=torch.float64)
+    for e in range(E):
+        idx, top_x = torch.where(F.one_hot(sel, E).permute(2, 1, 0)[e])
+        if top_x.numel():
+            xe = cx[top_x]
+            ref = ref.index_add(0, top_x, (F.silu(xe @ cwg[e].t()) * (xe @ cwu[e].t())) @ cwd[e].t() * rw[top_x, idx, None])
+    (ref * w.double()).sum().backward()
+    assert rel_err(logits, rl) < 1e-5 and rel_err(out, ref) < 1e-5
+    assert rel_err(gx.grad, cx.grad) < 1e-5 and rel_err(gwr.grad, cwr.grad) < 1e-4
+    used = 0
+    for e in range(E):
+        for a, b in ((gwg[e], cwg[e]), (gwu[e], cwu[e]), (gwd[e], cwd[e])):
+            if b.grad is None or float(b.grad.abs().max()) == 0.0:
+                assert float(a.grad.abs().max()) == 0.0, e
+            else:
+                used += 1
+                assert rel_err(a.grad, b.grad) < 1e-5, e
+    assert used >= 3
+
+
+@pytest.mark.gpu
+def test_cross_jamba_both_at_the_classify_configuration_vs_reference_fixture():
+    """Fixture t8: the reference's Cross_jamba_both at classify_mamba.py's configuration (dim 512, depth 6 -> 12 layers, heads 8, 16-expert
+    top-2 MoE on the odd layers, 208.5 M parameters, default d_cross = 160*160), two samples with native 160x160x96 image conditions:
+    logits, loss and every parameter gradient (norm + 16-element slice).  Weights and inputs regenerate from the deterministic initialiser."""
+    import zlib
+    import gfe_hip.det_init as det
+    from cross_atten.mamba_transformer import Cross_jamba_both
+    fx = golden("t8_jamba_classify.npz")
+    cards, n_cont, dim, depth, heads, vol, Bn = (11, 2, 2, 4, 4, 3, 3), 25, 512, 6, 8, (160, 160, 96), 2
+    ft = Cross_jamba_both(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads)
+    assert sum(p.numel() for p in ft.parameters()) == int(fx["nparams"])
+    ft.load_state_dict(det.det_state_dict(ft.state_dict(), seed=81, prefix="jam8."))
+    x, x_cat, x_num, y = det.det_inputs(Bn, vol, cards, n_cont, seed=81)
+    rnd = lambda key, shape: torch.from_numpy(np.random.Generator(np.random.Philox(key=[zlib.crc32(key.encode()), 12345])).standard_normal(shape).astype(np.float32))
+    pet, feat = rnd("jam8.pet", (Bn, 1) + vol), rnd("jam8.feat", (Bn, 4, dim))
+    ft = ft.cuda().eval()
+    pred = ft(x_cat.cuda(), x_num.cuda(), feat.cuda(), [x.cuda(), pet.cuda()])
+    e_pred = rel_err(pred, tt(fx["pred"]))
+    loss = F.binary_cross_entropy(torch.sigmoid(pred.squeeze(1)), y.cuda().float())
+    e_loss = abs(loss.item() - float(fx["loss"]))
+    loss.backward()
+    errs, unused = [], 0
+    for k, p in ft.named_parameters():
+        ref = float(fx["gnorm." + k])
+        if ref < 1e-9:                                  # experts no token was routed to (reference gradient None); k_proj.bias (exactly
+            unused += ".experts." in k                  # zero in exact arithmetic: softmax is shift-invariant; round-off on both sides)
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-8, k
+            continue
+        e_n = abs(float(p.grad.double().norm()) - ref) / ref
+        e_s = rel_err(_slices(p.grad, 16), tt(fx["gslice." + k]))
+        errs.append((max(e_n, e_s), k))
+    errs.sort(reverse=True)
+    print("Cross_jamba_both (classify configuration, 208.5 M parameters) vs reference: logits %.2e, loss %.2e, gradients: median %.2e, worst %s; "
+          "%d expert matrices unused" % (e_pred, e_loss, errs[len(errs) // 2][0], [("%.1e" % e, k) for e, k in errs[:4]], unused))
+    # f32 everywhere except the K / V projections over the (bf16) image condition
+    assert e_pred < 5e-3 and e_loss < 2e-3
+    assert errs[len(errs) // 2][0] < 5e-3 and errs[0][0] < 3e-2

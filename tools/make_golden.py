@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t9] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t8|t9] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -441,6 +441,30 @@ def t6(R, out):
     np.savez_compressed(os.path.join(out, "t6_jamba.npz"), **fx)
 
 
+def t8(R, out):
+    """Cross_jamba_both at the CLASSIFY configuration (classify_mamba.py:14, 36-51 with Cross_jamba_both in place of Cross_mamba_both:
+    dim 512, depth 6 -> 12 Jamba layers, heads 8, 16-expert top-2 MoE on the odd layers: 208.5 M parameters), default constructor
+    (d_cross = 160*160), two samples with native-size 160x160x96 image conditions.  Nothing but results is stored: weights and inputs
+    regenerate from the deterministic initialiser on both sides."""
+    cards, n_cont, dim, depth, heads, vol, Bn = (11, 2, 2, 4, 4, 3, 3), 25, 512, 6, 8, (160, 160, 96), 2
+    ft = R.mt.Cross_jamba_both(categories=cards, num_continuous=n_cont, dim=dim, depth=depth, heads=heads, dim_head=dim // heads)
+    load_det(ft, 81, "jam8.")
+    ft.eval()
+    x, x_cat, x_num, y = det.det_inputs(Bn, vol, cards, n_cont, seed=81)
+    pet = rnd_det("jam8.pet", (Bn, 1) + vol)
+    feat = rnd_det("jam8.feat", (Bn, 4, dim))
+    pred = ft(x_cat, x_num, feat, [x, pet])
+    loss = torch.nn.BCELoss()(torch.sigmoid(pred.squeeze(1)), y.float())
+    loss.backward()
+    fx = dict(meta=np.array(list(cards) + [n_cont, dim, depth, heads] + list(vol) + [Bn]), pred=npy(pred.double()), loss=npy(loss.double()),
+              nparams=np.array(sum(p.numel() for p in ft.parameters())))
+    for k, p in ft.named_parameters():
+        fx["gnorm." + k] = npy(p.grad.double().norm()) if p.grad is not None else np.array(-1.0)
+        if p.grad is not None:
+            fx["gslice." + k] = slices(p.grad, 16).astype(np.float32)
+    np.savez_compressed(os.path.join(out, "t8_jamba_classify.npz"), **fx)
+
+
 def t5(R, out):
     """table/deal_table.py:28-61 `prepare_table` on a synthetic TADPOLE-like frame: bookkeeping and baseline columns to drop, string
     categoricals (with missing values and a numeric-looking string column that contains letters), numeric columns with missing and
@@ -481,7 +505,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t9", t9)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t8", t8), ("t9", t9)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
