@@ -53,6 +53,8 @@ struct AttnParams {
     int H, n;
     int nqb, total;               // query blocks per (batch, head); blocks in the grid
     float c;                      // scale * log2(e): scores are kept in log2 units
+    float* nlse;                  // optional (training): -(m + log2 l) per row, [B][H][npad], rows n .. npad-1 = -inf (attn_bwd.hip)
+    int npad;
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -233,8 +235,11 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
                     if (h4 >= lim - crow(r, 0)) s[r] = -INFINITY;        // key index crow(r, 0) + 4 hi >= lim
             }
             // (v_max3 from asm: fmaxf() on MFMA outputs makes hipcc canonicalise every operand with an extra v_max_f32 x, x, x first)
+            // A VALU read of an MFMA result needs software wait states (11 after this 8-pass MFMA) and hipcc's hazard recogniser does not look
+            // inside inline asm: without the s_nops the steady-state path read s[0..2] before the matrix core had written them (the previous
+            // block's p values) -- spurious, harmless but run-to-run different moves of m.  The rest of the chain depends on this statement.
             float mx;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
+            asm("s_nop 7\n\ts_nop 3\n\tv_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
 #pragma unroll
             for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
             asm("v_max3_f32 %0, %1, %2, %2" : "=v"(mx) : "v"(mx), "v"(s[15]));
@@ -281,8 +286,15 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
             }
         }
         // tile t+1 has landed (this wave's pieces; the barrier makes all of it visible) while tile t+2's pieces, issued above, stay in flight
+#if defined(GFE_ATTN_EXP_DRAIN)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#elif defined(GFE_ATTN_EXP_2BAR)
+        if (RING > 2 && t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_barrier" ::: "memory");
+#else
         if (RING > 2 && t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     };
     static_assert(RING == 3, "the tile loop is unrolled by the ring depth");
     for (int t = 0; t < ntile; t += 3) {
@@ -295,6 +307,8 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
     const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / l;
     const int q = q0 + ql;
+    if (p.nlse && hi == 0 && q < p.npad)        // the backward restarts its score chains from this value: exp2(S + nlse) = the normalised probability
+        p.nlse[(size_t)bh * p.npad + q] = q < p.n ? negm[0] - __builtin_amdgcn_logf(l) : -INFINITY;   // (v_log_f32 is log2)
     if (q < p.n) {
         bf16_t* op = p.o + (size_t)b * p.o_batch + (size_t)q * p.o_row + h * AD;
 #pragma unroll
@@ -313,9 +327,9 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 
 extern "C" {
 
-int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t n, int64_t dh,
-                      int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
-                      int64_t o_batch, int64_t o_row, float scale, void* stream) {
+static int attention_fwd_launch(const void* q, const void* k, const void* v, void* o, float* nlse, int64_t B, int64_t H, int64_t n, int64_t dh,
+                                int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
+                                int64_t o_batch, int64_t o_row, float scale, void* stream) {
     GFE_REQUIRE(q && k && v && o, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && H > 0 && n > 0 && dh == AD && B * H <= 65535 && n <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(q_row % 8 == 0 && k_row % 8 == 0 && v_row % 8 == 0 && o_row % 4 == 0, GFE_ERR_SHAPE);       // 16-byte loads, 8-byte stores
@@ -324,12 +338,26 @@ int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int6
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
     p.q_batch = q_batch; p.q_row = q_row; p.k_batch = k_batch; p.k_row = k_row; p.v_batch = v_batch; p.v_row = v_row;
     p.o_batch = o_batch; p.o_row = o_row; p.H = (int)H; p.n = (int)n; p.c = scale * GFE_LOG2E;
+    p.nlse = nlse; p.npad = (int)(ceil_div(n, 64) * 64);
     p.nqb = (int)ceil_div(n, ANW * QW);
     const int64_t total = (int64_t)p.nqb * B * H;
     GFE_REQUIRE(total <= 0x7fffffff, GFE_ERR_SHAPE);
     p.total = (int)total;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)total), dim3(ANW * 64), 2 * RING * TILE_BYTES, (hipStream_t)stream, p);
     return gfe_launch_status();
+}
+
+int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t n, int64_t dh,
+                      int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
+                      int64_t o_batch, int64_t o_row, float scale, void* stream) {
+    return attention_fwd_launch(q, k, v, o, nullptr, B, H, n, dh, q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale, stream);
+}
+
+int gfe_attention_fwd_lse(const void* q, const void* k, const void* v, void* o, void* nlse, int64_t B, int64_t H, int64_t n, int64_t dh,
+                          int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
+                          int64_t o_batch, int64_t o_row, float scale, void* stream) {
+    GFE_REQUIRE(nlse, GFE_ERR_NULL);
+    return attention_fwd_launch(q, k, v, o, (float*)nlse, B, H, n, dh, q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale, stream);
 }
 
 }  // extern "C"

@@ -476,14 +476,36 @@ def layernorm(x, gamma, beta, rows, length, out_dtype, in_map=None, out_map=None
     return out
 
 
-def attention_fwd(q, k, v, B, H, n, dh, scale):
+def attention_fwd(q, k, v, B, H, n, dh, scale, with_lse=False):
     """Flash-style attention for long sequences (gfe_attention_fwd): q/k/v (B*n, >= H*dh) bf16 views with a common layout
-    (row strides allowed), dh == 64 -> (B*n, H*dh) bf16."""
+    (row strides allowed), dh == 64 -> (B*n, H*dh) bf16.  with_lse: also the (B, H, npad) f32 row statistic -(max + log2 sum) that
+    attention_bwd restarts from (gfe_attention_fwd_lse)."""
     assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
     o = torch.empty((B * n, H * dh), dtype=BF16, device=q.device)
-    call("gfe_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), B, H, n, dh, n * q.stride(0), q.stride(0), n * k.stride(0), k.stride(0),
-         n * v.stride(0), v.stride(0), n * H * dh, H * dh, float(scale), stream())
-    return o
+    strides = (n * q.stride(0), q.stride(0), n * k.stride(0), k.stride(0), n * v.stride(0), v.stride(0), n * H * dh, H * dh)
+    if not with_lse:
+        call("gfe_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), B, H, n, dh, *strides, float(scale), stream())
+        return o
+    nlse = torch.empty((B, H, -(-n // 64) * 64), dtype=torch.float32, device=q.device)
+    call("gfe_attention_fwd_lse", ptr(q), ptr(k), ptr(v), ptr(o), ptr(nlse), B, H, n, dh, *strides, float(scale), stream())
+    return o, nlse
+
+
+def attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, scale, dqkv=None):
+    """gfe_attention_bwd: gradients of attention_fwd(with_lse=True).  q/k/v: bf16 views with ONE common layout (slices of a (B*n, 3*H*dh)
+    projection output), o/dout: (B*n, H*dh) bf16 -> (dq, dk, dv) bf16 views of one (B*n, 3*H*dh) buffer (`dqkv`, allocated if None): the
+    layout the to_qkv weight-gradient GEMM consumes.  Deterministic (no atomics)."""
+    inner = H * dh
+    assert q.stride() == k.stride() == v.stride() and q.stride(1) == 1 and o.is_contiguous() and dout.is_contiguous() and dout.dtype == BF16
+    if dqkv is None:
+        dqkv = torch.empty((B * n, 3 * inner), dtype=BF16, device=q.device)
+    dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
+    npad = nlse.shape[-1]
+    qs = torch.empty((B * H * npad, dh), dtype=BF16, device=q.device)
+    ndelta = torch.empty((B * H * npad,), dtype=torch.float32, device=q.device)
+    call("gfe_attention_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(nlse), ptr(dq), ptr(dk), ptr(dv), ptr(qs), ptr(ndelta),
+         B, H, n, dh, n * q.stride(0), q.stride(0), n * inner, inner, n * dqkv.stride(0), dqkv.stride(0), float(scale), stream())
+    return dq, dk, dv
 
 
 def attention_small(q, k, v, B, H, nq, nk, dh, scale):

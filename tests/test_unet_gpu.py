@@ -269,6 +269,36 @@ def test_flash_attention_moved_maximum_branch():
     assert e < 2.5e-2, e              # scores of +-200 here: three orders of magnitude beyond a trained ViT's logits
 
 
+@pytest.mark.parametrize("B,H,n", [(2, 8, 1729), (1, 2, 64), (1, 3, 65), (2, 1, 127), (1, 2, 300), (1, 1, 1), (1, 2, 513)])
+def test_flash_attention_backward_vs_autograd(B, H, n):
+    """gfe_attention_bwd (dK/dV and dQ kernels, no atomics) against f64 autograd through softmax(q k^T / sqrt(d)) v on the same bf16
+    inputs (what the reference's vit_3d.py:47-57 does under autograd): ragged key tiles / query blocks, single token; the row statistic
+    of the training forward against logsumexp; bitwise repeatability."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(1000 + n)
+    dh = 64
+    inner = H * dh
+    qkv = (torch.randn(B * n, 3 * inner, generator=g) * 1.5).to(BF).to(DEV)
+    dout = torch.randn(B * n, inner, generator=g).to(BF).to(DEV)
+    q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    o, nlse = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True)
+    assert torch.equal(o, K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5))                 # the training forward is the same kernel
+    dq, dk, dv = K.attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, dh ** -0.5)
+    dq2, dk2, dv2 = K.attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, dh ** -0.5)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    qd, kd, vd = [t.double().view(B, n, H, dh).transpose(1, 2).requires_grad_() for t in qkv.cpu().chunk(3, dim=-1)]
+    sc = qd @ kd.transpose(-1, -2) * dh ** -0.5
+    ref = (torch.softmax(sc, dim=-1) @ vd).transpose(1, 2).reshape(B * n, inner)
+    gq, gk, gv = torch.autograd.grad(ref, (qd, kd, vd), dout.double().cpu())
+    lse2 = torch.logsumexp(sc.detach(), dim=-1) * 1.4426950408889634
+    e_l = (nlse[:, :, :n].double().cpu() + lse2).abs().max().item()
+    assert e_l < 0.05, e_l                                                                   # log2 units; Q is rounded once more (scale folded in)
+    assert torch.isinf(nlse[:, :, n:]).all() and (nlse[:, :, n:] < 0).all()
+    errs = [rel_err(a, b.transpose(1, 2).reshape(B * n, inner)) for a, b in ((dq, gq), (dk, gk), (dv, gv))]
+    print("flash attention backward B=%d H=%d n=%d: rel err dq %.2e dk %.2e dv %.2e, nlse %.2e" % (B, H, n, *errs, e_l))
+    assert max(errs) < 1.5e-2, errs
+
+
 @pytest.mark.parametrize("tag,kw", [("a", dict(image_size=16, image_patch_size=8, frames=16, frame_patch_size=8, channels=2)),
                                     ("b", dict(image_size=16, image_patch_size=4, frames=48, frame_patch_size=8, channels=1))])
 def test_vit3d_vs_reference_fixture(tag, kw):

@@ -29,3 +29,19 @@ e1.synchronize()
 ms = e0.elapsed_time(e1) / iters
 fl = 4.0 * B * H * n * n * dh
 print(f"attention B={B} H={H} n={n}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TFLOP/s  ({fl / ms / 1e9 / 2500:.3f} of 2.5 PFLOP/s)")
+
+# backward (gfe_attention_bwd: prep + dK/dV + dQ launches): 2.5x the forward's algorithmic flops (S, dP, dV, dK, dQ)
+o, nlse = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True)
+dout = torch.randn(B * n, inner, generator=g).to(torch.bfloat16).cuda()
+dqkv = torch.empty_like(qkv)
+for _ in range(3):
+    K.attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, dh ** -0.5, dqkv=dqkv)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(iters):
+    K.attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, dh ** -0.5, dqkv=dqkv)
+e1.record()
+e1.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print(f"attention backward B={B} H={H} n={n}: {ms * 1e3:.1f} us  {2.5 * fl / ms / 1e9:.1f} TFLOP/s  ({2.5 * fl / ms / 1e9 / 2500:.3f} of 2.5 PFLOP/s, "
+      f"algorithmic 10 n^2 d flops per head)")
