@@ -150,6 +150,56 @@ class Linear(nn.Linear):
         return linear(x, self.weight, self.bias)
 
 
+class _QkvFlashAttnFn(torch.autograd.Function):
+    """to_qkv (Linear, no bias) followed by softmax(q k^T * scale) v per head -- vit_pytorch_diy/vit_3d.py:49-59 -- as ONE autograd node for
+    head dim 64 and any token count: 2 launches forward (bf16 MFMA GEMM writing the (B*T, 3*inner) bf16 projection, flash attention with the
+    row statistic), 5 backward (gfe_attention_bwd's three + dgrad + wgrad reading the bf16 dq|dk|dv buffer in place).  The T x T score
+    matrix never exists in memory either way (the reference materialises it twice: `dots`, `attn`)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, heads, scale):
+        inner3, dim = weight.shape
+        inner = inner3 // 3
+        dh = inner // heads
+        B, T = h.shape[0], h.shape[1]
+        h2 = h.detach().reshape(B * T, dim)
+        if h2.dtype not in (BF16, torch.float32):
+            h2 = h2.float()
+        w16 = _w16(weight)
+        assert dh == 64 and dim % 8 == 0 and K._ex_ok(h2) and K._ex_ok(w16), "qkv_flash_attention: head dim 64, 16-byte aligned rows"
+        qkv = K.gemm_ex(h2, False, w16, False, out_dtype=BF16)
+        o, nlse = K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, heads, T, dh, scale, with_lse=True)
+        ctx.save_for_backward(h2, qkv, o, nlse, weight)
+        ctx.meta = (B, T, heads, dh, float(scale), h.dtype, h.shape)
+        return o.view(B, T, inner)
+
+    @staticmethod
+    def backward(ctx, do):
+        h2, qkv, o, nlse, weight = ctx.saved_tensors
+        B, T, heads, dh, scale, hdt, hs = ctx.meta
+        inner = heads * dh
+        d16 = do.reshape(B * T, inner)
+        d16 = d16.contiguous() if d16.dtype == BF16 else K.cast(d16.float(), BF16)
+        dqkv = torch.empty_like(qkv)
+        K.attention_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, d16, nlse, B, heads, T, dh, scale, dqkv=dqkv)
+        dh_ = dw = None
+        if ctx.needs_input_grad[0]:
+            dh_ = K.gemm_ex(dqkv, False, _w16(weight), True).reshape(hs).to(hdt)          # dqkv (M, 3 inner) . W (3 inner, dim) read reduction-major
+        if ctx.needs_input_grad[1]:
+            slot = _grad_slot(weight)
+            dw = K.gemm_ex(dqkv, True, h2, True, accum_into=slot)                          # dqkv^T . h, both read reduction-major
+            dw = None if slot is not None else dw.to(weight.dtype)
+        return dh_, dw, None, None
+
+
+def qkv_flash_attention(h, to_qkv_weight, heads, scale):
+    """h: (B, T, dim) f32|bf16 (the normed tokens) -> (B, T, heads*64) bf16 = rearrange(softmax(q k^T * scale) v) with q, k, v = chunks of
+    h @ to_qkv_weight^T (vit_3d.py:49-59, dropout p = 0), differentiable in h and the weight."""
+    if not h.is_cuda:
+        raise RuntimeError("gfe_hip qkv_flash_attention needs CUDA/HIP tensors (no CPU fallback)")
+    return _QkvFlashAttnFn.apply(h, to_qkv_weight, heads, scale)
+
+
 class _MidLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mid_in, mid_out, weight, bias):

@@ -4,7 +4,9 @@ Same constructor kwargs and state-dict keys (to_patch_embedding.{1,2,3}, pos_emb
 transformer.layers.{l}.{0,1}..., mlp_head.{0,1}).  The reference never instantiates this module on its hot path; SURVEY 8-d
 uses it as the MFMA-attention measurement row (image 96, patch 8, frames 96 -> 1729 tokens).  torch layers only hold
 parameters; forward() runs the HIP kernels: LayerNorm, bf16 MFMA GEMM (bias / GELU / residual epilogues) and the flash-style
-attention kernel gfe_attention_fwd.  Inference semantics (dropouts are identities).
+attention kernel gfe_attention_fwd.  Under no_grad: the inference pipeline (bf16 activations, fused epilogues).  With autograd enabled
+and trainable parameters: forward_train -- the same module through differentiable kernels (flash-attention forward with the row
+statistic + gfe_attention_bwd, LayerNorm and Linear nodes of the classifier head), which is how the reference trains it.
 """
 import torch
 from torch import nn
@@ -85,11 +87,47 @@ class ViT(nn.Module):
         emb = K.gemm_nt(tok, w["w_embed"], bias=w["b_embed"], out_dtype=torch.float32)
         return K.layernorm(emb, *w["ln_e"], rows=B * n, length=dim, out_dtype=torch.float32).view(B, n, dim)
 
+    def forward_train(self, video):
+        """vit_3d.py:113-128 with autograd (module.training decides the dropouts): every op is a HIP-kernel autograd node; attention is
+        train_ops.qkv_flash_attention for dim_head 64 (any token count), the 64-token kernel of the classifier head otherwise."""
+        import torch.nn.functional as F
+        from gfe_hip.head_ops import layernorm_rows, sdpa_small
+        from gfe_hip.train_ops import linear, qkv_flash_attention
+        n, dim = self.num_patches, self.dim
+        B, T = video.shape[0], n + 1
+        drop = lambda x, m: F.dropout(x, m.p, True) if (m.training and m.p > 0) else x
+        tpe = self.to_patch_embedding
+        t = self.patchify(video.float()).contiguous()
+        t = layernorm_rows(t, tpe[1].weight, tpe[1].bias, tpe[1].eps)
+        t = linear(t, tpe[2].weight, tpe[2].bias)
+        t = layernorm_rows(t, tpe[3].weight, tpe[3].bias, tpe[3].eps).view(B, n, dim)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), t), dim=1) + self.pos_embedding[:, :T]       # vit_3d.py:117-119
+        x = drop(x, self.dropout)
+        for attn, ff in self.transformer.layers:                                                      # vit_3d.py:70-73
+            h = layernorm_rows(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
+            p_attn = attn.dropout.p if (attn.training and attn.dropout.training) else 0.0
+            if attn.dim_head == 64 and p_attn == 0.0:
+                o = qkv_flash_attention(h, attn.to_qkv.weight, attn.heads, attn.scale)
+            else:
+                if T > 64 or attn.dim_head > 64:
+                    raise NotImplementedError("vit_3d training: attention dropout > 0 or dim_head != 64 is built for <= 64 tokens only")
+                q, k, v = linear(h, attn.to_qkv.weight, None).chunk(3, dim=-1)
+                o = sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), attn.heads, causal=False, dropout_p=p_attn)
+            x = drop(linear(o, attn.to_out[0].weight, attn.to_out[0].bias), attn.to_out[1]) + x
+            h = layernorm_rows(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
+            h = drop(F.gelu(linear(h, ff.net[1].weight, ff.net[1].bias)), ff.net[3])
+            x = drop(linear(h, ff.net[4].weight, ff.net[4].bias), ff.net[5]) + x
+        pooled = x.mean(dim=1) if self.pool == 'mean' else x[:, 0]                                    # vit_3d.py:125
+        hn = layernorm_rows(pooled.contiguous(), self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[0].eps)
+        return linear(hn, self.mlp_head[1].weight, self.mlp_head[1].bias)
+
     def forward(self, video):
-        """video: (B, C, F, H, W) float on the GPU -> (B, num_classes) f32.  vit_3d.py:113-128, eval mode."""
+        """video: (B, C, F, H, W) float on the GPU -> (B, num_classes) f32.  vit_3d.py:113-128."""
         assert video.is_cuda, "no CPU fallback"
         F_, H, W = self.geom[:3]
         assert tuple(video.shape[1:]) == (self.channels, F_, H, W)
+        if torch.is_grad_enabled() and (video.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_train(video)
         w, n, dim = self._weights(), self.num_patches, self.dim
         B, T = video.shape[0], n + 1
         emb = self.tokens(video).view(B * n, dim)

@@ -111,6 +111,29 @@ def test_vit3d():
         assert rel_err(out_mean, tt(fx["out_mean"])) < TOL
 
 
+def test_oracle_vit3d_backward_vs_reference_autograd():
+    """Fixture t10 = the REFERENCE's own autograd through vit_3d.ViT (cross-entropy of the logits): autograd through the oracle's vit3d
+    restatement gives the same loss, input gradient and parameter gradients -- the backward the flash-attention backward is compared with
+    (tests/test_unet_gpu.py)."""
+    import torch.nn.functional as F
+    sl = lambda t, n: t.detach().reshape(-1)[::max(1, t.numel() // n)][:n].double()
+    for tag, pf, p in (("b", 8, 4), ("c", 8, 4)):
+        fx = golden(f"t10_vit3d_grads_{tag}.npz")
+        tr = {k: v.clone().requires_grad_(True) for k, v in sub_sd(fx, "sd.").items()}
+        x = tt(fx["x"]).requires_grad_()
+        out, _ = O.vit3d(x, tr, "", frame_patch=pf, patch=p, heads=2, depth=2)
+        loss = F.cross_entropy(out, torch.from_numpy(fx["labels"]))
+        loss.backward()
+        assert rel_err(out, tt(fx["out"])) < TOL and abs(loss.item() - float(fx["loss"])) < 1e-5
+        assert rel_err(sl(x.grad, 256), tt(fx["dx_slice"])) < 1e-3
+        for k in [k[len("gnorm."):] for k in fx if k.startswith("gnorm.")]:
+            g = tr[k].grad
+            e_n = abs(g.double().norm().item() - float(fx["gnorm." + k])) / max(float(fx["gnorm." + k]), 1e-12)
+            assert e_n < 1e-4 and rel_err(sl(g, 128), tt(fx["gslice." + k])) < 1e-3, (tag, k, e_n)
+        for k in [k[len("gfull."):] for k in fx if k.startswith("gfull.")]:
+            assert rel_err(tr[k].grad, tt(fx["gfull." + k])) < 1e-4, (tag, k)
+
+
 def test_index_maps_bit_exact():
     fx = golden("t0_index_maps.npz")
     for name, shp in (("native", (40, 40, 24)), ("g96", (24, 24, 24)), ("g128", (32, 32, 32)), ("g32", (8, 8, 8))):

@@ -321,6 +321,46 @@ def test_vit3d_vs_reference_fixture(tag, kw):
         assert e_cls < 2.5e-2 and e_mean < 2.5e-2
 
 
+@pytest.mark.parametrize("tag,kw", [("b", dict(image_size=16, image_patch_size=4, frames=48, frame_patch_size=8, channels=1)),
+                                    ("c", dict(image_size=32, image_patch_size=4, frames=40, frame_patch_size=8, channels=1))])
+def test_vit3d_training_vs_reference_autograd_fixture(tag, kw):
+    """vit_3d.ViT twin under autograd (forward_train: flash attention forward + gfe_attention_bwd inside one node per layer) against the
+    REFERENCE's own autograd (fixture t10: logits, cross-entropy loss, input gradient, every parameter gradient): 97 tokens (two key
+    tiles, ragged) and 321 tokens (two query blocks, six key tiles, ragged).  bf16 matrix-core operands: gradients to 3e-2 (norms 2e-2)."""
+    import torch.nn.functional as F
+    from vit_pytorch_diy.vit_3d import ViT
+    fx = golden(f"t10_vit3d_grads_{tag}.npz")
+    m = ViT(num_classes=3, dim=128, depth=2, heads=2, dim_head=64, mlp_dim=256, pool="cls", **kw)
+    m.load_state_dict(sub_sd(fx, "sd."))
+    m = m.to(DEV).train()
+    x = tt(fx["x"]).to(DEV).requires_grad_()
+    out = m(x)
+    loss = F.cross_entropy(out, torch.from_numpy(fx["labels"]).to(DEV))
+    loss.backward()
+    sl = lambda t, n: t.detach().reshape(-1)[::max(1, t.numel() // n)][:n].double()
+    e_out, e_loss = rel_err(out, tt(fx["out"])), abs(loss.item() - float(fx["loss"]))
+    e_dx = rel_err(sl(x.grad, 256), tt(fx["dx_slice"]))
+    worst = ("", 0.0, 0.0)
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None, k
+        gn = float(fx["gnorm." + k])
+        e_n = abs(prm.grad.double().norm().item() - gn) / max(gn, 1e-12)
+        e_s = rel_err(sl(prm.grad, 128), tt(fx["gslice." + k]))
+        if max(e_n, e_s) > max(worst[1:]):
+            worst = (k, e_n, e_s)
+        assert e_n < 2e-2 and e_s < 3e-2, (k, e_n, e_s)
+    e_full = {k[len("gfull."):]: rel_err(dict(m.named_parameters())[k[len("gfull."):]].grad, tt(fx[k])) for k in fx if k.startswith("gfull.")}
+    print("vit_3d twin training %s vs reference autograd: logits %.2e, loss diff %.2e, dx %.2e, worst parameter gradient %s (norm %.2e, slice %.2e), "
+          "full to_qkv / to_out gradients %s" % (tag, e_out, e_loss, e_dx, *worst, {k.split(".")[-2]: "%.2e" % v for k, v in e_full.items()}))
+    assert e_out < 2.5e-2 and e_loss < 2e-2 and e_dx < 3e-2
+    assert max(e_full.values()) < 3e-2, e_full
+    # a second backward from the same graph inputs is bit-identical (no atomics anywhere in the attention backward)
+    g1 = m.transformer.layers[0][0].to_qkv.weight.grad.clone()
+    m.zero_grad(set_to_none=True)
+    F.cross_entropy(m(x), torch.from_numpy(fx["labels"]).to(DEV)).backward()
+    assert torch.equal(g1, m.transformer.layers[0][0].to_qkv.weight.grad)
+
+
 def test_generator_real_width_64_cubed_vs_oracle():
     """Full-width generator (f_maps 64/128/256, ViT 512x4x6) on a 64^3 volume -- every channel count of the real model, 2 tiles
     per axis incl. boundary classes -- against the oracle on the same deterministic weights."""

@@ -5,7 +5,7 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t8|t9] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t8|t9|t10] [--out tests/golden]
 """
 import argparse
 import importlib.util
@@ -369,6 +369,32 @@ def t9(R, out):
     np.savez_compressed(os.path.join(out, "t9_generator_grads.npz"), **fx)
 
 
+def t10(R, out):
+    """The reference's vit_3d.ViT under ITS autograd (vit_3d.py:47-57 trains through `dots` / `attn` / matmul): cross-entropy of the logits
+    against fixed labels, backward; logits, loss, the input gradient and every parameter gradient (norm + strided slice; the to_qkv / to_out
+    gradients of layer 0 in full).  Two geometries with dim_head 64: 97 tokens (two key tiles, ragged) and 321 tokens (two 256-row query
+    blocks, six key tiles, ragged) -- the flash-attention backward's tile edges."""
+    import torch.nn.functional as F
+    for tag, kw, shape in (("b", dict(image_size=16, image_patch_size=4, frames=48, frame_patch_size=8, channels=1), (2, 1, 48, 16, 16)),
+                           ("c", dict(image_size=32, image_patch_size=4, frames=40, frame_patch_size=8, channels=1), (2, 1, 40, 32, 32))):
+        v3 = R.vit3d.ViT(num_classes=3, dim=128, depth=2, heads=2, dim_head=64, mlp_dim=256, pool="cls", **kw)
+        sd = load_det(v3, seed=10, prefix="t10vit3d" + tag + ".")
+        v3.train()                                       # dropout p = 0: train and eval coincide
+        xi = rnd_det("t10.x" + tag, shape).requires_grad_()
+        labels = torch.tensor([2, 0])
+        out_ = v3(xi)
+        loss = F.cross_entropy(out_, labels)
+        loss.backward()
+        fx = {"sd." + k: npy(v) for k, v in sd.items()}
+        fx.update(x=npy(xi), labels=labels.numpy(), out=npy(out_), loss=npy(loss.double()), dx_slice=slices(xi.grad), dx_norm=npy(xi.grad.double().norm()))
+        for k, prm in v3.named_parameters():
+            fx["gnorm." + k] = npy(prm.grad.double().norm())
+            fx["gslice." + k] = slices(prm.grad, 128)
+        for k in ("transformer.layers.0.0.to_qkv.weight", "transformer.layers.0.0.to_out.0.weight"):
+            fx["gfull." + k] = npy(dict(v3.named_parameters())[k].grad)
+        np.savez_compressed(os.path.join(out, "t10_vit3d_grads_" + tag + ".npz"), **fx)
+
+
 def t3(R, out):
     """Cross_mamba_ablation (cross_atten/mamba_transformer.py:254-385): the four forward variants + parameter gradients of each."""
     cards, n_cont, dim, depth, heads, vol, Bn = (5, 3, 2), 6, 64, 2, 8, (8, 12, 6), 3
@@ -505,7 +531,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t8", t8), ("t9", t9)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t8", t8), ("t9", t9), ("t10", t10)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
