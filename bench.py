@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- measures BASELINE.json's metric on MI355X and prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan|vit3d|normalise|gen128|gentrain]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload step|scan|pscan|vit3d|vit3dtrain|normalise|gen128|gentrain]
 
 workload `step` (default): one classify_mamba training step (frozen generator fwd + head fwd/bwd + per-parameter
 clip + Adam) on a synthetic batch of 8 volumes of 96^3 per GPU (BASELINE config 5's per-GPU share == config 3 + bwd).
@@ -296,6 +296,60 @@ class Vit3dWorkload:
                 "sample": "oracle.ref_ops.vit3d, 1 volume of 96^3, fp32, torch CPU"}
 
 
+class Vit3dTrainWorkload(Vit3dWorkload):
+    """The same module under autograd, as the reference would train it (vit_3d.py:47-57 through autograd): forward_train, mean of the
+    logits as a stand-in loss, backward, FlatAdam update.  Roofline object: the attention BACKWARD (gfe_attention_bwd = prep + dK/dV + dQ
+    launches) of one layer against the bf16 MFMA peak, algorithmic flops = 5 matrix products = 10 B h n^2 d."""
+    name = "vit_3d.ViT training step (forward + backward + Adam), 96^3 / 8^3 patches = 1729 tokens, dim 512 depth 4 heads 8x64 (synthetic)"
+
+    def __init__(self, batch):
+        super().__init__(batch)
+        from gfe_hip.train_ops import FlatAdam
+        self.m.train()
+        self.opt = FlatAdam(list(self.m.parameters()), lr=1e-4, max_norm=float("inf"))
+        self.loss = None
+
+    def step(self):
+        self.opt.zero_grad()
+        loss = self.m(self.x).mean()
+        loss.backward()
+        self.opt.step()
+        self.loss = loss.detach()
+
+    def roofline(self, iters=50):
+        from gfe_hip import nn_ops as K
+        B, n, H, dh = self.B, self.n, self.H, self.dh
+        g = torch.Generator().manual_seed(1)
+        inner = H * dh
+        qkv = torch.randn(B * n, 3 * inner, generator=g).to(torch.bfloat16).cuda()
+        dout = torch.randn(B * n, inner, generator=g).to(torch.bfloat16).cuda()
+        q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+        o, nlse = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True)
+        dqkv = torch.empty_like(qkv)
+        f = lambda: K.attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, dh ** -0.5, dqkv=dqkv)
+        f()
+        ms = time_region(f, iters)
+        flops = 10.0 * B * H * n * n * dh
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "gfe_attention_bwd: attn_bwd_prep + attn_bwd_dkdv + attn_bwd_dq kernels (one layer, B x 8 heads x 1729 x 64; "
+                          "S and dP are recomputed in both main kernels: 28 MFMAs executed per 20 algorithmic)",
+                "launches_timed": iters, "launch_ms": round(ms, 4), "algorithmic_flops": flops}
+
+    def cpu_baseline(self):
+        """autograd through oracle.ref_ops.vit3d (torch CPU restatement of vit_3d.py:113-128) on ONE volume: forward + backward."""
+        from oracle import ref_ops as O
+        sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in self.m.state_dict().items()}
+        x = self.x[:1].cpu()
+        t0 = time.perf_counter()
+        out, _ = O.vit3d(x, sd, "", frame_patch=8, patch=8, heads=8, depth=4)
+        out.mean().backward()
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 3), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "autograd through oracle.ref_ops.vit3d, 1 volume of 96^3, fp32, torch CPU (forward + backward, no optimizer)"}
+
+
 class NormWorkload:
     """adaptive_normal (utils/data_normalization.py:20-48) over a batch of native-size 160x160x96 f32 volumes with an
     MRI-like histogram (35 % exact-zero background, skewed positive tissue intensities, some negatives)."""
@@ -447,7 +501,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "pscan", "vit3d", "normalise", "gen128", "gentrain"])
+    ap.add_argument("--workload", default=os.environ.get("GFE_BENCH_WORKLOAD", "step"), choices=["step", "scan", "pscan", "vit3d", "vit3dtrain", "normalise", "gen128", "gentrain"])
     ap.add_argument("--volume", default="96", choices=["96", "native"], help="step workload: 96 = 96^3 (BASELINE's metric); native = the reference's own 160x160x96 (config/classify_mamba_config.yaml:5-7; --batch 2 = its train_bc)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (volumes for `step`, sequences for `scan`; default 8, gen128: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -505,6 +559,11 @@ def main():
         wl = Vit3dWorkload(a.batch)
         steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 5
         metric, unit, dtype = "3-D ViT volumes/sec (96^3, 1729 tokens, bf16) forward [synthetic MFMA-attention row]", "volumes/s", "bf16"
+        cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
+    elif a.workload == "vit3dtrain":
+        wl = Vit3dTrainWorkload(a.batch)
+        steps, warmup = a.steps or 10, a.warmup if a.warmup is not None else 3
+        metric, unit, dtype = "3-D ViT volumes/sec (96^3, 1729 tokens, bf16) training step fwd+bwd+Adam [synthetic MFMA-attention row]", "volumes/s", "bf16"
         cfg = {"workload": wl.name, "batch_per_gpu": a.batch, "parallelism": f"replicas x{n_gpus}"}
     elif a.workload == "normalise":
         wl = NormWorkload(a.batch)

@@ -30,7 +30,8 @@ constexpr int AD = 64;            // head dim
 constexpr int BW = 8;             // waves per block (256 keys / 256 query rows)
 constexpr int RT = 64;            // rows per streamed tile
 constexpr int TILE_BYTES = RT * AD * 2;
-constexpr int RING = 3;
+constexpr int RING = 3;          // dq kernel
+constexpr int RING_KV = 4;       // dkdv kernel: tile t read, t+1 published, t+2 and t+3 in flight
 constexpr int STAT_BYTES = RT * 4;                                   // one row statistic per tile row
 constexpr int STAGE_KV = 2 * TILE_BYTES + 2 * STAT_BYTES;            // dkdv ring stage: Qs tile, dO tile, nlse, ndelta
 constexpr int STAGE_Q = 2 * TILE_BYTES;                              // dq ring stage: K tile, V tile
@@ -174,11 +175,18 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const BwdParams p, c
 }
 
 // ---- dK, dV: a wave owns 32 keys
+// Software pipeline over the 32-row blocks of the streamed tiles (two waves per SIMD cannot hide an LDS round trip in front of every MFMA):
+// block i+1's row fragments and row statistics are read into a second register set while block i is multiplied, across tile boundaries too --
+// the workgroup barrier that publishes tile t+1 (and retires tile t-1's last readers) sits in FRONT of tile t's last block, and the DMA that
+// refills tile t-1's ring slot with tile t+RING-1 is issued right behind it.
 __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING stages of STAGE_KV bytes
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING_KV stages of STAGE_KV bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
+#if defined(GFE_ATTNB_PRIO)
+    if (wave >= BW / 2) __builtin_amdgcn_s_setprio(GFE_ATTNB_PRIO);
+#endif
     const int item = xcd_item(blockIdx.x, p.total);
     const int bh = item / p.nblk, kblk = item - bh * p.nblk;
     const int b = bh / p.H, h = bh - b * p.H;
@@ -219,49 +227,98 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
         else dma4(rs_l, dst, (unsigned)(t * RT + lane) * 4);
     };
 
-    dma(0, 0);
-    if (ntile > 1) dma(1, 1);
-    if (ntile > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-
     const FragOffsets fo = frag_offsets(lane);
     const int stat_off = 16 * hi;                          // rows crow(4*r4 .. 4*r4+3, hi) = 8*r4 + 4*hi + 0..3: one 16-B read per r4
+    struct RowSet { bf16x8 q[4], d[4]; };                  // a block's A fragments (Qs rows, dO rows)
+    RowSet rs[2];
+    f32x16 s, dp;                                          // the chain starts nlse / -delta of the block's 32 rows, then S / dP, then P / dS
+    auto load_frags = [&](RowSet& f, const uint8_t* stage, int blk) {
+        load_rows(f.q, stage, blk, fo);
+        load_rows(f.d, stage + TILE_BYTES, blk, fo);
+    };
+    auto load_stats = [&](const uint8_t* stage, int blk) {
+        const uint8_t* sl = stage + 2 * TILE_BYTES + 32 * blk * 4 + stat_off;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 a = *reinterpret_cast<const float4*>(sl + 32 * r4);
+            const float4 d = *reinterpret_cast<const float4*>(sl + STAT_BYTES + 32 * r4);
+            s[4 * r4] = a.x; s[4 * r4 + 1] = a.y; s[4 * r4 + 2] = a.z; s[4 * r4 + 3] = a.w;
+            dp[4 * r4] = d.x; dp[4 * r4 + 1] = d.y; dp[4 * r4 + 2] = d.z; dp[4 * r4 + 3] = d.w;
+        }
+    };
 
+#pragma unroll
+    for (int t = 0; t < RING_KV - 1; ++t)
+        if (t < ntile) dma(t, t);
+    // vmcnt retires in order: tile 0 has landed once at most the younger tiles' pieces are outstanding
+    if (ntile >= RING_KV - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((RING_KV - 2) * PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    load_frags(rs[0], smem, 0);
+    load_stats(smem, 0);
+
+    constexpr int NB = RT / 32;                            // blocks per tile (even: the register set of a block is a compile-time choice)
+    static_assert(NB % 2 == 0, "ping-pong register sets");
     auto tile = [&](auto slot_c, const int t) {
         constexpr int SLOT = decltype(slot_c)::value;
-        const uint8_t* sq = smem + SLOT * STAGE_KV;
-        const uint8_t* sdo = sq + TILE_BYTES;
-        const uint8_t* sl = sq + 2 * TILE_BYTES;
-        const uint8_t* sd = sl + STAT_BYTES;
+        const uint8_t* st = smem + SLOT * STAGE_KV;
+        const uint8_t* nx = smem + ((SLOT + 1) % RING_KV) * STAGE_KV;
+        const bool more = t + 1 < ntile;
 #pragma unroll
-        for (int qb2 = 0; qb2 < RT / 32; ++qb2) {
-            if (qb2 == 0 && t + RING - 1 < ntile) dma(t + RING - 1, (SLOT + RING - 1) % RING);
-            // ---- S[q][key] + nlse[q]  and  dP[q][key] - delta[q]: the chains start from the row statistics
-            f32x16 s, dp;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 a = *reinterpret_cast<const float4*>(sl + (32 * qb2 + 8 * r4) * 4 + stat_off);
-                const float4 d = *reinterpret_cast<const float4*>(sd + (32 * qb2 + 8 * r4) * 4 + stat_off);
-                s[4 * r4] = a.x; s[4 * r4 + 1] = a.y; s[4 * r4 + 2] = a.z; s[4 * r4 + 3] = a.w;
-                dp[4 * r4] = d.x; dp[4 * r4 + 1] = d.y; dp[4 * r4 + 2] = d.z; dp[4 * r4 + 3] = d.w;
+        for (int j = 0; j < NB; ++j) {
+            RowSet& cur = rs[j & 1];
+            RowSet& nxt = rs[(j + 1) & 1];
+            if (j == NB - 1 && more) {
+                // tile t+1 published, tile t-1 retired: (RING_KV - 3) younger tiles may stay in flight
+                if (t + RING_KV - 2 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((RING_KV - 3) * PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if !defined(GFE_ATTNB_EXP_NODMA)       // timing experiment only
+                if (t + RING_KV - 1 < ntile) dma(t + RING_KV - 1, (SLOT + RING_KV - 1) % RING_KV);
+#endif
             }
-            bf16x8 qr[4], dor[4];
-            load_rows(qr, sq, qb2, fo);
-            load_rows(dor, sdo, qb2, fo);
+            // next block's row fragments: in flight under this block's MFMA chains
+#if !defined(GFE_ATTNB_EXP_NOLDS)       // timing experiment only
+            if (j < NB - 1) load_frags(nxt, st, j + 1);
+            else if (more) load_frags(nxt, nx, 0);
+#else
 #pragma unroll
-            for (int ds = 0; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ds], kf[ds], s, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(nxt.q[i]), "+v"(nxt.d[i])); }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S[q][key] + nlse[q]  and  dP[q][key] - delta[q]: the chains start from the row statistics
 #pragma unroll
-            for (int ds = 0; ds < 4; ++ds) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor[ds], vf[ds], dp, 0, 0, 0);
+            for (int ds = 0; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.q[ds], kf[ds], s, 0, 0, 0);
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.d[ds], vf[ds], dp, 0, 0, 0);
+            // the transposed fragments of THIS block (into the registers its row fragments leave)
+            bf16x8 dot[2][2], qt[2][2];
+#if !defined(GFE_ATTNB_EXP_NOLDS)
+            load_tr(dot, st + TILE_BYTES, j, fo);
+            load_tr(qt, st, j, fo);
+#else
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { dot[i][0] = cur.q[i]; dot[i][1] = cur.d[i]; qt[i][0] = cur.q[i + 2]; qt[i][1] = cur.d[i + 2]; }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
             // ---- P, dS (query rows >= n: nlse = -inf -> p = 0, dO = 0 and ndelta = 0 -> dS = 0)
+            bf16x8 pb[2], dsb[2];
+#if defined(GFE_ATTNB_EXP_NOVALU)       // timing experiment only: no exp / product / pack (wrong results)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                pb[tt] = __builtin_bit_cast(bf16x8, make_float4(s[8 * tt], s[8 * tt + 1], s[8 * tt + 2], s[8 * tt + 3]));
+                dsb[tt] = __builtin_bit_cast(bf16x8, make_float4(dp[8 * tt], dp[8 * tt + 1], dp[8 * tt + 2], dp[8 * tt + 3]));
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r]); dp[r] *= s[r]; }
-            bf16x8 pb[2], dsb[2];
             pack_b(pb, s);
             pack_b(dsb, dp);
-            // ---- dV^T += dO^T P, dK^T += Qs^T dS: A fragments by transposing reads of the [q][d] tiles
-            bf16x8 dot[2][2], qt[2][2];
-            load_tr(dot, sdo, qb2, fo);
-            load_tr(qt, sq, qb2, fo);
+#endif
+            // the next block's chain starts, into the registers P / dS leave: in flight under the eight MFMAs below
+#if !defined(GFE_ATTNB_EXP_NOLDS)
+            if (j < NB - 1) load_stats(st, j + 1);
+            else if (more) load_stats(nx, 0);
+#endif
+            // ---- dV^T += dO^T P, dK^T += Qs^T dS
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -271,13 +328,13 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
 #pragma unroll
                 for (int db = 0; db < 2; ++db) dka[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[tt][db], dsb[tt], dka[db], 0, 0, 0);
         }
-        if (t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    for (int t = 0; t < ntile; t += 3) {
+    static_assert(RING_KV == 4, "the tile loop is unrolled by the ring depth");
+    for (int t = 0; t < ntile; t += 4) {
         tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < ntile) tile(std::integral_constant<int, 1>{}, t + 1);
         if (t + 2 < ntile) tile(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < ntile) tile(std::integral_constant<int, 3>{}, t + 3);
     }
 
     if (key < p.n) {
@@ -294,6 +351,9 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING stages of STAGE_Q bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
+#if defined(GFE_ATTNB_PRIO)
+    if (wave >= BW / 2) __builtin_amdgcn_s_setprio(GFE_ATTNB_PRIO);
+#endif
     const int item = xcd_item(blockIdx.x, p.total);
     const int bh = item / p.nblk, qblk = item - bh * p.nblk;
     const int b = bh / p.H, h = bh - b * p.H;
@@ -408,7 +468,7 @@ int gfe_attention_bwd(const void* q, const void* k, const void* v, const void* o
     p.total = (int)total;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)ceil_div(rows, 32)), dim3(256), 0, st, p, rows);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)total), dim3(BW * 64), RING * STAGE_KV, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)total), dim3(BW * 64), RING_KV * STAGE_KV, st, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)total), dim3(BW * 64), RING * STAGE_Q, st, p);
     return gfe_launch_status();
 }

@@ -318,6 +318,100 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
     }
 }
 
+// ---- LayerNorm backward over MANY rows (the 3-D ViT's 13,832 token rows of 512: one block per row with two atomics per element onto 2 * dim
+// addresses took 314 us per call).  A wave owns a row at a time (row sums by shuffles, no barrier), keeps its share of dgamma / dbeta in
+// registers over the block's rows, the block's four waves combine through LDS into ONE partial row per block, and a second launch adds the
+// partials to dgamma / dbeta in a fixed order: no atomics, run-to-run identical.  dim <= 2048 (8 float4 per lane).
+constexpr int LN_TALL_MIN_ROWS = 256, LN_TALL_MAX_DIM = 2048, LN_TALL_MAX_BLOCKS = 1024;
+template <int NI>
+__global__ __launch_bounds__(256) void ln_tall_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ part, int rows, int dim, int rows_per_block) {
+    __shared__ float4 red[2][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float4 gm[NI], dg[NI], db[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = 4 * lane + 256 * i;
+        gm[i] = c < dim ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
+    }
+    const float inv_dim = 1.0f / (float)dim;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float mu = mean[r], rs = rstd[r];
+        float4 xh[NI], g[NI];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = 4 * lane + 256 * i;
+            float4 xv = make_float4(mu, mu, mu, mu), dv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < dim) { xv = *reinterpret_cast<const float4*>(x + (size_t)r * dim + c); dv = *reinterpret_cast<const float4*>(dy + (size_t)r * dim + c); }
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            g[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+            dg[i].x = fmaf(dv.x, xh[i].x, dg[i].x); dg[i].y = fmaf(dv.y, xh[i].y, dg[i].y); dg[i].z = fmaf(dv.z, xh[i].z, dg[i].z); dg[i].w = fmaf(dv.w, xh[i].w, dg[i].w);
+            db[i].x += dv.x; db[i].y += dv.y; db[i].z += dv.z; db[i].w += dv.w;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 *= inv_dim; s2 *= inv_dim;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < dim)
+                *reinterpret_cast<float4*>(dx + (size_t)r * dim + c) = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                                                                                  rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+        }
+    }
+    // the block's partial row: waves 1..3 park their sums, wave 0 adds them in order and writes part[block][0 | 1][dim]
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (wave > 0) { red[0][wave - 1][lane] = dg[i]; red[1][wave - 1][lane] = db[i]; }
+        __syncthreads();
+        if (wave == 0) {
+            const int c = 4 * lane + 256 * i;
+            float4 a = dg[i], b = db[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 pa = red[0][w][lane], pb = red[1][w][lane];
+                a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w; b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+            }
+            if (c < dim) {
+                *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2) * dim + c) = a;
+                *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 1) * dim + c) = b;
+            }
+        }
+        __syncthreads();
+    }
+}
+// part: [nblk][2 * dim] (dgamma | dbeta partial rows).  A block owns a strip of 64 columns: 16 float4 column quads x 16 row groups; every row
+// group sums its rows in order, the 16 group sums are added in order through LDS -> one fixed summation tree.
+__global__ __launch_bounds__(256) void ln_tall_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, int dim, int nblk) {
+    __shared__ float4 red[16][16];
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * cq;                  // column of [0, 2 * dim)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < 2 * dim) {
+        const int per = (nblk + 15) / 16, b0 = rg * per, b1 = min(nblk, b0 + per);
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * 2 * dim + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && c < 2 * dim) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) { const float4 v = red[g][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float* out = c < dim ? dgamma + c : dbeta + (c - dim);      // dim % 4 == 0: a quad never straddles the two halves
+        out[0] += t.x; out[1] += t.y; out[2] += t.z; out[3] += t.w;
+    }
+}
+
 // ---- LayerNorm over LONG rows (the generator ViT's LayerNorm(patch_dim), patch_dim = 262,144 at 128^3, 64 rows): one block per row
 // leaves 192 CUs idle and walks 1 MB three times from one CU (1.8 ms backward).  A row is cut into `splits` segments, grid (splits, rows):
 //   moments: per-segment mean and centred second moment (two local passes, the segment stays in L2), combined with Chan's formula
@@ -545,6 +639,17 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
         const int seg = (int)ceil_div(dim, (int64_t)splits);
         hipLaunchKernelGGL(ln_long_bwd_sums_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, (int)dim, seg);
         hipLaunchKernelGGL(ln_long_bwd_apply_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, dx, dgamma, dbeta, (int)dim, seg);
+        return gfe_launch_status();
+    }
+    if (ws && rows >= LN_TALL_MIN_ROWS && dim <= LN_TALL_MAX_DIM && dim % 4 == 0 && rows <= 0x7fffffff) {
+        const int rpb = (int)ceil_div(rows, (int64_t)LN_TALL_MAX_BLOCKS) < 8 ? 8 : (int)ceil_div(rows, (int64_t)LN_TALL_MAX_BLOCKS);
+        const int nblk = (int)ceil_div(rows, (int64_t)rpb);
+        const int ni = (int)ceil_div(dim, 256);
+        hipStream_t st = (hipStream_t)stream;
+#define GFE_LN_TALL(NI) hipLaunchKernelGGL(ln_tall_bwd_kernel<NI>, dim3((unsigned)nblk), dim3(256), 0, st, x, gamma, mean, rstd, dy, dx, ws, (int)rows, (int)dim, rpb)
+        if (ni <= 1) GFE_LN_TALL(1); else if (ni <= 2) GFE_LN_TALL(2); else if (ni <= 4) GFE_LN_TALL(4); else GFE_LN_TALL(8);
+#undef GFE_LN_TALL
+        hipLaunchKernelGGL(ln_tall_bwd_reduce_kernel, dim3((unsigned)ceil_div(2 * dim, 64)), dim3(256), 0, st, ws, dgamma, dbeta, (int)dim, nblk);
         return gfe_launch_status();
     }
     hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, (int)dim);

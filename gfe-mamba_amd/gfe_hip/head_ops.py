@@ -176,6 +176,8 @@ class _LayerNormRows(torch.autograd.Function):
         dx = torch.empty_like(x2)
         (dg, own_g), (db, own_b) = _acc_target(gamma), _acc_target(beta)
         ws = torch.empty(rows * 128, dtype=torch.float32, device=x2.device) if dim >= 16384 else None
+        if rows >= 256 and dim <= 2048 and dim % 4 == 0:
+            ws = torch.empty(2 * dim * 1024, dtype=torch.float32, device=x2.device)             # many rows: per-block partial rows, no atomics
         call("gfe_layernorm_rows_bwd", ptr(x2), ptr(g_), ptr(st[0]), ptr(st[1]), ptr(d), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, dim, stream())
         return dx.view(ctx.xs), (None if own_g else dg), (None if own_b else db), None
 

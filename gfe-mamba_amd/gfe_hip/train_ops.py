@@ -62,10 +62,10 @@ class _LinearFn(torch.autograd.Function):
     loads cannot take (K % 8, N % 8: tiny test widths, the 1-wide logit layer) go through cast + transpose + zero padding."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, x16, xT16):
+    def forward(ctx, x, weight, bias, x16, xT16, exact=True):
         N, Kd = weight.shape
         xs = x.shape
-        if Kd <= F32_LINEAR_MAX_K and x16 is None and weight.dtype == torch.float32:
+        if exact and Kd <= F32_LINEAR_MAX_K and x16 is None and weight.dtype == torch.float32:
             # exact-f32 path (the reference's own precision for the head): 1 launch forward, 2-3 backward, no casts
             x32 = x.detach().reshape(-1, Kd)
             if x32.dtype != torch.float32 or x32.stride(-1) != 1:
@@ -134,13 +134,15 @@ class _LinearFn(torch.autograd.Function):
             call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), int(slot is not None), stream())
             if slot is not None:
                 db = None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, weight, bias=None, x16=None, xT16=None):
+def linear(x, weight, bias=None, x16=None, xT16=None, exact=True):
+    """exact=False: bf16 matrix-core operands (f32 accumulation) also below F32_LINEAR_MAX_K inputs, where the default keeps the
+    reference's own f32 precision (the classifier head's Linears)."""
     if not x.is_cuda:
         raise RuntimeError("gfe_hip linear needs CUDA/HIP tensors (no CPU fallback)")
-    return _LinearFn.apply(x, weight, bias, x16, xT16)
+    return _LinearFn.apply(x, weight, bias, x16, xT16, exact)
 
 
 class Linear(nn.Linear):

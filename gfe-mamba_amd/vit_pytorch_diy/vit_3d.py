@@ -92,7 +92,8 @@ class ViT(nn.Module):
         train_ops.qkv_flash_attention for dim_head 64 (any token count), the 64-token kernel of the classifier head otherwise."""
         import torch.nn.functional as F
         from gfe_hip.head_ops import layernorm_rows, sdpa_small
-        from gfe_hip.train_ops import linear, qkv_flash_attention
+        from gfe_hip.train_ops import linear as linear_, qkv_flash_attention
+        linear = lambda a, w, b: linear_(a, w, b, exact=False)         # bf16 MFMA operands, like the inference pipeline and the attention
         n, dim = self.num_patches, self.dim
         B, T = video.shape[0], n + 1
         drop = lambda x, m: F.dropout(x, m.p, True) if (m.training and m.p > 0) else x
@@ -119,7 +120,7 @@ class ViT(nn.Module):
             x = drop(linear(h, ff.net[4].weight, ff.net[4].bias), ff.net[5]) + x
         pooled = x.mean(dim=1) if self.pool == 'mean' else x[:, 0]                                    # vit_3d.py:125
         hn = layernorm_rows(pooled.contiguous(), self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[0].eps)
-        return linear(hn, self.mlp_head[1].weight, self.mlp_head[1].bias)
+        return linear_(hn, self.mlp_head[1].weight, self.mlp_head[1].bias)                           # (B x dim: exact f32)
 
     def forward(self, video):
         """video: (B, C, F, H, W) float on the GPU -> (B, num_classes) f32.  vit_3d.py:113-128."""

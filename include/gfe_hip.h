@@ -383,7 +383,9 @@ int gfe_sdpa_small_bwd(const float* q, const float* k, const float* v, const flo
 
 /* nn.LayerNorm(dim) over (rows, dim) f32 (mamba_transformer.py:79-82, corss_ft_transformer.py:16); mean / rstd (rows) kept for the
  * backward, which ACCUMULATES dgamma / dbeta (f32 atomics) and writes dx.  ws: NULL, or rows * 128 floats of scratch -- with it, rows of
- * dim >= 16384 (the generator ViT's LayerNorm(patch_dim), vit.py:101-105) are cut into up to 64 segments that run on different CUs. */
+ * dim >= 16384 (the generator ViT's LayerNorm(patch_dim), vit.py:101-105) are cut into up to 64 segments that run on different CUs.
+ * Backward with >= 256 rows of dim <= 2048 (dim % 4 == 0; the 3-D ViT's token rows) and ws of 2 * dim * 1024 floats: per-block partial
+ * rows + a fixed-order reduction instead of the atomics (deterministic). */
 int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, float* ws,
                            int64_t rows, int64_t dim, float eps, void* stream);
 int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,

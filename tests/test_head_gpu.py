@@ -570,6 +570,19 @@ def test_head_small_ops_vs_torch_and_reference_fixture():
     (y * w.to(DEV)).sum().backward(); (yr * w.double()).sum().backward()
     for a, b in ((gx, cx), (gg, cg), (gb, cb)):
         assert rel_err(a.grad, b.grad) < 1e-5
+    # --- the same with MANY rows (the 3-D ViT's token rows): per-block partial rows + fixed-order reduction instead of atomics, ragged
+    # widths (dim % 256 != 0, one to eight float4 per lane), row counts off the 8-row block grid, accumulation into existing gradients; bitwise repeatable
+    for rows, dim in ((300, 128), (1027, 512), (259, 516), (4100, 2048), (256, 4)):
+        x, ga, be, w = r(rows, dim) * 3 + 1, r(dim), r(dim), r(rows, dim)
+        gx, gg, gb = (t.to(DEV).requires_grad_(True) for t in (x, ga, be))
+        cx, cg, cb = dd(x), dd(ga), dd(be)
+        (Hd.layernorm_rows(gx, gg, gb) * w.to(DEV)).sum().backward(); (F.layer_norm(cx, (dim,), cg, cb) * w.double()).sum().backward()
+        for a, b in ((gx, cx), (gg, cg), (gb, cb)):
+            assert rel_err(a.grad, b.grad) < 1e-5, (rows, dim)
+        g1 = [t.grad.clone() for t in (gx, gg, gb)]
+        (Hd.layernorm_rows(gx, gg, gb) * w.to(DEV)).sum().backward()                  # accumulates: exactly twice, in the same order
+        for a, b in zip((gx, gg, gb), g1):
+            assert torch.equal(a.grad, 2 * b), (rows, dim)
     # --- GEGLU (no dropout: exact), then the dropout statistics and mask consistency between forward and backward
     x, w = r(6, 2048), r(6, 1024)
     gx, cx = x.to(DEV).requires_grad_(True), dd(x)

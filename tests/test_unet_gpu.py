@@ -345,15 +345,27 @@ def test_vit3d_training_vs_reference_autograd_fixture(tag, kw):
         assert prm.grad is not None, k
         gn = float(fx["gnorm." + k])
         e_n = abs(prm.grad.double().norm().item() - gn) / max(gn, 1e-12)
-        e_s = rel_err(sl(prm.grad, 128), tt(fx["gslice." + k]))
+        # the strided 128-element sample: against the gradient's own scale (a sample of small elements of a bf16-operand product has no
+        # relative accuracy of its own; the full-tensor comparison is the oracle one below)
+        ref_s = tt(fx["gslice." + k]).double()
+        e_s = ((sl(prm.grad, 128).cpu() - ref_s).abs().max() / (gn / prm.numel() ** 0.5)).item()
         if max(e_n, e_s) > max(worst[1:]):
             worst = (k, e_n, e_s)
-        assert e_n < 2e-2 and e_s < 3e-2, (k, e_n, e_s)
+        assert e_n < 2e-2 and e_s < 5e-2, (k, e_n, e_s)
     e_full = {k[len("gfull."):]: rel_err(dict(m.named_parameters())[k[len("gfull."):]].grad, tt(fx[k])) for k in fx if k.startswith("gfull.")}
-    print("vit_3d twin training %s vs reference autograd: logits %.2e, loss diff %.2e, dx %.2e, worst parameter gradient %s (norm %.2e, slice %.2e), "
+    print("vit_3d twin training %s vs reference autograd: logits %.2e, loss diff %.2e, dx %.2e, worst parameter gradient %s (norm %.2e, slice/scale %.2e), "
           "full to_qkv / to_out gradients %s" % (tag, e_out, e_loss, e_dx, *worst, {k.split(".")[-2]: "%.2e" % v for k, v in e_full.items()}))
     assert e_out < 2.5e-2 and e_loss < 2e-2 and e_dx < 3e-2
     assert max(e_full.values()) < 3e-2, e_full
+    # every parameter gradient IN FULL against autograd through the oracle's restatement (pinned to this fixture on the CPU:
+    # tests/test_oracle_golden.py::test_oracle_vit3d_backward_vs_reference_autograd)
+    from oracle import ref_ops as O
+    tr = {k: v.clone().requires_grad_(True) for k, v in sub_sd(fx, "sd.").items()}
+    out_o, _ = O.vit3d(tt(fx["x"]), tr, "", frame_patch=kw["frame_patch_size"], patch=kw["image_patch_size"], heads=2, depth=2)
+    F.cross_entropy(out_o, torch.from_numpy(fx["labels"])).backward()
+    e_all = {k: rel_err(prm.grad, tr[k].grad) for k, prm in m.named_parameters()}
+    print("    full gradients vs oracle autograd: worst %.2e (%s)" % (max(e_all.values()), max(e_all, key=e_all.get)))
+    assert max(e_all.values()) < 1e-2, e_all
     # a second backward from the same graph inputs is bit-identical (no atomics anywhere in the attention backward)
     g1 = m.transformer.layers[0][0].to_qkv.weight.grad.clone()
     m.zero_grad(set_to_none=True)
