@@ -323,6 +323,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #endif
 }
 
+
 }  // namespace
 
 extern "C" {
