@@ -217,9 +217,15 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #if !GFE_ATTN_PREFETCH
             load_k(kb2);
 #endif
+#if defined(GFE_ATTN_EXP_NOMFMA)          // timing experiment only: no matrix instructions (wrong results)
+            s = negm;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) { asm volatile("" :: "v"(kf[ds])); s[ds] += 1.0f; }
+#else
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
 #pragma unroll
             for (int ds = 1; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
+#endif
 #if GFE_ATTN_PREFETCH
             __builtin_amdgcn_sched_barrier(0);
             load_v(kb2);
@@ -234,18 +240,22 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
                 for (int r = 0; r < 16; ++r)
                     if (h4 >= lim - crow(r, 0)) s[r] = -INFINITY;        // key index crow(r, 0) + 4 hi >= lim
             }
-            // (v_max3 from asm: fmaxf() on MFMA outputs makes hipcc canonicalise every operand with an extra v_max_f32 x, x, x first)
-            // A VALU read of an MFMA result needs software wait states (11 after this 8-pass MFMA) and hipcc's hazard recogniser does not look
-            // inside inline asm: without the s_nops the steady-state path read s[0..2] before the matrix core had written them (the previous
-            // block's p values) -- spurious, harmless but run-to-run different moves of m.  The rest of the chain depends on this statement.
-            float mx;
-            asm("s_nop 7\n\ts_nop 3\n\tv_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
+#if defined(GFE_ATTN_EXP_NOVALU)          // timing experiment only: no softmax arithmetic (wrong results)
+            bf16x8 pb[2];
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
-            asm("v_max3_f32 %0, %1, %2, %2" : "=v"(mx) : "v"(mx), "v"(s[15]));
+            for (int tt = 0; tt < 2; ++tt) pb[tt] = __builtin_bit_cast(bf16x8, make_float4(s[8 * tt], s[8 * tt + 1], s[8 * tt + 2], s[8 * tt + 3]));
+#else
+            // The row maximum is a plain fmaxf() chain: built with -fno-honor-nans (csrc/Makefile) it compiles to eight v_max3_f32 without the
+            // canonicalising v_max_f32 x, x, x that hipcc otherwise puts in front of every MFMA result.  (Rounds 2-3 wrote the chain as inline asm
+            // instead -- and the hazard recogniser does not look inside asm: a VALU read of an MFMA result needs 11 software wait states
+            // after this 8-pass MFMA, the steady-state path had none, and the chain sometimes read the previous block's p values: spurious,
+            // harmless, but run-to-run different moves of m.  Compiler-visible instructions get their s_nops and can be scheduled.)
+            float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[r]);
             {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
                 const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                asm("v_max3_f32 %0, %1, %2, %2" : "=v"(mx) : "v"(__uint_as_float(xm[0])), "v"(__uint_as_float(xm[1])));
+                mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
             }
             if (kidx == 0 || __builtin_amdgcn_ballot_w64(mx > THR)) {   // move the maximum (mx = -inf, a fully masked block, moves nothing)
                 const float d = (kidx == 0) ? mx : fmaxf(mx, 0.f);       // per row: new m = m + d
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
                 const uint4 u = make_uint4(x0[0], x1[0], x0[1], x1[1]);
                 pb[tt] = __builtin_bit_cast(bf16x8, u);
             }
+#endif
             // ---- O^T += V^T P^T: two 32-wide d blocks x the block's two 16-key slots; A fragments by transposing reads of [key][d]
 #if !GFE_ATTN_PREFETCH
             load_v(kb2);
@@ -281,12 +292,20 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
+#if defined(GFE_ATTN_EXP_NOMFMA)
+                    asm volatile("" :: "v"(vf[tt][db]), "v"(pb[tt]));
+#else
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[tt][db], pb[tt], oacc[db], 0, 0, 0);
+#endif
                 }
             }
         }
         // tile t+1 has landed (this wave's pieces; the barrier makes all of it visible) while tile t+2's pieces, issued above, stay in flight
-#if defined(GFE_ATTN_EXP_DRAIN)
+#if defined(GFE_ATTN_EXP_SKEW)            // timing experiment: the younger wave of every SIMD pair leaves the barrier late
+        if (RING > 2 && t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave >= ANW / 2) __builtin_amdgcn_s_sleep(GFE_ATTN_EXP_SKEW);
+#elif defined(GFE_ATTN_EXP_DRAIN)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #elif defined(GFE_ATTN_EXP_2BAR)
         if (RING > 2 && t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");
