@@ -343,6 +343,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 }
 
 
+
 }  // namespace
 
 extern "C" {
