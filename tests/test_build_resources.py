@@ -15,7 +15,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 def _resources(src, tmp_path):
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-c", os.path.join(CSRC, src), *(["-fno-honor-nans"] if src == "attn.hip" else []),
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-c", os.path.join(CSRC, src), *(["-fno-honor-nans"] if src in ("attn.hip", "sscan2.hip") else []),
                           "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     res, cur = {}, None
