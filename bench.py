@@ -517,6 +517,11 @@ def main():
     # started by torch.distributed.run (any N, ALSO N = 1): the process group, the barrier, the gradient all-reduce on the head stream
     # and the graphed head are all live, so that a one-GPU box exercises exactly the code path the 8-GPU run takes (tests/test_multirank_gpu.py)
     distributed = "WORLD_SIZE" in os.environ
+    # stdout carries the ONE JSON line and nothing else: everything printed while the job runs (RCCL announces its version / library path on
+    # stdout when the first communicator is created, from C stdio) goes to stderr; the descriptor comes back just before the line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     if distributed:
@@ -624,7 +629,12 @@ def main():
             out["allreduce"] = comm
         if per_rank is not None:
             out["ms_per_step_by_rank"] = {"min": min(per_rank), "max": max(per_rank), "ranks": per_rank}
-        print(json.dumps(out))
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)                # C-side buffers (RCCL's banner) leave through stderr too
+        os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)                                 # (anything the teardown prints is not part of the contract either)
     if distributed:
         dist.destroy_process_group()
 

@@ -9,6 +9,7 @@ python3 $R/bench.py --no-pipeline > $O/step_b8_serial_bench.json 2> /dev/null
 python3 $R/bench.py --workload gen128 > $O/gen128_b2_bench.json 2> /dev/null
 python3 $R/bench.py --workload vit3d > $O/vit3d_b8_bench.json 2> /dev/null
 python3 $R/bench.py --workload gentrain > $O/gentrain_b2_bench.json 2> /dev/null
+python3 $R/bench.py --workload vit3dtrain > $O/vit3dtrain_b8_bench.json 2> /dev/null
 for b in 1 8 64; do python3 $R/bench.py --workload scan --batch $b > $O/scan_b${b}_bench.json 2> /dev/null; done
 python3 $R/bench.py --workload pscan > $O/pscan_b1_bench.json 2> /dev/null
 python3 $R/bench.py --volume native --batch 2 > $O/step_native_b2_bench.json 2> /dev/null
@@ -21,6 +22,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gen128 -o gen --
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv64 -o conv64 -- python3 $R/tools/conv_bench.py 64 96 8 20 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gentrain -o gentrain -- python3 $R/bench.py --workload gentrain --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vit3d -o vit -- python3 $R/bench.py --workload vit3d --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vit3dtrain -o vt -- python3 $R/bench.py --workload vit3dtrain --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_attnb -o attnb -- python3 $R/tools/attn_bench.py > /dev/null 2>&1
+cp $O/prof_vit3dtrain/vt_kernel_stats.csv $O/vit3dtrain_b8_kernel_stats.csv
+cp $O/prof_attnb/attnb_kernel_stats.csv $O/attn_bwd_kernel_stats.csv
 cp $O/prof_gentrain/gentrain_kernel_stats.csv $O/gentrain_b2_kernel_stats.csv
 cp $O/prof_vit3d/vit_kernel_stats.csv $O/vit3d_b8_kernel_stats.csv
 cp $O/prof_step/step_kernel_stats.csv $O/step_b8_kernel_stats.csv
@@ -35,7 +40,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_conv_fet
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_conv_write -o p -- python3 $R/tools/conv_bench.py 64 96 8 10 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_attn_fetch -o p -- python3 $R/tools/attn_bench.py 8 8 1729 20 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_attn_write -o p -- python3 $R/tools/attn_bench.py 8 8 1729 20 > /dev/null 2>&1
-bash $R/tools/pmc_attn.sh r03/attn_pmc > $O/attn_pmc.txt 2>&1
+bash $R/tools/pmc_attn.sh r03/attn_pmc attn_fwd attn_bwd_dkdv attn_bwd_dq > $O/attn_pmc.txt 2>&1
 bash $R/tools/pmc_scan.sh r03/scan_pmc > $O/scan_pmc.txt 2>&1
 cd /tmp
 cd $R
@@ -66,6 +71,13 @@ for d, scale in (("pmc_attn_fetch", 2.0), ("pmc_attn_write", 1.0)):
     if not f: continue
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "attn_fwd" in r["Kernel_Name"]]
     if v: attn[d] = sum(v) / len(v) * scale * 1024
+attnb = {}
+for kern in ("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_prep"):
+    for d, scale in (("pmc_attn_fetch", 2.0), ("pmc_attn_write", 1.0)):
+        f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+        if not f: continue
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if kern in r["Kernel_Name"]]
+        if v: attnb.setdefault(kern, {})[d] = sum(v) / len(v) * scale * 1024
 conv = {}
 for d, scale in (("pmc_conv_fetch", 2.0), ("pmc_conv_write", 1.0)):
     f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
@@ -81,6 +93,10 @@ if len(attn) == 2:
     extra["attn_fwd_b8_h8_n1729"] = {"traffic_bytes": sum(attn.values()), "fetch_x2_bytes": attn["pmc_attn_fetch"], "write_bytes": attn["pmc_attn_write"],
                                      "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of attn_fwd_kernel in tools/attn_bench.py 8 8 1729"}
     print("attention B=8 H=8 n=1729 traffic per launch: fetch %.1f MB (x2 applied) + write %.1f MB" % (attn["pmc_attn_fetch"] / 1e6, attn["pmc_attn_write"] / 1e6))
+if attnb:
+    extra["attn_bwd_b8_h8_n1729"] = {"traffic_bytes": sum(sum(v.values()) for v in attnb.values()), "per_kernel": attnb,
+                                     "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of the three gfe_attention_bwd kernels in tools/attn_bench.py 8 8 1729"}
+    print("attention backward traffic per launch:", {k: {kk: round(vv / 1e6, 1) for kk, vv in v.items()} for k, v in attnb.items()})
 json.dump({**extra, "scan_b8": {"traffic_bytes": tot, "per_kernel": res,
                        "method": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 reports half of coalesced reads at 4, 8 and 16 B per lane, tools/probes/fetch_calib.hip) and --pmc WRITE_SIZE, separate passes, mean per launch of sscan2_fwd + sscan2_bwd at B=8 L=4096 ED=1024 N=16 bf16"}},
           open(os.path.join(O, "traffic_r03.json"), "w"), indent=1)
