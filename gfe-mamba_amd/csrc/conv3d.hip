@@ -111,6 +111,9 @@ struct ConvParams {
     // multi-class launches (the 8 parity classes of a transposed conv in ONE launch, work item = (tile, class)): class c uses taps
     // c_tap0[c] .. c_tap0[c] + c_ntaps[c] - 1 of toff / txor, the weight set at element offset c_woff[c], output parity c_op[c]
     int ncls; int c_ntaps[8]; int c_tap0[8]; int c_op[8]; long long c_woff[8]; unsigned w_bytes;
+    // dynamic tile scheduling (single-class launches): sched[0..7] = per-XCD ticket counters, sched[8] = finished blocks; zero between
+    // launches (the last block to finish resets them).  NULL: every block walks its static share.
+    int* sched;
 };
 
 struct TilePos { int b, td, th, tw, cls; };
@@ -159,7 +162,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     const int tile_end = MC ? min(ntiles, tile_begin + p.tiles_per_block) : xcd_end;
     const int upt = p.ngroups * p.nslab;                     // units per tile: (group, slab)
     const int my_tiles = tile_end > tile_begin ? (tile_end - tile_begin + tile_stride - 1) / tile_stride : 0;
-    const int nunits = my_tiles * upt;
+    // Dynamic scheduling: the blocks of an XCD draw the tiles of the XCD's range in order from a ticket counter instead of walking fixed
+    // shares.  At any time the XCD still works on ~nbx consecutive tiles (the L2 argument above), but a block that shares its CU with another
+    // stream's kernels (the head of the previous batch in the two-stream step, RCCL's all-reduce in a multi-rank run) simply draws fewer
+    // tiles, where a static share made the whole launch wait for it.  The ticket for tile k+1 is drawn while tile k is computed (its DMA is
+    // issued one unit ahead), by thread 0, and travels through LDS behind the stage barriers.  Results do not depend on who computes a tile.
+    __shared__ int s_ticket;
+    const bool dyn = !MC && p.sched != nullptr && upt >= 2;
+    auto finish = [&]() {                                    // the last block of the launch leaves the counters at zero for the next one
+        if (dyn && tid == 0) {
+            __threadfence();
+            if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) p.sched[i] = 0;
+            }
+        }
+    };
+    int dyn_first = 0;
+    if (dyn) {
+        if (tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
+        __syncthreads();
+        dyn_first = xcd_begin + __builtin_amdgcn_readfirstlane(s_ticket);
+        __syncthreads();                                     // (thread 0 overwrites the ticket at the top of the first unit)
+        if (dyn_first >= xcd_end) { finish(); return; }
+    }
+    const int nunits = dyn ? 0x7fffffff : my_tiles * upt;
     if (nunits <= 0) return;
 #if defined(GFE_EXP_STAMP)
     const bool stamp_on = g_stamp_buf != nullptr && blockIdx.x == 101;
@@ -214,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         q.td = t % p.ntd; q.b = t / p.ntd;
         return q;
     };
-    int cur_t = tile_begin, nxt_t = tile_begin;             // work-item indices (block-uniform)
+    int cur_t = dyn ? dyn_first : tile_begin, nxt_t = cur_t;  // work-item indices (block-uniform)
     TilePos cur = decode(cur_t);
     TilePos nxt = cur;
 
@@ -294,10 +321,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 
     for (int u = 0; u < nunits; ++u) {
         const int ut = u % upt, group = ut / p.nslab, slab = ut - group * p.nslab;
-        const bool next_unit = u + 1 < nunits;
         const int ut1 = (ut + 1 == upt) ? 0 : ut + 1;
         const int group1 = ut1 / p.nslab, slab1 = ut1 - group1 * p.nslab;
-        if (next_unit && ut1 == 0) { nxt_t += tile_stride; nxt = decode(nxt_t); }
+        bool next_unit = u + 1 < nunits;
+        if (dyn) {
+            // first unit of a tile: draw the ticket of the tile after it; last unit (>= one stage barrier later): read it
+            if (ut == 0 && tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
+            if (ut1 == 0) {
+                nxt_t = xcd_begin + __builtin_amdgcn_readfirstlane(*(volatile int*)&s_ticket);
+                next_unit = nxt_t < xcd_end;
+                if (next_unit) nxt = decode(nxt_t);
+            }
+        } else if (next_unit && ut1 == 0) { nxt_t += tile_stride; nxt = decode(nxt_t); }
         const uint8_t* aT = sA + (A_BUFS == 2 ? (u & 1) * A_BYTES : 0);
         const int ntaps_u = MC ? p.c_ntaps[cur.cls] : p.ntaps, tap0_u = MC ? p.c_tap0[cur.cls] : 0;
         const int nstage = (ntaps_u + TPS - 1) / TPS;
@@ -443,7 +478,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         }
 
 #if defined(GFE_EXP_NOEPI)     // timing experiment only: results are never stored
-        if (slab == p.nslab - 1 && u + 1 == nunits) {
+        if (slab == p.nslab - 1 && !next_unit) {
 #else
         if (slab == p.nslab - 1) {
 #endif
@@ -731,8 +766,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             }
         }
         GFE_STAMP(5);
-        if (ut + 1 == upt) { cur_t += tile_stride; cur = decode(min(cur_t, ntiles - 1)); }
+        if (!next_unit) break;
+        if (ut + 1 == upt) {
+            if (dyn) { cur_t = nxt_t; cur = nxt; }
+            else { cur_t += tile_stride; cur = decode(min(cur_t, ntiles - 1)); }
+        }
     }
+    finish();
 #endif
 }
 
@@ -819,6 +859,23 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     }
 }
 
+// Ticket counters of the dynamic tile scheduler: a ring of 16-int slots, zeroed once; a launch takes the next slot (a captured launch keeps
+// its slot across replays: the kernel leaves it at zero).  Allocated outside stream capture only; GFE_CONV_STATIC=1 turns the scheduler off.
+static int* conv_sched_slot(hipStream_t st) {
+    constexpr int SLOTS = 256;
+    static int* ring = nullptr;
+    static bool off = getenv("GFE_CONV_STATIC") != nullptr && getenv("GFE_CONV_STATIC")[0] == '1';
+    static unsigned seq = 0;
+    if (off) return nullptr;
+    if (!ring) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        if (hipMalloc((void**)&ring, SLOTS * 16 * sizeof(int)) != hipSuccess) { ring = nullptr; return nullptr; }
+        if (hipMemset(ring, 0, SLOTS * 16 * sizeof(int)) != hipSuccess) return nullptr;
+    }
+    return ring + 16 * (seq++ % SLOTS);
+}
+
 template <int NT, int TPS, bool REG27, bool STATS, bool MC = false, bool RES1 = false, bool OUT1 = false>
 int conv_launch(const ConvParams& p, hipStream_t st) {
     constexpr int W_PIECES = (TPS * NT * 16 + 15) / 16;
@@ -827,6 +884,7 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     if (tiles > 0x7fffffff) return GFE_ERR_SHAPE;
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
+    q.sched = MC ? nullptr : conv_sched_slot(st);
     q.tiles_per_block = (int)ceil_div(tiles, NBLK);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;

@@ -1,12 +1,14 @@
 """GPU parity of the generator kernels (conv3d implicit GEMM, GroupNorm, pool, transposed conv, fold, ViT, GEMM) against
 reference-generated fixtures and the oracle.  bf16 activations -> tolerance 1e-2 rel (BASELINE.json north_star);
 index permutations and max-pool are bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, rel_err, sub_sd, tt
+from conftest import ROOT, golden, rel_err, sub_sd, tt
 from oracle import ref_ops as O
 
 pytestmark = pytest.mark.gpu
@@ -217,6 +219,47 @@ def test_fused_groupnorm_partials_match_the_statistics_pass(C, shape):
     skip = torch.randn(B, 2 * D, 2 * H, 2 * W, C, generator=g).to(BF).to(DEV)
     with torch.no_grad():
         check(up(skip, x))
+
+
+_CONV_CHILD = """
+import sys, torch
+sys.path.insert(0, %r)
+from gfe_hip import nn_ops as K
+t = torch.load(sys.argv[1])
+x, w, tab = t["x"].cuda(), t["w"].cuda(), t["tab"].cuda()
+st = (K.new_gn_partials(2, K.conv_stat_slots(2, 40, 24, 56, 64), 64, x.device), 0)
+y = K.conv_igemm(x, w, K.CONV3_TAPS, 64, bias_tab=tab, relu=True, stats=st)
+torch.save({"y": y.cpu(), "stats": st[0].cpu()}, sys.argv[2])
+"""
+
+
+def test_conv_ticket_scheduler_equals_static_shares(tmp_path):
+    """The conv kernel's blocks draw their tiles from per-XCD ticket counters (csrc/conv3d.hip: a block that shares its CU with another
+    stream's kernel just draws fewer); GFE_CONV_STATIC=1 restores the fixed shares.  Outputs and GroupNorm partials must not depend on who
+    computed a tile: two fresh processes on the same operands, bit for bit; the counters must be back at zero after every launch (a 5-launch
+    loop in this process, which reuses them, gives the same bits)."""
+    import subprocess
+    import sys
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 40, 24, 56, 64, generator=g).to(BF).to(DEV)
+    w32 = K.pack_conv3((torch.randn(64, 64, 3, 3, 3, generator=g) / 40).to(DEV), torch.float32)
+    ss = K.groupnorm_scale_shift(x, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 8)
+    w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, 64, 64)
+    ops = str(tmp_path / "operands.pt")
+    torch.save({"x": x.cpu(), "w": w.cpu(), "tab": tab.cpu()}, ops)
+    src = _CONV_CHILD % os.path.join(ROOT, "gfe-mamba_amd")
+    outs = {}
+    for mode in ("0", "1"):
+        f = str(tmp_path / f"conv_{mode}.pt")
+        r = subprocess.run([sys.executable, "-c", src, ops, f], env=dict(os.environ, GFE_CONV_STATIC=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(f)
+    assert torch.equal(outs["0"]["y"], outs["1"]["y"]) and torch.equal(outs["0"]["stats"], outs["1"]["stats"])
+    for _ in range(5):
+        st = (K.new_gn_partials(2, K.conv_stat_slots(2, 40, 24, 56, 64), 64, x.device), 0)
+        y = K.conv_igemm(x, w, K.CONV3_TAPS, 64, bias_tab=tab, relu=True, stats=st)
+        assert torch.equal(y.cpu(), outs["1"]["y"]) and torch.equal(st[0].cpu(), outs["1"]["stats"])
 
 
 @pytest.mark.parametrize("B,H,n", [(2, 8, 1729), (1, 2, 64), (1, 3, 65), (2, 1, 127), (1, 2, 300), (1, 1, 1)])
