@@ -861,7 +861,8 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
 
 // Ticket counters of the dynamic tile scheduler: a ring of 16-int slots, zeroed once; a launch takes the next slot (a captured launch keeps
 // its slot across replays: the kernel leaves it at zero).  Allocated outside stream capture only; GFE_CONV_STATIC=1 turns the scheduler off.
-static int* conv_sched_slot(hipStream_t st) {
+}  // namespace
+int* conv_sched_slot(hipStream_t st) {
     constexpr int SLOTS = 256;
     static int* ring = nullptr;
     static bool off = getenv("GFE_CONV_STATIC") != nullptr && getenv("GFE_CONV_STATIC")[0] == '1';
@@ -875,6 +876,7 @@ static int* conv_sched_slot(hipStream_t st) {
     }
     return ring + 16 * (seq++ % SLOTS);
 }
+namespace {
 
 template <int NT, int TPS, bool REG27, bool STATS, bool MC = false, bool RES1 = false, bool OUT1 = false>
 int conv_launch(const ConvParams& p, hipStream_t st) {

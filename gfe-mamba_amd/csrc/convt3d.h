@@ -14,9 +14,11 @@ struct ConvTParams {
     int c_ntaps[CONVT_NCLS], c_lg[CONVT_NCLS], c_tap0[CONVT_NCLS], c_op[CONVT_NCLS];
     long long c_woff[CONVT_NCLS]; unsigned w_bytes;
     int toff[27], txor[27];   // LDS byte offset / swizzle term of each tap inside a slab image (same as conv3d.hip's halo tile)
+    int* sched;               // dynamic tile scheduling (conv3d.hip): [0..7] per-XCD ticket counters, [8] finished blocks; NULL = static shares
 };
 
 bool convt_resident_fits(int64_t Cin, int64_t Cout);
 int convt_resident_grid(int64_t B, int64_t D, int64_t H, int64_t W, int* tiles_per_block);
 int convt_resident_tiles(int64_t D, int64_t H, int64_t W);      // tiles (= GroupNorm partial slots) per sample
 int convt_resident_launch(ConvTParams& p, hipStream_t st);
+int* conv_sched_slot(hipStream_t st);                            // conv3d.hip: the next slot of the ticket-counter ring (NULL: off / not allocatable now)

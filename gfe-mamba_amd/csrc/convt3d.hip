@@ -69,9 +69,30 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
     const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const int vb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     const int nbx = xq + (xcd < xr ? 1 : 0);
-    const int tile_begin = min(ntiles, (vb - xi) * p.tiles_per_block) + xi, tile_end = min(ntiles, (vb - xi + nbx) * p.tiles_per_block);
-    if (tile_begin >= tile_end) return;
-    const int my_tiles = (tile_end - tile_begin + nbx - 1) / nbx;
+    const int xcd_begin = min(ntiles, (vb - xi) * p.tiles_per_block);
+    int tile_begin = xcd_begin + xi;
+    const int tile_end = min(ntiles, (vb - xi + nbx) * p.tiles_per_block);
+    // dynamic tile scheduling (conv3d.hip): the XCD's blocks draw its tiles in order from a ticket counter; the ticket of tile k+1 is drawn at
+    // the top of tile k by thread 0 and read, behind the classes' barriers, when the last class starts (the first use of the next tile)
+    __shared__ int s_ticket;
+    const bool dyn = p.sched != nullptr;
+    auto finish = [&]() {
+        if (dyn && tid == 0) {
+            __threadfence();
+            if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) p.sched[i] = 0;
+            }
+        }
+    };
+    if (dyn) {
+        if (tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
+        __syncthreads();
+        tile_begin = xcd_begin + rfl(s_ticket);
+        __syncthreads();
+    }
+    if (tile_begin >= tile_end) { finish(); return; }
+    const int my_tiles = dyn ? 0x7fffffff : (tile_end - tile_begin + nbx - 1) / nbx;
 
     auto decode = [&](int t) {
         TilePos q;
@@ -143,13 +164,19 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
     int gstage = 0;
 
     for (int ti = 0; ti < my_tiles; ++ti) {
-        const bool next_tile = ti + 1 < my_tiles;
-        const TilePos nxt = next_tile ? decode(tile_begin + (ti + 1) * nbx) : cur;
+        bool next_tile = !dyn && ti + 1 < my_tiles;
+        TilePos nxt = next_tile ? decode(tile_begin + (ti + 1) * nbx) : cur;
+        if (dyn && tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
         int pf_slab = 0;                                          // slabs of the next tile already requested
         // classes in reverse buffer order: the host puts the heavy classes first, the 8-tap class must run LAST here
         for (int ci = CONVT_NCLS - 1; ci >= 0; --ci) {
             const int ntaps = p.c_ntaps[ci], lg = p.c_lg[ci], tap0 = p.c_tap0[ci];
             const int nk = ntaps * p.nslab, nst = (nk + TPS - 1) / TPS;
+            if (dyn && ci == 0) {                                  // seven classes' worth of barriers after the draw
+                const int nt_ = xcd_begin + rfl(*(volatile int*)&s_ticket);
+                next_tile = nt_ < tile_end;
+                if (next_tile) nxt = decode(nt_);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -313,8 +340,10 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
             }
             __syncthreads();
         }
+        if (!next_tile) break;
         cur = nxt;
     }
+    finish();
 #endif
 }
 
@@ -334,6 +363,7 @@ int convt_resident_grid(int64_t B, int64_t D, int64_t H, int64_t W, int* tiles_p
 int convt_resident_launch(ConvTParams& p, hipStream_t st) {
     p.ntd = (int)ceil_div(p.D, TD); p.nth = (int)ceil_div(p.H, TH); p.ntw = (int)ceil_div(p.W, TW);
     const int grid = convt_resident_grid(p.B, p.D, p.H, p.W, &p.tiles_per_block);
+    p.sched = conv_sched_slot(st);
     const size_t lds = (size_t)CONVT_MAX_SLABS * SLAB_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * 64 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)convt_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
