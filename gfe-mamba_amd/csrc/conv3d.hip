@@ -862,6 +862,12 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
 // Ticket counters of the dynamic tile scheduler: a ring of 16-int slots, zeroed once; a launch takes the next slot (a captured launch keeps
 // its slot across replays: the kernel leaves it at zero).  Allocated outside stream capture only; GFE_CONV_STATIC=1 turns the scheduler off.
 }  // namespace
+static int g_conv_reserved_cus = -1;
+int conv_reserved_cus() {
+    if (g_conv_reserved_cus < 0) { const char* e = getenv("GFE_CONV_RESERVE_CUS"); g_conv_reserved_cus = e ? atoi(e) : 0; }
+    return g_conv_reserved_cus < 0 ? 0 : (g_conv_reserved_cus > 128 ? 128 : g_conv_reserved_cus);
+}
+extern "C" int gfe_conv_reserve_cus(int n) { const int old = conv_reserved_cus(); g_conv_reserved_cus = n < 0 ? 0 : n; return old; }
 int* conv_sched_slot(hipStream_t st) {
     constexpr int SLOTS = 256;
     static int* ring = nullptr;
@@ -887,7 +893,9 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
     q.sched = MC ? nullptr : conv_sched_slot(st);
-    q.tiles_per_block = (int)ceil_div(tiles, NBLK);
+    // with the ticket scheduler the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream
+    const int nblk = (q.sched && NBLK == 256) ? NBLK - conv_reserved_cus() : NBLK;
+    q.tiles_per_block = (int)ceil_div(tiles, nblk);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1, OUT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }

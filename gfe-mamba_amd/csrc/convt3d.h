@@ -21,4 +21,5 @@ bool convt_resident_fits(int64_t Cin, int64_t Cout);
 int convt_resident_grid(int64_t B, int64_t D, int64_t H, int64_t W, int* tiles_per_block);
 int convt_resident_tiles(int64_t D, int64_t H, int64_t W);      // tiles (= GroupNorm partial slots) per sample
 int convt_resident_launch(ConvTParams& p, hipStream_t st);
+int conv_reserved_cus();                                         // conv3d.hip: CUs the persistent conv kernels leave free (gfe_conv_reserve_cus)
 int* conv_sched_slot(hipStream_t st);                            // conv3d.hip: the next slot of the ticket-counter ring (NULL: off / not allocatable now)

@@ -362,8 +362,13 @@ int convt_resident_grid(int64_t B, int64_t D, int64_t H, int64_t W, int* tiles_p
 
 int convt_resident_launch(ConvTParams& p, hipStream_t st) {
     p.ntd = (int)ceil_div(p.D, TD); p.nth = (int)ceil_div(p.H, TH); p.ntw = (int)ceil_div(p.W, TW);
-    const int grid = convt_resident_grid(p.B, p.D, p.H, p.W, &p.tiles_per_block);
+    int grid = convt_resident_grid(p.B, p.D, p.H, p.W, &p.tiles_per_block);
     p.sched = conv_sched_slot(st);
+    if (p.sched && conv_reserved_cus() > 0) {                     // leave CUs to another stream's kernels (conv3d.hip)
+        const int64_t tiles = (int64_t)p.B * p.ntd * p.nth * p.ntw;
+        p.tiles_per_block = (int)ceil_div(tiles, (int64_t)(256 - conv_reserved_cus()));
+        grid = (int)ceil_div(tiles, (int64_t)p.tiles_per_block);
+    }
     const size_t lds = (size_t)CONVT_MAX_SLABS * SLAB_BYTES + 2 * (size_t)W_PIECES * 1024 + (size_t)NWAVES * 2 * 64 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)convt_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }

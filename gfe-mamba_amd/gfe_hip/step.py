@@ -46,9 +46,9 @@ class ClassifyStep:
         self.world_size, self.group = world_size, group
         # The generator is frozen (classify_mamba.py:53,100), so its forward for step k+1 does not depend on update k: with
         # overlap_update the gradient all-reduce + Adam of step k run on a side stream underneath it (same arithmetic, same order
-        # of updates).  Off by default: measured on one GPU it LOSES 3 % (16.9 -> 17.5 ms) -- the update kernel takes CUs away from
-        # the persistent one-block-per-CU conv kernels, whose statically partitioned tile ranges then wait for the straggler --
-        # and RCCL's kernels would do the same; to be re-measured on an 8-GPU node before it becomes the default there.
+        # of updates).  Off by default: measured on one GPU in round 1 it LOST 3 % (16.9 -> 17.5 ms) -- the update kernel took CUs away
+        # from the persistent one-block-per-CU conv kernels, whose statically partitioned tile ranges then waited for the straggler
+        # (the conv kernels draw their tiles from ticket counters since round 3); to be re-measured on an 8-GPU node.
         self.overlap_update = bool(overlap_update)
 
     # ---- cross-batch software pipeline -------------------------------------------------------------------------------

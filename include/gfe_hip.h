@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 38
+#define GFE_ABI_VERSION 39
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -154,6 +154,11 @@ int gfe_conv3d_igemm(const void* x, const void* w_packed, int64_t w_batch_stride
 
 /* Number of 8x8x8 output tiles per sample of gfe_conv3d_igemm on a (D, H, W) class grid = partial slots one call writes. Host-only. */
 int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W);
+
+/* The implicit-GEMM conv kernels run one persistent block per CU and draw their tiles from per-XCD ticket counters; with n > 0 they launch
+ * 256 - n blocks, i.e. leave n CUs to the kernels of another stream (the head of the previous batch in the two-stream step; a conv block
+ * fills a CU's registers and LDS, nothing else can share it).  Returns the previous value.  Process-wide; default 0 or GFE_CONV_RESERVE_CUS. */
+int gfe_conv_reserve_cus(int n);
 /* GroupNorm-partial slots per sample one gfe_conv3d_igemm call with stats_ws writes (see above). Host-only. */
 int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout);
 
