@@ -467,6 +467,12 @@ int gfe_attention_bwd(const void* q, const void* k, const void* v, const void* o
     GFE_REQUIRE(total <= 0x7fffffff && rows <= 0x7fffffff, GFE_ERR_SHAPE);
     p.total = (int)total;
     hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;                         // 66 KB of dynamic LDS for the dK/dV ring
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_KV * STAGE_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING * STAGE_Q);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)ceil_div(rows, 32)), dim3(256), 0, st, p, rows);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)total), dim3(BW * 64), RING_KV * STAGE_KV, st, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)total), dim3(BW * 64), RING * STAGE_Q, st, p);
