@@ -14,6 +14,7 @@
 //                 C: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi (+32) of ITS row -> the online-softmax rescale is a per-lane
 //                 scalar, no cross-lane traffic at all.
 #include "common.h"
+#include "attn_drop.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -55,6 +56,10 @@ struct AttnParams {
     float c;                      // scale * log2(e): scores are kept in log2 units
     float* nlse;                  // optional (training): -(m + log2 l) per row, [B][H][npad], rows n .. npad-1 = -inf (attn_bwd.hip)
     int npad;
+    // dropout on the probabilities (vit_3d.py:56, training): element (bh, q, key) is kept iff attn_drop_hash(seed_bh, q * npad + key) >= drop_thr;
+    // kept probabilities are scaled by inv_keep = 1 / (1 - p) (folded into the final normalisation); the row sum is the UNdropped softmax's
+    uint32_t drop_thr, seed_lo, seed_hi;
+    float inv_keep;
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -71,6 +76,7 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) * 16); }
 
 // (HIP: the second __launch_bounds__ argument is the minimum number of waves per SIMD: 3 keeps the kernel at <= 168 VGPRs)
+template <bool DROP>
 __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)       // the host pass only needs the launch stub (the body uses device-only buffer / LDS-DMA builtins)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // 2 * RING * TILE_BYTES: K[RING], V[RING]
@@ -271,6 +277,13 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
                 ps0 += s[r]; ps1 += s[r + 1];
             }
             lsum += ps0 + ps1;
+            if constexpr (DROP) {                                        // attn = dropout(softmax): the mask is a hash of (seed, head, row, key)
+                const uint32_t sb = attn_drop_seed(p.seed_lo, p.seed_hi, (uint32_t)bh);
+                const uint32_t e0 = (uint32_t)(q0 + ql) * (uint32_t)p.npad + 32u * (uint32_t)kidx + 4u * (uint32_t)hi;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (attn_drop_hash(sb, e0 + (uint32_t)crow(r, 0)) < p.drop_thr) s[r] = 0.f;
+            }
             // ---- P -> bf16 B operands.  16-key slot tt of the block: lane hi=0 must hold keys 0..7 of the slot, hi=1 keys 8..15;
             // it owns {0..3, 8..11} + 4hi -> one v_permlane32_swap per word pair exchanges the misplaced halves.
             bf16x8 pb[2];
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 
     // ---- normalise and store: lane (q, hi) holds d = 32*db + crow(r, hi) of its row
     const float l = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / l;
+    const float inv = (DROP ? p.inv_keep : 1.0f) / l;
     const int q = q0 + ql;
     if (p.nlse && hi == 0 && q < p.npad)        // the backward restarts its score chains from this value: exp2(S + nlse) = the normalised probability
         p.nlse[(size_t)bh * p.npad + q] = q < p.n ? negm[0] - __builtin_amdgcn_logf(l) : -INFINITY;   // (v_log_f32 is log2)
@@ -350,7 +363,7 @@ extern "C" {
 
 static int attention_fwd_launch(const void* q, const void* k, const void* v, void* o, float* nlse, int64_t B, int64_t H, int64_t n, int64_t dh,
                                 int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
-                                int64_t o_batch, int64_t o_row, float scale, void* stream) {
+                                int64_t o_batch, int64_t o_row, float scale, float p_drop, int64_t seed, void* stream) {
     GFE_REQUIRE(q && k && v && o, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && H > 0 && n > 0 && dh == AD && B * H <= 65535 && n <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(q_row % 8 == 0 && k_row % 8 == 0 && v_row % 8 == 0 && o_row % 4 == 0, GFE_ERR_SHAPE);       // 16-byte loads, 8-byte stores
@@ -360,25 +373,29 @@ static int attention_fwd_launch(const void* q, const void* k, const void* v, voi
     p.q_batch = q_batch; p.q_row = q_row; p.k_batch = k_batch; p.k_row = k_row; p.v_batch = v_batch; p.v_row = v_row;
     p.o_batch = o_batch; p.o_row = o_row; p.H = (int)H; p.n = (int)n; p.c = scale * GFE_LOG2E;
     p.nlse = nlse; p.npad = (int)(ceil_div(n, 64) * 64);
+    GFE_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || n <= 65535), GFE_ERR_SHAPE);          // (the mask's element index q * npad + key is 32-bit)
+    p.drop_thr = attn_drop_threshold(p_drop); p.seed_lo = (uint32_t)(uint64_t)seed; p.seed_hi = (uint32_t)((uint64_t)seed >> 32);
+    p.inv_keep = 1.0f / (1.0f - p_drop);
     p.nqb = (int)ceil_div(n, ANW * QW);
     const int64_t total = (int64_t)p.nqb * B * H;
     GFE_REQUIRE(total <= 0x7fffffff, GFE_ERR_SHAPE);
     p.total = (int)total;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)total), dim3(ANW * 64), 2 * RING * TILE_BYTES, (hipStream_t)stream, p);
+    if (p.drop_thr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)total), dim3(ANW * 64), 2 * RING * TILE_BYTES, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)total), dim3(ANW * 64), 2 * RING * TILE_BYTES, (hipStream_t)stream, p);
     return gfe_launch_status();
 }
 
 int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t n, int64_t dh,
                       int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
                       int64_t o_batch, int64_t o_row, float scale, void* stream) {
-    return attention_fwd_launch(q, k, v, o, nullptr, B, H, n, dh, q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale, stream);
+    return attention_fwd_launch(q, k, v, o, nullptr, B, H, n, dh, q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale, 0.f, 0, stream);
 }
 
 int gfe_attention_fwd_lse(const void* q, const void* k, const void* v, void* o, void* nlse, int64_t B, int64_t H, int64_t n, int64_t dh,
                           int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
-                          int64_t o_batch, int64_t o_row, float scale, void* stream) {
+                          int64_t o_batch, int64_t o_row, float scale, float p_drop, int64_t seed, void* stream) {
     GFE_REQUIRE(nlse, GFE_ERR_NULL);
-    return attention_fwd_launch(q, k, v, o, (float*)nlse, B, H, n, dh, q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale, stream);
+    return attention_fwd_launch(q, k, v, o, (float*)nlse, B, H, n, dh, q_batch, q_row, k_batch, k_row, v_batch, v_row, o_batch, o_row, scale, p_drop, seed, stream);
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 // A streamed tile is read both by rows (ds_read_b128, the A operand of S / dP) and transposed (ds_read_b64_tr_b16, the A operand of the
 // dV^T / dK^T / dQ^T products): ONE swizzled image serves both conflict-free, see u_swz.
 #include "common.h"
+#include "attn_drop.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -44,6 +45,7 @@ struct BwdParams {
     int H, n, npad;
     int nblk, total;              // blocks per (batch, head); blocks in the grid
     float scale;
+    uint32_t drop_thr, seed_lo, seed_hi; float inv_keep;      // dropout on the probabilities (attn_drop.h), as in the forward
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const BwdParams p, c
 // block i+1's row fragments and row statistics are read into a second register set while block i is multiplied, across tile boundaries too --
 // the workgroup barrier that publishes tile t+1 (and retires tile t-1's last readers) sits in FRONT of tile t's last block, and the DMA that
 // refills tile t-1's ring slot with tile t+RING-1 is issued right behind it.
+template <bool DROP>
 __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING_KV stages of STAGE_KV bytes
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
             const float4 a = *reinterpret_cast<const float4*>(sl + 32 * r4);
             const float4 d = *reinterpret_cast<const float4*>(sl + STAT_BYTES + 32 * r4);
             s[4 * r4] = a.x; s[4 * r4 + 1] = a.y; s[4 * r4 + 2] = a.z; s[4 * r4 + 3] = a.w;
-            dp[4 * r4] = d.x; dp[4 * r4 + 1] = d.y; dp[4 * r4 + 2] = d.z; dp[4 * r4 + 3] = d.w;
+            if constexpr (DROP) { dp[4 * r4] = 0.f; dp[4 * r4 + 1] = 0.f; dp[4 * r4 + 2] = 0.f; dp[4 * r4 + 3] = 0.f; }     // the mask sits between dP and -delta
+            else { dp[4 * r4] = d.x; dp[4 * r4 + 1] = d.y; dp[4 * r4 + 2] = d.z; dp[4 * r4 + 3] = d.w; }
         }
     };
 
@@ -308,8 +312,28 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
                 dsb[tt] = __builtin_bit_cast(bf16x8, make_float4(dp[8 * tt], dp[8 * tt + 1], dp[8 * tt + 2], dp[8 * tt + 3]));
             }
 #else
+            if constexpr (DROP) {
+                // dS = P o (mask / (1 - p) o dP - delta); dV takes the masked P (its 1 / (1 - p) at the very end)
+                const uint32_t sb = attn_drop_seed(p.seed_lo, p.seed_hi, (uint32_t)bh);
+                const uint32_t e0 = (uint32_t)(RT * t + 32 * j + 4 * hi) * (uint32_t)p.npad + (uint32_t)key;
+                const uint8_t* sd = st + 2 * TILE_BYTES + STAT_BYTES + 32 * j * 4 + stat_off;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r]); dp[r] *= s[r]; }
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(sd + 32 * r4);
+                    const float nd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * r4 + i;
+                        const bool keep = attn_drop_hash(sb, e0 + (uint32_t)crow(r, 0) * (uint32_t)p.npad) >= p.drop_thr;
+                        const float pr = fast_exp2(s[r]);
+                        dp[r] = pr * fmaf(keep ? p.inv_keep : 0.f, dp[r], nd[i]);
+                        s[r] = keep ? pr : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r]); dp[r] *= s[r]; }
+            }
             pack_b(pb, s);
             pack_b(dsb, dp);
 #endif
@@ -339,13 +363,14 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
 
     if (key < p.n) {
         const size_t go = (size_t)b * p.g_batch + (size_t)key * p.g_row + h * AD;
-        store_rows(p.dv + go, dva, 1.0f, hi);
+        store_rows(p.dv + go, dva, DROP ? p.inv_keep : 1.0f, hi);
         store_rows(p.dk + go, dka, 0.6931471805599453f, hi);             // dS^T Qs carries scale * log2 e
     }
 #endif
 }
 
 // ---- dQ: a wave owns 32 query rows
+template <bool DROP>
 __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING stages of STAGE_Q bytes
@@ -411,7 +436,15 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
             f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[0], qf[0], nlv, 0, 0, 0);
 #pragma unroll
             for (int ds = 1; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[ds], qf[ds], s, 0, 0, 0);
-            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[0], dof[0], ndv, 0, 0, 0);
+            f32x16 dp;
+            if constexpr (DROP) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[0], dof[0], z, 0, 0, 0);
+            } else {
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[0], dof[0], ndv, 0, 0, 0);
+            }
 #pragma unroll
             for (int ds = 1; ds < 4; ++ds) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[ds], dof[ds], dp, 0, 0, 0);
             if (ragged) {                                                // keys >= n do not exist
@@ -420,8 +453,18 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
                 for (int r = 0; r < 16; ++r)
                     if (h4 >= lim - crow(r, 0)) s[r] = -INFINITY;
             }
+            if constexpr (DROP) {
+                const uint32_t sb = attn_drop_seed(p.seed_lo, p.seed_hi, (uint32_t)bh);
+                const uint32_t e0 = (uint32_t)q * (uint32_t)p.npad + (uint32_t)(RT * t + 32 * kb2 + 4 * hi);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dp[r] *= fast_exp2(s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const bool keep = attn_drop_hash(sb, e0 + (uint32_t)crow(r, 0)) >= p.drop_thr;
+                    dp[r] = fast_exp2(s[r]) * fmaf(keep ? p.inv_keep : 0.f, dp[r], nd);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] *= fast_exp2(s[r]);
+            }
             bf16x8 dsb[2];
             pack_b(dsb, dp);
             // ---- dQ^T += K^T dS^T
@@ -451,7 +494,7 @@ extern "C" {
 int gfe_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* nlse,
                       void* dq, void* dk, void* dv, void* qs_ws, void* ndelta_ws, int64_t B, int64_t H, int64_t n, int64_t dh,
                       int64_t in_batch, int64_t in_row, int64_t o_batch, int64_t o_row, int64_t g_batch, int64_t g_row,
-                      float scale, void* stream) {
+                      float scale, float p_drop, int64_t seed, void* stream) {
     GFE_REQUIRE(q && k && v && o && dout && nlse && dq && dk && dv && qs_ws && ndelta_ws, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && H > 0 && n > 0 && dh == AD && B * H <= 65535 && n <= (1 << 24), GFE_ERR_SHAPE);
     GFE_REQUIRE(in_row % 8 == 0 && in_batch % 8 == 0 && o_row % 8 == 0 && o_batch % 8 == 0 && g_row % 4 == 0 && g_batch % 4 == 0, GFE_ERR_SHAPE);
@@ -462,6 +505,9 @@ int gfe_attention_bwd(const void* q, const void* k, const void* v, const void* o
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.in_batch = in_batch; p.in_row = in_row; p.o_batch = o_batch; p.o_row = o_row; p.g_batch = g_batch; p.g_row = g_row;
     p.H = (int)H; p.n = (int)n; p.npad = (int)(ceil_div(n, RT) * RT); p.scale = scale;
+    GFE_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || n <= 65535), GFE_ERR_SHAPE);
+    p.drop_thr = attn_drop_threshold(p_drop); p.seed_lo = (uint32_t)(uint64_t)seed; p.seed_hi = (uint32_t)((uint64_t)seed >> 32);
+    p.inv_keep = 1.0f / (1.0f - p_drop);
     p.nblk = (int)ceil_div(n, BW * 32);
     const int64_t total = (int64_t)p.nblk * B * H, rows = B * H * p.npad;
     GFE_REQUIRE(total <= 0x7fffffff && rows <= 0x7fffffff, GFE_ERR_SHAPE);
@@ -469,13 +515,20 @@ int gfe_attention_bwd(const void* q, const void* k, const void* v, const void* o
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;                         // 66 KB of dynamic LDS for the dK/dV ring
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_KV * STAGE_KV);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING * STAGE_Q);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_KV * STAGE_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_KV * STAGE_KV);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * STAGE_Q);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING * STAGE_Q);
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)ceil_div(rows, 32)), dim3(256), 0, st, p, rows);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)total), dim3(BW * 64), RING_KV * STAGE_KV, st, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)total), dim3(BW * 64), RING * STAGE_Q, st, p);
+    if (p.drop_thr) {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3((unsigned)total), dim3(BW * 64), RING_KV * STAGE_KV, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)total), dim3(BW * 64), RING * STAGE_Q, st, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3((unsigned)total), dim3(BW * 64), RING_KV * STAGE_KV, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)total), dim3(BW * 64), RING * STAGE_Q, st, p);
+    }
     return gfe_launch_status();
 }
 

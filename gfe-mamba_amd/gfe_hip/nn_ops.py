@@ -476,10 +476,12 @@ def layernorm(x, gamma, beta, rows, length, out_dtype, in_map=None, out_map=None
     return out
 
 
-def attention_fwd(q, k, v, B, H, n, dh, scale, with_lse=False):
+def attention_fwd(q, k, v, B, H, n, dh, scale, with_lse=False, dropout_p=0.0, seed=0):
     """Flash-style attention for long sequences (gfe_attention_fwd): q/k/v (B*n, >= H*dh) bf16 views with a common layout
     (row strides allowed), dh == 64 -> (B*n, H*dh) bf16.  with_lse: also the (B, H, npad) f32 row statistic -(max + log2 sum) that
-    attention_bwd restarts from (gfe_attention_fwd_lse)."""
+    attention_bwd restarts from (gfe_attention_fwd_lse); with it, dropout_p / seed: dropout on the probabilities (vit_3d.py:56; the mask is a
+    hash of (seed, head, row, key) that attention_bwd regenerates from the same two numbers)."""
+    assert with_lse or dropout_p == 0.0
     assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
     o = torch.empty((B * n, H * dh), dtype=BF16, device=q.device)
     strides = (n * q.stride(0), q.stride(0), n * k.stride(0), k.stride(0), n * v.stride(0), v.stride(0), n * H * dh, H * dh)
@@ -487,11 +489,11 @@ def attention_fwd(q, k, v, B, H, n, dh, scale, with_lse=False):
         call("gfe_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), B, H, n, dh, *strides, float(scale), stream())
         return o
     nlse = torch.empty((B, H, -(-n // 64) * 64), dtype=torch.float32, device=q.device)
-    call("gfe_attention_fwd_lse", ptr(q), ptr(k), ptr(v), ptr(o), ptr(nlse), B, H, n, dh, *strides, float(scale), stream())
+    call("gfe_attention_fwd_lse", ptr(q), ptr(k), ptr(v), ptr(o), ptr(nlse), B, H, n, dh, *strides, float(scale), float(dropout_p), int(seed), stream())
     return o, nlse
 
 
-def attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, scale, dqkv=None):
+def attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, scale, dqkv=None, dropout_p=0.0, seed=0):
     """gfe_attention_bwd: gradients of attention_fwd(with_lse=True).  q/k/v: bf16 views with ONE common layout (slices of a (B*n, 3*H*dh)
     projection output), o/dout: (B*n, H*dh) bf16 -> (dq, dk, dv) bf16 views of one (B*n, 3*H*dh) buffer (`dqkv`, allocated if None): the
     layout the to_qkv weight-gradient GEMM consumes.  Deterministic (no atomics)."""
@@ -504,7 +506,7 @@ def attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, scale, dqkv=None):
     qs = torch.empty((B * H * npad, dh), dtype=BF16, device=q.device)
     ndelta = torch.empty((B * H * npad,), dtype=torch.float32, device=q.device)
     call("gfe_attention_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(nlse), ptr(dq), ptr(dk), ptr(dv), ptr(qs), ptr(ndelta),
-         B, H, n, dh, n * q.stride(0), q.stride(0), n * inner, inner, n * dqkv.stride(0), dqkv.stride(0), float(scale), stream())
+         B, H, n, dh, n * q.stride(0), q.stride(0), n * inner, inner, n * dqkv.stride(0), dqkv.stride(0), float(scale), float(dropout_p), int(seed), stream())
     return dq, dk, dv
 
 

@@ -159,7 +159,7 @@ class _QkvFlashAttnFn(torch.autograd.Function):
     matrix never exists in memory either way (the reference materialises it twice: `dots`, `attn`)."""
 
     @staticmethod
-    def forward(ctx, h, weight, heads, scale):
+    def forward(ctx, h, weight, heads, scale, p_drop):
         inner3, dim = weight.shape
         inner = inner3 // 3
         dh = inner // heads
@@ -170,20 +170,23 @@ class _QkvFlashAttnFn(torch.autograd.Function):
         w16 = _w16(weight)
         assert dh == 64 and dim % 8 == 0 and K._ex_ok(h2) and K._ex_ok(w16), "qkv_flash_attention: head dim 64, 16-byte aligned rows"
         qkv = K.gemm_ex(h2, False, w16, False, out_dtype=BF16)
-        o, nlse = K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, heads, T, dh, scale, with_lse=True)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0          # host-side draw from torch's CPU generator: no device sync
+        o, nlse = K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, heads, T, dh, scale, with_lse=True,
+                                  dropout_p=p_drop, seed=seed)
         ctx.save_for_backward(h2, qkv, o, nlse, weight)
-        ctx.meta = (B, T, heads, dh, float(scale), h.dtype, h.shape)
+        ctx.meta = (B, T, heads, dh, float(scale), h.dtype, h.shape, float(p_drop), seed)
         return o.view(B, T, inner)
 
     @staticmethod
     def backward(ctx, do):
         h2, qkv, o, nlse, weight = ctx.saved_tensors
-        B, T, heads, dh, scale, hdt, hs = ctx.meta
+        B, T, heads, dh, scale, hdt, hs, p_drop, seed = ctx.meta
         inner = heads * dh
         d16 = do.reshape(B * T, inner)
         d16 = d16.contiguous() if d16.dtype == BF16 else K.cast(d16.float(), BF16)
         dqkv = torch.empty_like(qkv)
-        K.attention_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, d16, nlse, B, heads, T, dh, scale, dqkv=dqkv)
+        K.attention_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, d16, nlse, B, heads, T, dh, scale, dqkv=dqkv,
+                        dropout_p=p_drop, seed=seed)
         dh_ = dw = None
         if ctx.needs_input_grad[0]:
             dh_ = K.gemm_ex(dqkv, False, _w16(weight), True).reshape(hs).to(hdt)          # dqkv (M, 3 inner) . W (3 inner, dim) read reduction-major
@@ -191,15 +194,15 @@ class _QkvFlashAttnFn(torch.autograd.Function):
             slot = _grad_slot(weight)
             dw = K.gemm_ex(dqkv, True, h2, True, accum_into=slot)                          # dqkv^T . h, both read reduction-major
             dw = None if slot is not None else dw.to(weight.dtype)
-        return dh_, dw, None, None
+        return dh_, dw, None, None, None
 
 
-def qkv_flash_attention(h, to_qkv_weight, heads, scale):
-    """h: (B, T, dim) f32|bf16 (the normed tokens) -> (B, T, heads*64) bf16 = rearrange(softmax(q k^T * scale) v) with q, k, v = chunks of
-    h @ to_qkv_weight^T (vit_3d.py:49-59, dropout p = 0), differentiable in h and the weight."""
+def qkv_flash_attention(h, to_qkv_weight, heads, scale, dropout_p=0.0):
+    """h: (B, T, dim) f32|bf16 (the normed tokens) -> (B, T, heads*64) bf16 = rearrange(dropout(softmax(q k^T * scale)) v) with q, k, v =
+    chunks of h @ to_qkv_weight^T (vit_3d.py:49-59), differentiable in h and the weight; dropout_p: the probabilities' dropout of :56."""
     if not h.is_cuda:
         raise RuntimeError("gfe_hip qkv_flash_attention needs CUDA/HIP tensors (no CPU fallback)")
-    return _QkvFlashAttnFn.apply(h, to_qkv_weight, heads, scale)
+    return _QkvFlashAttnFn.apply(h, to_qkv_weight, heads, scale, float(dropout_p))
 
 
 class _MidLinearFn(torch.autograd.Function):

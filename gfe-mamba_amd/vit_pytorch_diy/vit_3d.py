@@ -107,11 +107,11 @@ class ViT(nn.Module):
         for attn, ff in self.transformer.layers:                                                      # vit_3d.py:70-73
             h = layernorm_rows(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
             p_attn = attn.dropout.p if (attn.training and attn.dropout.training) else 0.0
-            if attn.dim_head == 64 and p_attn == 0.0:
-                o = qkv_flash_attention(h, attn.to_qkv.weight, attn.heads, attn.scale)
+            if attn.dim_head == 64:
+                o = qkv_flash_attention(h, attn.to_qkv.weight, attn.heads, attn.scale, dropout_p=p_attn)
             else:
                 if T > 64 or attn.dim_head > 64:
-                    raise NotImplementedError("vit_3d training: attention dropout > 0 or dim_head != 64 is built for <= 64 tokens only")
+                    raise NotImplementedError("vit_3d training: dim_head != 64 is built for <= 64 tokens only")
                 q, k, v = linear(h, attn.to_qkv.weight, None).chunk(3, dim=-1)
                 o = sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), attn.heads, causal=False, dropout_p=p_attn)
             x = drop(linear(o, attn.to_out[0].weight, attn.to_out[0].bias), attn.to_out[1]) + x

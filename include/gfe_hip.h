@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 39
+#define GFE_ABI_VERSION 40
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -283,19 +283,21 @@ int gfe_attention_fwd(const void* q, const void* k, const void* v, void* o, int6
                       int64_t o_batch, int64_t o_row, float scale, void* stream);
 
 /* Training forward of the same product: additionally writes the row statistic the backward restarts from,
- * nlse[b][h][row] = -(max + log2(sum)) in log2 units (f32, [B][H][npad], npad = n rounded up to 64; rows n .. npad-1 = -inf). */
+ * nlse[b][h][row] = -(max + log2(sum)) in log2 units (f32, [B][H][npad], npad = n rounded up to 64; rows n .. npad-1 = -inf).
+ * p_drop > 0: `attn = dropout(attn)` of vit_3d.py:56 on the probabilities (kept ones scaled by 1 / (1 - p)); the mask is a counter-based
+ * hash of (seed, batch*head, row, key) (csrc/attn_drop.h) that the backward regenerates; n <= 65535 then. */
 int gfe_attention_fwd_lse(const void* q, const void* k, const void* v, void* o, void* nlse, int64_t B, int64_t H, int64_t n, int64_t dh,
                           int64_t q_batch, int64_t q_row, int64_t k_batch, int64_t k_row, int64_t v_batch, int64_t v_row,
-                          int64_t o_batch, int64_t o_row, float scale, void* stream);
+                          int64_t o_batch, int64_t o_row, float scale, float p_drop, int64_t seed, void* stream);
 
-/* Backward of gfe_attention_fwd_lse (what autograd does for vit_pytorch_diy/vit_3d.py:47-57; dropout p = 0): bf16 dq / dk / dv from
+/* Backward of gfe_attention_fwd_lse (what autograd does for vit_pytorch_diy/vit_3d.py:47-57), same p_drop / seed: bf16 dq / dk / dv from
  * bf16 q / k / v / o / dout and the forward's nlse.  q/k/v share (in_batch, in_row), o/dout (o_batch, o_row), dq/dk/dv (g_batch, g_row)
  * (element strides; in/o multiples of 8, g of 4).  Deterministic: no atomics, one owner per output element.
  * Workspaces: qs_ws bf16 [B*H*npad*64], ndelta_ws f32 [B*H*npad].  dh == 64. */
 int gfe_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* nlse,
                       void* dq, void* dk, void* dv, void* qs_ws, void* ndelta_ws, int64_t B, int64_t H, int64_t n, int64_t dh,
                       int64_t in_batch, int64_t in_row, int64_t o_batch, int64_t o_row, int64_t g_batch, int64_t g_row,
-                      float scale, void* stream);
+                      float scale, float p_drop, int64_t seed, void* stream);
 
 /* from_patch_embedding's Linear over the token axis (vit.py:104-106): y[b][j][:] = sum_i W[j][i] x[b][i][:] + bias[j].
  * x: (B, nin, dim) f32|bf16, W: (nout, nin) f32, y: (B, nout, dim) bf16. */

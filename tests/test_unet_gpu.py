@@ -342,6 +342,55 @@ def test_flash_attention_backward_vs_autograd(B, H, n):
     assert max(errs) < 1.5e-2, errs
 
 
+def _attn_drop_keep(seed, B, H, n, p):
+    """csrc/attn_drop.h restated with numpy uint32 arithmetic: keep[b, h, q, key] of the flash kernels' dropout mask."""
+    def h32(sd, e):
+        x = (e ^ sd).astype(np.uint32)
+        x ^= x >> np.uint32(16); x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
+        x ^= x >> np.uint32(15); x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+    npad = -(-n // 64) * 64
+    lo, hi = np.uint32(seed & 0xffffffff), np.uint32((seed >> 32) & 0xffffffff)
+    bh = np.arange(B * H, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        sb = h32(hi, lo ^ (bh * np.uint32(0x9E3779B9)).astype(np.uint32))
+        e = (np.arange(n, dtype=np.uint32)[:, None] * np.uint32(npad) + np.arange(n, dtype=np.uint32)[None, :]).astype(np.uint32)
+        hv = h32(sb[:, None, None], e[None])
+    thr = np.uint32(min(int(p * 4294967296.0), 4294967295))
+    return torch.from_numpy((hv >= thr)).view(B, H, n, n)
+
+
+@pytest.mark.parametrize("B,H,n,p", [(2, 2, 300, 0.1), (1, 3, 65, 0.5), (1, 2, 513, 0.25)])
+def test_flash_attention_dropout_forward_and_backward(B, H, n, p):
+    """`attn = dropout(softmax(dots))` (vit_3d.py:55-57) inside the flash kernels: the mask is a counter-based hash of (seed, head, row, key)
+    regenerated in both backward kernels.  With the mask restated on the host (numpy), forward and gradients must match f64 autograd through
+    softmax -> mask / (1 - p) -> @ v on the same bf16 inputs; the keep rate must be 1 - p; another seed gives another mask; p = 0 is the plain kernel."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(7 * n)
+    dh, seed = 64, 0x1234567887654321 % (2 ** 62)
+    inner = H * dh
+    qkv = (torch.randn(B * n, 3 * inner, generator=g) * 1.2).to(BF).to(DEV)
+    dout = torch.randn(B * n, inner, generator=g).to(BF).to(DEV)
+    q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    o, nlse = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True, dropout_p=p, seed=seed)
+    o0, nlse0 = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True)
+    assert torch.equal(nlse, nlse0) and not torch.equal(o, o0)               # the row statistic is the undropped softmax's
+    o_b, _ = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True, dropout_p=p, seed=seed + 1)
+    assert not torch.equal(o, o_b)
+    keep = _attn_drop_keep(seed, B, H, n, p)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    qd, kd, vd = [t.double().view(B, n, H, dh).transpose(1, 2).requires_grad_() for t in qkv.cpu().chunk(3, dim=-1)]
+    pr = torch.softmax(qd @ kd.transpose(-1, -2) * dh ** -0.5, dim=-1) * keep.double() / (1 - p)
+    ref = (pr @ vd).transpose(1, 2).reshape(B * n, inner)
+    gq, gk, gv = torch.autograd.grad(ref, (qd, kd, vd), dout.double().cpu())
+    dq, dk, dv = K.attention_bwd(q, k, v, o, dout, nlse, B, H, n, dh, dh ** -0.5, dropout_p=p, seed=seed)
+    errs = [rel_err(o, ref)] + [rel_err(a, b.transpose(1, 2).reshape(B * n, inner)) for a, b in ((dq, gq), (dk, gk), (dv, gv))]
+    print("flash attention with dropout p=%.2f B=%d H=%d n=%d: keep rate %.4f, rel err o %.2e dq %.2e dk %.2e dv %.2e" % (p, B, H, n, rate, *errs))
+    assert max(errs) < 1.5e-2, errs
+
+
 @pytest.mark.parametrize("tag,kw", [("a", dict(image_size=16, image_patch_size=8, frames=16, frame_patch_size=8, channels=2)),
                                     ("b", dict(image_size=16, image_patch_size=4, frames=48, frame_patch_size=8, channels=1))])
 def test_vit3d_vs_reference_fixture(tag, kw):
@@ -414,6 +463,28 @@ def test_vit3d_training_vs_reference_autograd_fixture(tag, kw):
     m.zero_grad(set_to_none=True)
     F.cross_entropy(m(x), torch.from_numpy(fx["labels"]).to(DEV)).backward()
     assert torch.equal(g1, m.transformer.layers[0][0].to_qkv.weight.grad)
+
+
+def test_vit3d_training_with_dropout_runs_on_the_flash_kernels():
+    """vit_3d.ViT(dropout=0.1, emb_dropout=0.1).train(): the attention-probability dropout (vit_3d.py:56) is inside the flash kernels for any
+    token count (321 here: beyond the 64-token kernel), the other dropouts are F.dropout; two steps draw different masks, eval() is the
+    deterministic inference pipeline, gradients are finite and reach every parameter."""
+    import torch.nn.functional as F
+    from vit_pytorch_diy.vit_3d import ViT
+    torch.manual_seed(5)
+    m = ViT(num_classes=3, dim=128, depth=2, heads=2, dim_head=64, mlp_dim=256, pool="cls", dropout=0.1, emb_dropout=0.1,
+            image_size=32, image_patch_size=4, frames=40, frame_patch_size=8, channels=1).to(DEV).train()
+    x = torch.randn(2, 1, 40, 32, 32, device=DEV)
+    lab = torch.tensor([2, 0], device=DEV)
+    o1 = m(x)
+    F.cross_entropy(o1, lab).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    o2 = m(x)
+    assert not torch.equal(o1, o2)                                   # fresh masks
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x), m(x)
+    assert torch.equal(e1, e2) and (o1.detach() - e1).abs().max() < 1.0
 
 
 def test_generator_real_width_64_cubed_vs_oracle():
