@@ -64,7 +64,7 @@ def test_one_rank_rccl_group_graphed_pipelined_step_equals_the_plain_step(tmp_pa
     # and Adam turns a gradient element that is pure rounding noise (k_proj.bias: exactly zero in exact arithmetic) into a +-lr step of
     # either sign.  So: all but a sliver of the 21.8 M elements within 1e-6 (1 % of one step's movement), none further than the 5 steps
     # can carry two noise elements apart.
-    assert frac < 1e-3, frac
+    assert frac < 3e-3, frac                       # (0.9e-4 ... 2.8e-4 in six runs)
     assert dp.max().item() <= 5 * 2 * 1e-4 * 1.01
 
 
@@ -151,6 +151,6 @@ def test_world_size_2_update_from_summed_half_batch_gradients_equals_the_full_ba
         print("step %d: DP(2) vs full batch: gradient rel err %.2e, parameters: max |d| %.2e, %.2e of the elements beyond 1e-6" % (step, e_g, e_p, frac))
         assert e_g < 1e-5, e_g
         # Adam divides by sqrt(v): an element whose gradient is rounding noise moves by up to lr in either direction (see the test above)
-        assert frac < 1e-3 and e_p <= (step + 1) * 2 * 1e-4 * 1.01, (frac, e_p)
+        assert frac < 3e-3 and e_p <= (step + 1) * 2 * 1e-4 * 1.01, (frac, e_p)
         # keep rank 1's replica in step with rank 0's (every rank applies the same update)
         r1.opt.flat_p.copy_(r0.opt.flat_p); r1.opt.flat_p16.copy_(r0.opt.flat_p16)
