@@ -523,6 +523,14 @@ def main():
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # GFE_DIST_BACKEND=gloo: dry run of the N-rank code path on a box with fewer GPUs than ranks (ranks share devices round-robin; the
+    # gradient all-reduce is staged through host memory, gfe_hip.step.all_reduce_).  RCCL refuses two ranks on one device, so this is how
+    # `torchrun --nproc-per-node 2 bench.py --gpus 2` runs on a one-GPU box (tests/test_multirank_gpu.py).  Default and product path: nccl = RCCL.
+    backend = os.environ.get("GFE_DIST_BACKEND", "nccl").lower()
+    assert backend in ("nccl", "gloo"), backend
+    gloo = distributed and backend == "gloo"
+    if gloo:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if distributed:
         torch.set_num_threads(max(1, min(torch.get_num_threads(), (os.cpu_count() or 8) // max(world, 1))))    # N ranks share the host
@@ -530,7 +538,7 @@ def main():
         # NOT device_id=...: binding the group to the device at init (eager communicator) makes every kernel of the step slower on this
         # stack -- 10.9 -> 12.8-13.0 ms per step with a ONE-rank group and no collective at all (tools/dp_graph_probe.py: PROBE_PG_MODE=eager
         # vs lazy); with the communicator created lazily on the first collective the step time is unchanged.
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     n_gpus = world
     assert a.gpus == n_gpus or "WORLD_SIZE" in os.environ, "internal: --gpus N > 1 without WORLD_SIZE is started by maybe_self_launch()"
     # per-rank RNG stream for everything drawn on the device during the step (the GEGLU feed-forward's dropout mask,
@@ -582,12 +590,13 @@ def main():
         steps, warmup = a.steps or 40, a.warmup if a.warmup is not None else 10     # (a fresh box needs a few steps before clocks / page-ins settle)
         metric, unit, dtype = "MRI volumes/sec (%s bf16) classify_mamba fwd+bwd" % ("96^3" if a.volume == "96" else "160x160x96"), "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "x".join(map(str, vol)),
-               "parallelism": f"dp{n_gpus}", "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
+               "parallelism": f"dp{n_gpus}", "dist_backend": (backend if distributed else None), "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
                "pipeline": ("generator(batch k+1) || head(batch k), 2 streams" + (", head replayed from a HIP graph" if getattr(wl, "graph_head", False) else "")) if wl.pipeline else "none"}
 
     def barrier():
         if distributed:
-            dist.barrier(device_ids=[local])
+            from gfe_hip.step import barrier as _barrier
+            _barrier(local)
 
     for _ in range(warmup):
         wl.step()
@@ -604,10 +613,11 @@ def main():
     el = time.perf_counter() - t0
     per_rank = None
     if distributed:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        cdev = "cpu" if gloo else "cuda"
+        t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
-        own = torch.tensor([el_own / steps * 1e3], device="cuda", dtype=torch.float64)
+        own = torch.tensor([el_own / steps * 1e3], device=cdev, dtype=torch.float64)
         allr = [torch.zeros_like(own) for _ in range(world)]
         dist.all_gather(allr, own)
         per_rank = [round(v.item(), 4) for v in allr]       # a host-bound or straggling rank shows up here

@@ -2,14 +2,15 @@
 Same constructor arguments and state-dict keys (q_proj, k_proj, v_proj, out_proj / in_proj, out_proj).  The four
 q / out projections run on the exact-f32 MFMA GEMM; the K/V projections of the image condition (94 % of the trainable FLOPs) on the
 bf16 one, reading the bf16 condition buffers of gfe_hip.train_ops.Condition in both GEMM layouts so neither forward nor weight
-gradient re-casts or transposes the 28 MB condition; the one-query softmax attention between them is gfe_cross_attn_q1."""
-import math
+gradient re-casts or transposes the 28 MB condition; the one-query softmax attention between them is gfe_cross_attn_q1.
 
+No torch-math attention is left in these modules (round 4): SelfAttention runs on gfe_sdpa_small (sequences up to 64 tokens, head dim
+<= 64: the sizes of the classifier's token stream), CrossAttention on gfe_cross_attn_q1 (one query per sample = every call the
+reference makes, mamba_transformer.py:124-126); anything else raises instead of silently leaving the HIP path."""
 import torch
 from torch import nn
-from torch.nn import functional as F
 
-from gfe_hip.head_ops import cross_attn_q1
+from gfe_hip.head_ops import cross_attn_q1, sdpa_small
 from gfe_hip.train_ops import Condition, Linear, linear
 
 
@@ -22,14 +23,13 @@ class SelfAttention(nn.Module):
         self.d_head = d_embed // n_heads
 
     def forward(self, x, causal_mask=False):
+        """sd_cross_atten.py:18-37: softmax(q k^T / sqrt(d_head) [+ causal mask]) v per head, then out_proj."""
         b, s, d = x.shape
+        if s > 64 or self.d_head > 64:
+            raise NotImplementedError(f"SelfAttention on the HIP path covers <= 64 tokens and head dim <= 64 (gfe_sdpa_small); got {s} tokens, "
+                                      f"head dim {self.d_head}.  Long sequences with head dim 64: gfe_hip.train_ops.qkv_flash_attention.")
         q, k, v = self.in_proj(x).chunk(3, dim=-1)
-        q, k, v = [t.view(b, s, self.n_heads, self.d_head).transpose(1, 2) for t in (q, k, v)]
-        weight = q @ k.transpose(-1, -2)
-        if causal_mask:
-            weight = weight.masked_fill(torch.ones_like(weight, dtype=torch.bool).triu(1), -torch.inf)
-        weight = F.softmax(weight / math.sqrt(self.d_head), dim=-1)
-        return self.out_proj((weight @ v).transpose(1, 2).reshape(b, s, d))
+        return self.out_proj(sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), self.n_heads, causal=bool(causal_mask)))
 
 
 class CrossAttention(nn.Module):
@@ -52,11 +52,7 @@ class CrossAttention(nn.Module):
             v = linear(a16, self.v_proj.weight, self.v_proj.bias, x16=a16, xT16=aT16).view(b, y.keys, d)
         else:
             k, v = self.k_proj(y), self.v_proj(y)
-        if lq == 1 and q.is_cuda:
-            return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))          # the classify path: one query per sample, one kernel each way
-        q = q.view(b, -1, self.n_heads, self.d_head).transpose(1, 2)
-        k = k.view(b, -1, self.n_heads, self.d_head).transpose(1, 2)
-        v = v.view(b, -1, self.n_heads, self.d_head).transpose(1, 2)
-        weight = F.softmax((q @ k.transpose(-1, -2)) / math.sqrt(self.d_head), dim=-1)
-        out = (weight @ v).transpose(1, 2).contiguous().view(b, lq, d)
-        return self.out_proj(out)
+        if lq != 1:
+            raise NotImplementedError("CrossAttention on the HIP path takes ONE query per sample (gfe_cross_attn_q1: every call of the reference, "
+                                      f"mamba_transformer.py:124-126); got {lq} queries -- no torch-math fallback is kept")
+        return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))              # one kernel each way

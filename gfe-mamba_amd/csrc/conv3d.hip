@@ -896,6 +896,9 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     // with the ticket scheduler the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream
     const int nblk = (q.sched && NBLK == 256) ? NBLK - conv_reserved_cus() : NBLK;
     q.tiles_per_block = (int)ceil_div(tiles, nblk);
+    // multi-class work lists keep a tile's classes in ONE block: the GroupNorm partials of a tile have one slot, written by the block that
+    // finishes the tile's last class (a range that ended inside a tile made two blocks store to the same slot: ADVICE r03)
+    if (MC) q.tiles_per_block = (int)(ceil_div(q.tiles_per_block, p.ncls) * p.ncls);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1, OUT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }

@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256) void embed_tokens_fwd_kernel(const int64_t* __
     }
 }
 
-// gradients: one block per token slot t, threads over dim, loop over the batch (deterministic sums; atomics only for the embedding rows,
-// which different (b, j) may share)
+// gradients: one block per token slot t, threads over dim, loop over the batch in order: every sum has ONE owner thread and a fixed order.
+// The embedding rows of slot j (rows offset[j] .. offset[j+1]-1 of the table: each categorical column has its own range,
+// mamba_transformer.py:44-51) are touched by slot j's block only, and element d of each by thread d only, so the scatter is a plain
+// read-modify-write in batch order (round 3: f32 atomics).  Out-of-range indices are clamped as in the forward (torch raises instead).
 __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ x_cat,
                                                                const int64_t* __restrict__ offsets, const float* __restrict__ x_num,
                                                                float* __restrict__ d_emb, float* __restrict__ d_num_w, float* __restrict__ d_num_b,
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __re
             for (int b = 0; b < B; ++b) {
                 int64_t idx = x_cat[(size_t)b * ncat + j] + offsets[j];
                 idx = idx < 0 ? 0 : (idx >= ntok ? ntok - 1 : idx);
-                atomicAdd(d_emb + (size_t)idx * dim + d, dout[((size_t)b * L + t) * dim + d]);
+                d_emb[(size_t)idx * dim + d] += dout[((size_t)b * L + t) * dim + d];
             }
         } else if (t <= ncat + ncont) {
             const int j = t - 1 - ncat;
@@ -294,11 +296,33 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restric
     for (int d = threadIdx.x; d < dim; d += 256) y[(size_t)r * dim + d] = fmaf((xp[d] - mu) * rs, gamma[d], beta[d]);
     if (threadIdx.x == 0) { mean[r] = mu; rstd[r] = rs; }
 }
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum_rows dy * xhat, dbeta += sum_rows dy (f32 atomics: rows <= batch)
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum_rows dy * xhat, dbeta += sum_rows dy.
+// Blocks 0 .. rows-1 own a row each (dx); blocks rows .. rows + ceil(dim/64) - 1 own 64 COLUMNS each: their four waves split the rows,
+// fold through LDS in wave order and add to dgamma / dbeta with a plain read-modify-write -- one owner and one summation order per
+// element, no atomics (rows < LN_TALL_MIN_ROWS here; round 3 added every row's term with an f32 atomic).
 __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ dy, float* __restrict__ dx,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int dim) {
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int dim) {
     __shared__ float scratch[32];
+    __shared__ float colred[2][4][64];
+    if ((int)blockIdx.x >= rows) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int d = ((int)blockIdx.x - rows) * 64 + lane;
+        float ag = 0.f, ab = 0.f;
+        if (d < dim)
+            for (int r = wave; r < rows; r += 4) {
+                const float g = dy[(size_t)r * dim + d];
+                ag = fmaf(g, (x[(size_t)r * dim + d] - mean[r]) * rstd[r], ag);
+                ab += g;
+            }
+        colred[0][wave][lane] = ag; colred[1][wave][lane] = ab;
+        __syncthreads();
+        if (wave == 0 && d < dim) {
+            dgamma[d] += (colred[0][0][lane] + colred[0][1][lane]) + (colred[0][2][lane] + colred[0][3][lane]);
+            dbeta[d] += (colred[1][0][lane] + colred[1][1][lane]) + (colred[1][2][lane] + colred[1][3][lane]);
+        }
+        return;
+    }
     const int r = blockIdx.x;
     const float mu = mean[r], rs = rstd[r];
     const float* xp = x + (size_t)r * dim;
@@ -313,8 +337,6 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
     for (int d = threadIdx.x; d < dim; d += 256) {
         const float xh = (xp[d] - mu) * rs, g = gp[d] * gamma[d];
         dx[(size_t)r * dim + d] = rs * (g - s1 - xh * s2);
-        atomicAdd(dgamma + d, gp[d] * xh);
-        atomicAdd(dbeta + d, gp[d]);
     }
 }
 
@@ -468,10 +490,24 @@ __global__ __launch_bounds__(256) void ln_long_bwd_sums_kernel(const float* __re
     s2 = block_sum(s2, scratch + 16);
     if (threadIdx.x == 0) { part[((size_t)r * gridDim.x + sp) * 2] = s1; part[((size_t)r * gridDim.x + sp) * 2 + 1] = s2; }
 }
+// grid (splits, rows + 1): y < rows applies dx to one row segment; y == rows owns the segment's COLUMNS and sums dgamma / dbeta over all
+// rows in row order (one owner per element, no atomics; the rows are few here: B * patches)
 __global__ __launch_bounds__(256) void ln_long_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ dy, const float* __restrict__ part,
-                                                                float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int dim, int seg) {
+                                                                float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int dim, int seg) {
     const int r = blockIdx.y, sp = blockIdx.x, d0 = sp * seg, d1 = min(dim, d0 + seg);
+    if (r == rows) {
+        for (int d = d0 + threadIdx.x; d < d1; d += 256) {
+            float ag = 0.f, ab = 0.f;
+            for (int q = 0; q < rows; ++q) {
+                const float g = dy[(size_t)q * dim + d];
+                ag = fmaf(g, (x[(size_t)q * dim + d] - mean[q]) * rstd[q], ag);
+                ab += g;
+            }
+            dgamma[d] += ag; dbeta[d] += ab;
+        }
+        return;
+    }
     double a1 = 0.0, a2 = 0.0;
     for (int k = 0; k < (int)gridDim.x; ++k) { a1 += part[((size_t)r * gridDim.x + k) * 2]; a2 += part[((size_t)r * gridDim.x + k) * 2 + 1]; }
     const float s1 = (float)(a1 / dim), s2 = (float)(a2 / dim);
@@ -481,8 +517,6 @@ __global__ __launch_bounds__(256) void ln_long_bwd_apply_kernel(const float* __r
     for (int d = d0 + threadIdx.x; d < d1; d += 256) {
         const float xh = (xp[d] - mu) * rs, g = gp[d] * gamma[d];
         dx[(size_t)r * dim + d] = rs * (g - s1 - xh * s2);
-        atomicAdd(dgamma + d, gp[d] * xh);
-        atomicAdd(dbeta + d, gp[d]);
     }
 }
 constexpr int LN_LONG_DIM = 16384, LN_LONG_SEG = 4096, LN_LONG_MAX_SPLITS = 64;
@@ -638,7 +672,7 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
         int splits = (int)ceil_div(dim, (int64_t)LN_LONG_SEG); if (splits > LN_LONG_MAX_SPLITS) splits = LN_LONG_MAX_SPLITS;
         const int seg = (int)ceil_div(dim, (int64_t)splits);
         hipLaunchKernelGGL(ln_long_bwd_sums_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, (int)dim, seg);
-        hipLaunchKernelGGL(ln_long_bwd_apply_kernel, dim3((unsigned)splits, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, dx, dgamma, dbeta, (int)dim, seg);
+        hipLaunchKernelGGL(ln_long_bwd_apply_kernel, dim3((unsigned)splits, (unsigned)rows + 1), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, ws, dx, dgamma, dbeta, (int)rows, (int)dim, seg);
         return gfe_launch_status();
     }
     if (ws && rows >= LN_TALL_MIN_ROWS && dim <= LN_TALL_MAX_DIM && dim % 4 == 0 && rows <= 0x7fffffff) {
@@ -652,7 +686,8 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
         hipLaunchKernelGGL(ln_tall_bwd_reduce_kernel, dim3((unsigned)ceil_div(2 * dim, 64)), dim3(256), 0, st, ws, dgamma, dbeta, (int)dim, nblk);
         return gfe_launch_status();
     }
-    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, (int)dim);
+    GFE_REQUIRE(rows + ceil_div(dim, 64) <= 0x7fffffff, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)(rows + ceil_div(dim, 64))), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, (int)rows, (int)dim);
     return gfe_launch_status();
 }
 

@@ -20,19 +20,37 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     for (int c = lane; c < dim; c += 64) yr[c] = xr[c] * r * w[c];
 }
 
-// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd.  One row per wave at a time, RB rows per wave; a
-// lane owns columns lane + 64 i and keeps their weight-gradient partials in registers over its rows (a global atomic per row and
-// column is 296-way contended on 512 addresses: 23 us; LDS float atomics are not much better), then waves fold through LDS.
+// dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd.
+// Blocks 0 .. nrb-1: one row per wave at a time, RB rows per wave (dx).  Blocks nrb .. nrb + ceil(dim/64) - 1 own 64 COLUMNS of dw each:
+// their four waves split the rows, fold through LDS in wave order and add with a plain read-modify-write -- one owner and one summation
+// order per element (round 3: per-block partial rows added to dw with 37-way f32 atomics; round 1: one atomic per row and column, 23 us).
+// x and dy are read twice (1.2 MB at 296 x 512, L2-resident).
 constexpr int RMS_RB = 2;          // rows per wave
 constexpr int RMS_CV = 16;         // columns per lane kept in registers (dim <= 1024)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ rstd,
                                                           const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
-                                                          int rows, int dim) {
-    extern __shared__ float sdw[];                      // [4][dim]
+                                                          int rows, int dim, int nrb) {
+    __shared__ float colred[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float wv[RMS_CV], dwacc[RMS_CV];
+    if ((int)blockIdx.x >= nrb) {
+        const int c = ((int)blockIdx.x - nrb) * 64 + lane;
+        float a0 = 0.f, a1 = 0.f;
+        if (c < dim) {
+            int r = wave;
+            for (; r + 4 < rows; r += 8) {
+                a0 = fmaf(dy[(size_t)r * dim + c] * x[(size_t)r * dim + c], rstd[r], a0);
+                a1 = fmaf(dy[(size_t)(r + 4) * dim + c] * x[(size_t)(r + 4) * dim + c], rstd[r + 4], a1);
+            }
+            if (r < rows) a0 = fmaf(dy[(size_t)r * dim + c] * x[(size_t)r * dim + c], rstd[r], a0);
+        }
+        colred[wave][lane] = a0 + a1;
+        __syncthreads();
+        if (wave == 0 && c < dim) dw[c] += (colred[0][lane] + colred[1][lane]) + (colred[2][lane] + colred[3][lane]);
+        return;
+    }
+    float wv[RMS_CV];
 #pragma unroll
-    for (int i = 0; i < RMS_CV; ++i) { const int c = lane + 64 * i; wv[i] = c < dim ? w[c] : 0.f; dwacc[i] = 0.f; }
+    for (int i = 0; i < RMS_CV; ++i) { const int c = lane + 64 * i; wv[i] = c < dim ? w[c] : 0.f; }
     for (int k = 0; k < RMS_RB; ++k) {
         const int row = (blockIdx.x * 4 + wave) * RMS_RB + k;
         if (row >= rows) break;
@@ -54,13 +72,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         for (int i = 0; i < RMS_CV; ++i) {
             const int c = lane + 64 * i;
             if (c < dim) dxr[c] = r * (gv[i] * wv[i] - xv[i] * kk);
-            dwacc[i] = fmaf(gv[i] * xv[i], r, dwacc[i]);
         }
     }
-#pragma unroll
-    for (int i = 0; i < RMS_CV; ++i) { const int c = lane + 64 * i; if (c < dim) sdw[wave * dim + c] = dwacc[i]; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dw + c, sdw[c] + sdw[dim + c] + sdw[2 * dim + c] + sdw[3 * dim + c]);
 }
 
 // ---- depthwise causal conv1d (kernel KS, left padding KS-1) + bias + SiLU on (B, L, ED); lane = channel --------------------
@@ -82,11 +95,12 @@ __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const float* __res
 
 // backward: dpre = dy * silu'(pre); dx[t] = sum_k w[k] * dpre[t + (KS-1) - k]; dw[k] += dpre[t] * x[t + k - (KS-1)]; db += dpre.
 // Block = 64 channels of one sample; its 4 waves split the time steps: phase 1 writes dpre[t][channel] to LDS and keeps dw / db
-// partials, phase 2 forms dx from the LDS copy, then the partials are folded across the waves and added to dw / db (B-way atomics).
+// partials, phase 2 forms dx from the LDS copy, then the partials are folded across the waves (fixed order) and stored as the sample's
+// partial row part[b][k][e]; dwconv_fold_kernel adds the samples in order to dw / db (round 3: B-way f32 atomics).
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
-                                                              float* __restrict__ db, int L, int ED, int ldx, int lddx) {
+                                                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ partial,
+                                                              int L, int ED, int ldx, int lddx) {
     extern __shared__ float sp[];                       // [L + KS - 1][64] dpre (zero tail), then [4][KS + 1][64] partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane, b = blockIdx.y;
@@ -134,10 +148,20 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const float* __res
         for (int k = 0; k <= KS; ++k) {
             const float t = part[(0 * (KS + 1) + k) * 64 + lane] + part[(1 * (KS + 1) + k) * 64 + lane] +
                             part[(2 * (KS + 1) + k) * 64 + lane] + part[(3 * (KS + 1) + k) * 64 + lane];
-            if (k < KS) atomicAdd(dw + e * KS + k, t);
-            else if (db) atomicAdd(db + e, t);
+            partial[((size_t)b * (KS + 1) + k) * ED + e] = t;
         }
     }
+}
+// dw[e][k] += sum_b part[b][k][e] (k < KS), db[e] += sum_b part[b][KS][e]: samples in order, one owner per element
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, int B, int ED) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (KS + 1) * ED) return;
+    const int k = i / ED, e = i - k * ED;
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += partial[((size_t)b * (KS + 1) + k) * ED + e];
+    if (k < KS) dw[e * KS + k] += t;
+    else if (db) db[e] += t;
 }
 
 }  // namespace
@@ -212,13 +236,14 @@ int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64
     return gfe_launch_status();
 }
 
-int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_zeroed,
+int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_accum,
                     int64_t rows, int64_t dim, void* stream) {
-    GFE_REQUIRE(x && w && rstd && dy && dx && dw_zeroed, GFE_ERR_NULL);
-    GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
+    GFE_REQUIRE(x && w && rstd && dy && dx && dw_accum, GFE_ERR_NULL);
+    GFE_REQUIRE(rows > 0 && rows <= 0x3fffffff && dim > 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(dim <= 64 * RMS_CV, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)ceil_div(rows, 4 * RMS_RB)), dim3(256), (size_t)4 * dim * sizeof(float), (hipStream_t)stream,
-                       x, w, rstd, dy, dx, dw_zeroed, (int)rows, (int)dim);
+    const int nrb = (int)ceil_div(rows, 4 * RMS_RB);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)(nrb + ceil_div(dim, 64))), dim3(256), 0, (hipStream_t)stream,
+                       x, w, rstd, dy, dx, dw_accum, (int)rows, (int)dim, nrb);
     return gfe_launch_status();
 }
 
@@ -229,14 +254,15 @@ int gfe_dwconv1d_silu_fwd(const float* x, int64_t ldx, const float* w, const flo
     return gfe_launch_status();
 }
 
-int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_zeroed, float* db_zeroed,
-                          int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
-    GFE_REQUIRE(x && w && dy && dx && dw_zeroed, GFE_ERR_NULL);
+int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_accum, float* db_accum,
+                          float* ws, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream) {
+    GFE_REQUIRE(x && w && dy && dx && dw_accum && ws, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 65535 && L > 0 && ED > 0 && KS == 4 && ldx >= ED && lddx >= ED && ldx <= 0x7fffffff && lddx <= 0x7fffffff, GFE_ERR_SHAPE);
     const size_t rows = (size_t)L + 3 > 20 ? (size_t)L + 3 : 20;          // dpre rows, reused for the 4 x 5 partial rows
     GFE_REQUIRE(rows * 64 * sizeof(float) <= 64 * 1024, GFE_ERR_SHAPE);
     hipLaunchKernelGGL((dwconv_silu_bwd_kernel<4>), dim3((unsigned)ceil_div(ED, 64), (unsigned)B), dim3(256), rows * 64 * sizeof(float), (hipStream_t)stream,
-                       x, w, bias, dy, dx, dw_zeroed, db_zeroed, (int)L, (int)ED, (int)ldx, (int)lddx);
+                       x, w, bias, dy, dx, ws, (int)L, (int)ED, (int)ldx, (int)lddx);
+    hipLaunchKernelGGL((dwconv_fold_kernel<4>), dim3((unsigned)ceil_div(5 * ED, 256)), dim3(256), 0, (hipStream_t)stream, ws, dw_accum, db_accum, (int)B, (int)ED);
     return gfe_launch_status();
 }
 

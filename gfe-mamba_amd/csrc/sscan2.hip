@@ -418,6 +418,11 @@ struct S2Bwd {
     int B, L, ED, T, nchunks, softplus, nseg, bc_bf16;
     int ld_z, ld_bc, ld_dbc;            // row strides of z / dz, of the B / C rows, and of the dB / dC accumulation rows (see S2Fwd)
     int a_log;                          // A holds A_log: A = -exp(A_log), and dA_ws receives the gradient w.r.t. A_log (= dA * A)
+    // Deterministic accumulation (round 4): with these two workspaces nothing is added atomically.  Every block leaves its contributions as
+    // plain stores -- part_vec[b * nchunks + c][dA (ED x 16) | dD (ED) | dbias (ED)], part_bc[b][channel group][t][16 dB | 16 dC] -- and
+    // sscan2_fold_kernel sums them in a fixed order (samples / chunks in order for the vectors, channel groups in order for the rows).
+    // NULL: f32 atomics onto zeroed buffers (large L x B: the dB / dC partial rows would be 128 B per (group, b, t), 134 MB at config 2, B = 8).
+    float* part_vec; float* part_bc;
 };
 
 constexpr int RSL = TT * 32 + 8;   // slab stride: + 8 floats so that the four (channel & 3) slabs of one ds_write_b64 fall on disjoint banks
@@ -564,7 +569,10 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
             for (int i = 0; i < 4; ++i) {
                 const int v = lane + 64 * i, t2 = 8 * w + (v >> 5), j = v & 31;
                 const float sum = red[t2 * 32 + j];
-                if (tb + t2 < t1) atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * p.ld_dbc + (j & 15), sum);
+                if (tb + t2 < t1) {
+                    if (p.part_bc) p.part_bc[(((size_t)b * gridDim.x + blockIdx.x) * p.L + tb + t2) * 32 + j] = sum;
+                    else atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * p.ld_dbc + (j & 15), sum);
+                }
             }
         };
 
@@ -738,16 +746,47 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         return;
     }
     if (p.a_log) dAacc *= An;                                            // d/dA_log = dA * dA/dA_log = dA * A
-    atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr, dAacc.x);
-    atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr + 1, dAacc.y);
     // dD / dbias: the 8 owner lanes of a channel (pair bits 2, 3, 4) hold partial sums over their steps
     dDacc += __shfl_xor(dDacc, 4, 64); dbacc += __shfl_xor(dbacc, 4, 64);
     dDacc += __shfl_xor(dDacc, 8, 64); dbacc += __shfl_xor(dbacc, 8, 64);
     dDacc += __shfl_xor(dDacc, 16, 64); dbacc += __shfl_xor(dbacc, 16, 64);
+    if (p.part_vec) {                                                    // this (sample, chunk)'s row of partials: plain stores, summed in order later
+        float* pv = p.part_vec + ((size_t)b * p.nchunks + c) * ((size_t)p.ED * 18);
+        *reinterpret_cast<f2*>(pv + (size_t)e * 16 + 2 * pr) = dAacc;
+        if (pr == 0) { pv[(size_t)p.ED * 16 + e] = dDacc; pv[(size_t)p.ED * 17 + e] = dbacc; }
+        return;
+    }
+    atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr, dAacc.x);
+    atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr + 1, dAacc.y);
     if (pr == 0) {
         if (p.dDws) atomicAdd(p.dDws + e, dDacc);
         if (p.dbiasws) atomicAdd(p.dbiasws + e, dbacc);
     }
+}
+
+// Fixed-order sums of the backward's partials (S2Bwd::part_vec / part_bc).  Blocks [0, nb_vec): dA / dD / dbias += sum over the (sample,
+// chunk) rows in order (accumulating: the targets may be the optimizer's gradient slots); blocks [nb_vec, ...): dB / dC rows = sum over the
+// channel groups in order (plain store: the rows need no zero fill).
+__global__ __launch_bounds__(256) void sscan2_fold_kernel(const S2Bwd p, int nb_vec, int G) {
+    if ((int)blockIdx.x < nb_vec) {
+        const int i = blockIdx.x * 256 + threadIdx.x, n = p.ED * 18;
+        if (i >= n) return;
+        float s = 0.f;
+        const int rows = p.B * p.nchunks;
+        for (int k = 0; k < rows; ++k) s += p.part_vec[(size_t)k * n + i];
+        if (i < p.ED * 16) p.dAws[i] += s;
+        else if (i < p.ED * 17) { if (p.dDws) p.dDws[i - p.ED * 16] += s; }
+        else if (p.dbiasws) p.dbiasws[i - p.ED * 17] += s;
+        return;
+    }
+    const int64_t i = (int64_t)((int)blockIdx.x - nb_vec) * 256 + threadIdx.x;           // (b, t, j)
+    if (i >= (int64_t)p.B * p.L * 32) return;
+    const int j = (int)(i & 31);
+    const int64_t bt = i >> 5;
+    const int b = (int)(bt / p.L), t = (int)(bt - (int64_t)b * p.L);
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += p.part_bc[(((size_t)b * G + g) * p.L + t) * 32 + j];
+    (j < 16 ? p.dBws : p.dCws)[(size_t)bt * p.ld_dbc + (j & 15)] = s;
 }
 
 template <typename T>
@@ -755,6 +794,11 @@ int sscan2_bwd_launch(const S2Bwd& p, hipStream_t st) {
     const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
     if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_bwd_kernel<T, true>), grid, blk, 0, st, p);      // local adjoint carries of every chunk
     hipLaunchKernelGGL((sscan2_bwd_kernel<T, false>), grid, blk, 0, st, p);
+    if (p.part_vec) {
+        const int nb_vec = (int)ceil_div((int64_t)p.ED * 18, 256);
+        const int64_t nb_bc = ceil_div((int64_t)p.B * p.L * 32, 256);
+        hipLaunchKernelGGL(sscan2_fold_kernel, dim3((unsigned)(nb_vec + nb_bc)), dim3(256), 0, st, p, nb_vec, p.ED / CB);
+    }
     return gfe_launch_status();
 }
 
@@ -810,7 +854,7 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void*
                    const float* D, const void* z, const float* delta_bias, const void* dy, const void* yscan,
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
-                   const float* ckpt, float* qstate, const float* sdelta,
+                   const float* ckpt, float* qstate, const float* sdelta, float* part_vec, float* part_bc,
                    int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
                    int64_t ld_z, int64_t ld_bc, int64_t ld_dbc, int a_is_log, void* stream) {
     GFE_REQUIRE(bc_dtype == GFE_F32 || bc_dtype == GFE_BF16, GFE_ERR_DTYPE);
@@ -820,8 +864,11 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void*
     GFE_REQUIRE(ld_z >= ED && ld_z % 4 == 0 && ld_bc >= 16 && ld_bc % 4 == 0 && ld_dbc >= 16 && ld_z <= 0x7fffffff && ld_bc <= 0x7fffffff && ld_dbc <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(u && delta && A && Bm && Cm && dy && du && ddelta && dA_ws && dB_ws && dC_ws && ckpt, GFE_ERR_NULL);
     GFE_REQUIRE(!z || (dz && yscan), GFE_ERR_NULL);
+    GFE_REQUIRE((part_vec == nullptr) == (part_bc == nullptr), GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
+    GFE_REQUIRE(!part_vec || (B * L * 32 <= 0x7fffffff * (int64_t)256 && ED * 18 <= 0x7fffffff), GFE_ERR_SHAPE);
     S2Bwd p;
+    p.part_vec = part_vec; p.part_bc = part_bc;
     p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.dy = dy; p.yscan = yscan; p.A = A; p.D = D; p.dbias = delta_bias;
     p.du = du; p.ddelta = ddelta; p.dz = dz; p.dAws = dA_ws; p.dBws = dB_ws; p.dCws = dC_ws; p.dDws = dD_ws; p.dbiasws = dbias_ws;
     p.ckpt = ckpt; p.qstate = qstate; p.sdelta = sdelta;

@@ -12,10 +12,12 @@ namespace {
 // ---- head Linear forward: out[b][src*C + c][s] += sum_{hw in chunk} mid_src[b][hw][c] * W[s][hw] --------------------
 // A skinny reduction over hw (13 824 rows of 512 B per (sample, tensor)): HBM-bound.  grid (chunks, 2*B), blockIdx.y = b*2 + src.
 // Thread = (row slot, 16-byte channel chunk): every lane streams; 4 rows in flight per thread; Wt is W transposed to (HW, S) so a
-// row's S weights are one float4.  The block's row slots are folded through LDS, one f32 atomic per (channel, s) and block.
+// row's S weights are one float4.  The block's row slots are folded through LDS into ONE partial slab per block (part[chunk][b][src][c][s]);
+// mid_linear_fold_kernel sums the chunks in a fixed order and adds the bias: no atomics, the head's first activation is run-to-run
+// identical (round 3: one f32 atomic per (channel, s) and block onto a zeroed output).
 template <int S>
 __global__ __launch_bounds__(256) void mid_linear_fwd_kernel(const bf16_t* __restrict__ mid_in, const bf16_t* __restrict__ mid_out,
-                                                             const float* __restrict__ Wt, float* __restrict__ out,
+                                                             const float* __restrict__ Wt, float* __restrict__ part,
                                                              int HW, int C, int rows_per_block) {
     static_assert(S == 4, "a row's weights are read as one float4");
     extern __shared__ float red[];                       // [row slots][S][C]
@@ -60,8 +62,17 @@ __global__ __launch_bounds__(256) void mid_linear_fwd_kernel(const bf16_t* __res
         const int s = i / C, c = i - s * C;
         float t = 0.f;
         for (int k = 0; k < RPP; ++k) t += red[(k * S + s) * C + c];
-        atomicAdd(out + ((size_t)b * 2 * C + src * C + c) * S + s, t);
+        part[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * C * S + (size_t)c * S + s] = t;
     }
+}
+// out[b][src*C + c][s] = bias[s] + sum_chunks part[chunk][b*2 + src][c][s]   (fixed order)
+__global__ __launch_bounds__(256) void mid_linear_fold_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                              int nchunks, int64_t n, int S) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = 0.f;
+    for (int k = 0; k < nchunks; ++k) t += part[(size_t)k * n + i];
+    out[i] = t + (bias ? bias[i % S] : 0.f);
 }
 
 // ---- head Linear weight gradient: dW[s][hw] = sum_{b,src,c} dout[b][src*C+c][s] * mid_src[b][hw][c] -------------------
@@ -126,7 +137,11 @@ __global__ __launch_bounds__(256) void mid_linear_wgrad_kernel(const bf16_t* __r
 // chunk table (host-built, device-resident): {offset, length, tensor id} with chunks never crossing a tensor boundary.
 struct Chunk { int64_t off; int len; int tid; };
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, const Chunk* __restrict__ chunks, float* __restrict__ norm2, float gscale) {
+// Squared norms WITHOUT atomics (round 4): the clip factor of a tensor must come out bit-identical on every rank and in every run --
+// replicas that clip by factors one ulp apart drift apart (tests/test_multirank_gpu.py compares two ranks' parameters with torch.equal).
+// Pass 1 leaves one partial per chunk; pass 2 (one block per tensor) finds the tensor's chunk range in the table (chunks are sorted by
+// tensor id) and sums its partials in a fixed order.
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, const Chunk* __restrict__ chunks, float* __restrict__ part, float gscale) {
     __shared__ float red[16];
     const Chunk ck = chunks[blockIdx.x];
     float s = 0.f;
@@ -139,7 +154,21 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     }
     for (int i = 4 * n4 + threadIdx.x; i < ck.len; i += 256) { const float v = g[ck.off + i] * gscale; s = fmaf(v, v, s); }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(norm2 + ck.tid, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__device__ __forceinline__ int chunk_lower_bound(const Chunk* __restrict__ chunks, int n, int tid) {     // first chunk with .tid >= tid
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (chunks[mid].tid < tid) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void sqnorm_fold_kernel(const Chunk* __restrict__ chunks, int nchunks, const float* __restrict__ part, float* __restrict__ norm2) {
+    __shared__ float red[16];
+    const int tid = blockIdx.x;
+    const int c0 = chunk_lower_bound(chunks, nchunks, tid), c1 = chunk_lower_bound(chunks, nchunks, tid + 1);
+    float s = 0.f;
+    for (int i = c0 + threadIdx.x; i < c1; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) norm2[tid] = s;
 }
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -236,8 +265,10 @@ extern "C" {
 int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream) {
     GFE_REQUIRE(x && out, GFE_ERR_NULL);
     GFE_REQUIRE(M > 0 && N > 0 && M <= 0x7fffffff && N <= 0x7fffffff, GFE_ERR_SHAPE);
-    // the column blocks alone are ceil(N/64): split the rows too until the launch has a few hundred blocks
-    int64_t rblocks = ceil_div((int64_t)256, ceil_div(N, 64));
+    // the column blocks alone are ceil(N/64): tall inputs (the 3-D ViT's 13 832 token rows) split the rows too until the launch has a few
+    // hundred blocks, and then add with f32 atomics; up to 4 096 rows (every bias gradient of the classifier head: 8 ... 296 rows) ONE
+    // block owns a column and sums its rows in a fixed order -- the trainable half of the step is run-to-run identical (round 4)
+    int64_t rblocks = M <= 4096 ? 1 : ceil_div((int64_t)256, ceil_div(N, 64));
     if (rblocks > ceil_div(M, 32)) rblocks = ceil_div(M, 32);
     if (rblocks < 1) rblocks = 1;
     const int rpb = (int)ceil_div(M, rblocks);
@@ -248,19 +279,36 @@ int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld,
     return gfe_launch_status();
 }
 
-int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt, float* out_zeroed,
+static void mid_linear_geometry(int64_t B, int64_t HW, int* rpb, int64_t* chunks) {
+    // ~512 blocks: enough to stream at HBM rate
+    int64_t want = ceil_div((int64_t)512, 2 * B);
+    int r = (int)ceil_div(HW, want);
+    if (r < 32) r = 32;
+    *rpb = r;
+    *chunks = ceil_div(HW, r);
+}
+int gfe_mid_linear_plan(int64_t B, int64_t HW, int* nchunks) {
+    GFE_REQUIRE(nchunks, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && HW > 0, GFE_ERR_SHAPE);
+    int rpb; int64_t chunks;
+    mid_linear_geometry(B, HW, &rpb, &chunks);
+    *nchunks = (int)chunks;
+    return GFE_OK;
+}
+int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt, const float* bias, float* out, float* ws,
                        int64_t B, int64_t HW, int64_t C, int64_t S, void* stream) {
-    GFE_REQUIRE(mid_in && mid_out && Wt && out_zeroed, GFE_ERR_NULL);
+    GFE_REQUIRE(mid_in && mid_out && Wt && out && ws, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 32767 && HW > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && 256 % (C / 8) == 0 && S == 4, GFE_ERR_SHAPE);
-    // ~512 blocks: enough to stream at HBM rate, few enough that the atomics stay 32-way
-    int64_t chunks = ceil_div((int64_t)512, 2 * B);
-    int rpb = (int)ceil_div(HW, chunks);
-    if (rpb < 32) rpb = 32;
-    const dim3 grid((unsigned)ceil_div(HW, rpb), (unsigned)(2 * B));
+    int rpb; int64_t chunks;
+    mid_linear_geometry(B, HW, &rpb, &chunks);
+    const dim3 grid((unsigned)chunks, (unsigned)(2 * B));
     const size_t lds = (size_t)(256 / (C / 8)) * S * C * sizeof(float);
     GFE_REQUIRE(lds <= 64 * 1024, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL((mid_linear_fwd_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)mid_in, (const bf16_t*)mid_out, Wt, out_zeroed, (int)HW, (int)C, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((mid_linear_fwd_kernel<4>), grid, dim3(256), lds, st,
+                       (const bf16_t*)mid_in, (const bf16_t*)mid_out, Wt, ws, (int)HW, (int)C, rpb);
+    const int64_t n = 2 * B * C * S;
+    hipLaunchKernelGGL(mid_linear_fold_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, ws, bias, out, (int)chunks, n, (int)S);
     return gfe_launch_status();
 }
 
@@ -280,18 +328,20 @@ int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* d
 }
 
 int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
-                  float* norm2_zeroed, float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps,
+                  float* norm2, int64_t ntensors, float* partials, float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps,
                   int64_t step, void* stream) {
-    GFE_REQUIRE(p && g && m && v && chunks && norm2_zeroed, GFE_ERR_NULL);
-    GFE_REQUIRE(nchunks > 0 && nchunks <= 0x7fffffff && step >= 1, GFE_ERR_SHAPE);
+    GFE_REQUIRE(p && g && m && v && chunks && norm2 && partials, GFE_ERR_NULL);
+    GFE_REQUIRE(nchunks > 0 && nchunks <= 0x7fffffff && ntensors > 0 && ntensors <= nchunks && step >= 1, GFE_ERR_SHAPE);
     // bias corrections as torch.optim.Adam computes them (Python doubles): 1 - 0.999^t in f32 loses ~1e-5 relative to cancellation
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipStream_t st = (hipStream_t)stream;
     // max_norm = +inf (plain Adam, the generator's optimizer): the clip coefficient is 1 for every tensor, whatever the norms (zeros here)
-    if (max_norm < 3.0e38f)
-        hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const Chunk*)chunks, norm2_zeroed, grad_scale);
+    if (max_norm < 3.0e38f) {
+        hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const Chunk*)chunks, partials, grad_scale);
+        hipLaunchKernelGGL(sqnorm_fold_kernel, dim3((unsigned)ntensors), dim3(256), 0, st, (const Chunk*)chunks, (int)nchunks, partials, norm2);
+    }
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_bf16, (const Chunk*)chunks,
-                       norm2_zeroed, grad_scale, max_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)eps, (float)(1.0 / sqrt(bc2)));
+                       norm2, grad_scale, max_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)eps, (float)(1.0 / sqrt(bc2)));
     return gfe_launch_status();
 }
 

@@ -10,7 +10,7 @@ import torch
 
 from . import call, dtype_code, ptr, stream
 from . import nn_ops as K
-from .scan_ops import sscan2_plan
+from .scan_ops import sscan2_det_ws, sscan2_plan
 from .train_ops import _grad_slot
 
 F32 = torch.float32
@@ -96,7 +96,9 @@ class _MambaBlockFn(torch.autograd.Function):
         g_out = wgrad(out_w, d2, y)
         # scan: dz / dB / dC land in the gradients of the projection outputs they were read from
         dxz = torch.empty((Bsz * L, 2 * ED), dtype=F32, device=dev)                    # [d xs | d z]
-        ddbc = torch.zeros((Bsz * L, W), dtype=F32, device=dev)                        # [d delta_r | dB | dC] (dB / dC: f32 atomics)
+        pvec, pbc = sscan2_det_ws(Bsz, L, ED, nc, dev)                                 # fixed-order partial sums (no atomics) at the head's sizes
+        # [d delta_r | dB | dC]: with the partial workspaces the scan's fold launch overwrites the dB / dC columns (no zero fill); else f32 atomics
+        ddbc = (torch.empty if pbc is not None else torch.zeros)((Bsz * L, W), dtype=F32, device=dev)
         du = torch.empty((Bsz * L, ED), dtype=F32, device=dev)
         dd = torch.empty((Bsz * L, ED), dtype=F32, device=dev)
         (dA_t, g_A), (dD_t, g_D), (db_t, g_dtb) = vec_slot(A_log, ED * N), vec_slot(D, ED), vec_slot(dt_b, ED)
@@ -104,7 +106,7 @@ class _MambaBlockFn(torch.autograd.Function):
         fcode = dtype_code(F32)
         call("gfe_sscan2_bwd", ptr(xc), ptr(delta), ptr(det(A_log)), ptr(dbc) + 4 * R, ptr(dbc) + 4 * (R + N), ptr(det(D)), ptr(xz) + 4 * ED,
              ptr(det(dt_b)), ptr(dy), ptr(yscan), ptr(du), ptr(dd), ptr(dxz) + 4 * ED, ptr(dA_t), ptr(ddbc) + 4 * R, ptr(ddbc) + 4 * (R + N),
-             ptr(dD_t), ptr(db_t), ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, 1, fcode, fcode, 2 * ED, W, W, 1, stream())
+             ptr(dD_t), ptr(db_t), ptr(ckpt), ptr(qstate), ptr(sdelta), ptr(pvec), ptr(pbc), Bsz, L, ED, T, 1, fcode, fcode, 2 * ED, W, W, 1, stream())
         # dt_proj (no bias here: it lives inside the scan)
         _gemm_into(dd, False, det(dt_w), True, ddbc[:, :R])                            # d delta_r = d delta . W_dt
         g_dtw = wgrad(dt_w, dd, dbc[:, :R])
@@ -115,7 +117,8 @@ class _MambaBlockFn(torch.autograd.Function):
         sw, sb = _grad_slot(conv_w), _grad_slot(conv_b)
         dcw = sw if sw is not None else torch.zeros_like(conv_w, dtype=F32)
         dcb = sb if sb is not None else torch.zeros_like(conv_b, dtype=F32)
-        call("gfe_dwconv1d_silu_bwd", ptr(xz), 2 * ED, ptr(det(conv_w)), ptr(det(conv_b)), ptr(du), ptr(dxz), 2 * ED, ptr(dcw), ptr(dcb),
+        cws = torch.empty(Bsz * 5 * ED, dtype=F32, device=dev)                          # per-sample partial rows of dw / db
+        call("gfe_dwconv1d_silu_bwd", ptr(xz), 2 * ED, ptr(det(conv_w)), ptr(det(conv_b)), ptr(du), ptr(dxz), 2 * ED, ptr(dcw), ptr(dcb), ptr(cws),
              Bsz, L, ED, 4, stream())
         # in_proj
         dx = K.gemm_f32(dxz, False, det(in_w), True).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None

@@ -37,6 +37,22 @@ def sscan2_plan(B, L, ED, chunk=0):
     return T.value, nc.value
 
 
+DET_PART_BC_MAX_BYTES = 4 << 20
+
+
+def sscan2_det_ws(Bsz, L, ED, nc, dev):
+    """Workspaces of gfe_sscan2_bwd's atomics-free accumulation (include/gfe_hip.h), or (None, None): the dB / dC partial rows cost 128 B per
+    (32-channel group, b, t), so the fixed-order path is the default up to 4 MB of them (the classifier head: 37 tokens, 1.2 MB at 8
+    samples -> its gradients are run-to-run identical) and f32 atomics stay the default at benchmark sizes (L = 4096: 16.8 MB per sample).
+    GFE_SCAN_DETERMINISTIC=1 / =0 forces either."""
+    nbc = Bsz * (ED // 32) * L * 32
+    env = os.environ.get("GFE_SCAN_DETERMINISTIC")
+    if env == "0" or (env != "1" and 4 * nbc > DET_PART_BC_MAX_BYTES):
+        return None, None
+    ws = torch.empty(Bsz * nc * ED * 18 + nbc, device=dev, dtype=torch.float32)
+    return ws[:Bsz * nc * ED * 18], ws[Bsz * nc * ED * 18:]
+
+
 def _al16(t):
     """The single-pass kernels move rows as 8/16-byte vectors: a contiguous view at an odd storage offset is copied once."""
     return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
@@ -85,14 +101,15 @@ class _SelectiveScan2(torch.autograd.Function):
         du = torch.empty_like(u_)
         dd = torch.empty_like(u_)
         dz = torch.empty_like(u_) if z_ is not None else None
-        sizes = [ED * 16, Bsz * L * 16, Bsz * L * 16, ED, ED]                   # one zeroed f32 slab for every atomically accumulated gradient
+        sizes = [ED * 16, Bsz * L * 16, Bsz * L * 16, ED, ED]                   # one zeroed f32 slab for every accumulated gradient
         slab = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
         dA_ws, dB_ws, dC_ws, dD_ws, db_ws = torch.split(slab, sizes)
         qstate = torch.empty((Bsz, nc, ED, 16), device=dev, dtype=torch.float32) if nc > 1 else None
+        pvec, pbc = sscan2_det_ws(Bsz, L, ED, nc, dev)                          # fixed-order sums instead of atomics where that is cheap
         call("gfe_sscan2_bwd", ptr(u_), ptr(d_), ptr(A_), ptr(B_), ptr(C_), ptr(D_), ptr(z_), ptr(b_), ptr(dy_), ptr(yscan),
              ptr(du), ptr(dd), ptr(dz), ptr(dA_ws), ptr(dB_ws), ptr(dC_ws),
              ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
-             ptr(ckpt), ptr(qstate), ptr(sdelta), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), 0, 0, 0, 0, stream())
+             ptr(ckpt), ptr(qstate), ptr(sdelta), ptr(pvec), ptr(pbc), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), 0, 0, 0, 0, stream())
         to = lambda g, i: None if in_dtypes[i] is None else g.to(in_dtypes[i])
         return (to(du, 0), to(dd, 1), to(dA_ws.view(ED, 16), 2), to(dB_ws.view(Bsz, L, 16), 3), to(dC_ws.view(Bsz, L, 16), 4),
                 to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,

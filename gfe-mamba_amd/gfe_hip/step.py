@@ -27,13 +27,45 @@ def shard_batch(tensors, rank, world_size):
     return out
 
 
-def allreduce_grads_(flat_grad, world_size, group=None, force=False):
-    """The step's only collective: SUM all-reduce of the flat gradient buffer (RCCL on GPUs, gloo in the CPU tests).
-    Returns the scale the optimiser must apply (folded into the clip/Adam kernel instead of a separate pass).
-    `force`: issue the collective for a ONE-rank group too (the identity; lets a one-GPU box run the multi-rank code path)."""
+def _is_gloo(group=None):
     import torch.distributed as dist
+    return dist.is_initialized() and str(dist.get_backend(group)).lower() == "gloo"
+
+
+def all_reduce_(t, op=None, group=None):
+    """dist.all_reduce on the backend the process group was created with.  RCCL (backend "nccl") is the product path.  `gloo` exists so that a
+    ONE-GPU box can run the N-rank code path with N processes sharing the device (RCCL refuses two ranks on one device): there a device
+    tensor is staged through pinned host memory -- stream-ordered copy out, host all-reduce, copy back -- a test / dry-run transport
+    (GFE_DIST_BACKEND=gloo in bench.py, tests/test_multirank_gpu.py), never chosen by itself."""
+    import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and _is_gloo(group):
+        h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h, non_blocking=True)
+        torch.cuda.current_stream().synchronize()          # (h is freed on return)
+        return t
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def barrier(local_device=0, group=None):
+    """dist.barrier; RCCL wants the device it should use (no eagerly bound communicator), gloo takes none."""
+    import torch.distributed as dist
+    if _is_gloo(group):
+        dist.barrier(group=group)
+    else:
+        dist.barrier(group=group, device_ids=[local_device])
+
+
+def allreduce_grads_(flat_grad, world_size, group=None, force=False):
+    """The step's only collective: SUM all-reduce of the flat gradient buffer (RCCL on GPUs; gloo in the CPU tests and in the
+    two-processes-on-one-GPU dry run).  Returns the scale the optimiser must apply (folded into the clip/Adam kernel instead of a
+    separate pass).  `force`: issue the collective for a ONE-rank group too (the identity; lets a one-GPU box run the multi-rank code path)."""
     if world_size > 1 or force:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_(flat_grad, group=group)
     return dp_mean_scale(world_size)
 
 

@@ -94,7 +94,10 @@ class StepWorkload:
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                 "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r03", "traffic_r03.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if (self.batch == 8 and self.vol_tag == "96^3") else None,
                 "traffic_source": "profiles/r03/traffic_r03.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
-                "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @%s, ReLU)" % self.vol_tag, "launch_ms": round(ms, 4), "launches_timed": iters,
+                "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @%s, ReLU): the launch the step makes three times per "
+                          "forward (encoders.0 conv3, decoders.1 conv2 / conv3), timed alone on operands built from encoders.0's lifted tensor and "
+                          "conv2 weights -- the step itself collapses encoders.0 conv2 to a one-channel conv (DESIGN 4.1)" % self.vol_tag,
+                "launch_ms": round(ms, 4), "launches_timed": iters,
                 "algorithmic_flops": flops}
 
     def cpu_baseline(self):
@@ -119,24 +122,29 @@ class StepWorkload:
 
     def allreduce_stats(self, local=0, iters=10):
         """The step's only collective, timed alone on every rank (max over ranks): SUM all-reduce of the flat f32 gradient buffer.
-        bus GB/s = 2 (N-1)/N x bytes / time (the ring all-reduce's per-link traffic)."""
+        bus GB/s = 2 (N-1)/N x bytes / time (the ring all-reduce's per-link traffic).  Under the gloo dry-run transport
+        (GFE_DIST_BACKEND=gloo: N processes on one GPU) the figure is that of the host-staged stand-in, and says so."""
         import torch.distributed as dist
+        from .step import _is_gloo, all_reduce_, barrier
         g = self.step_obj.opt.flat_g
+        gloo = _is_gloo()
+        iters = 3 if gloo else iters
         for _ in range(2):
-            dist.all_reduce(g)
+            all_reduce_(g)
         torch.cuda.synchronize()
-        dist.barrier(device_ids=[local])
+        barrier(local)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            dist.all_reduce(g)
+            all_reduce_(g)
         torch.cuda.synchronize()
-        dt = torch.tensor([(time.perf_counter() - t0) / iters], device="cuda", dtype=torch.float64)
+        dt = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         g.zero_()
         n, nbytes = self.world, g.numel() * 4
         return {"bytes": nbytes, "ms": round(dt.item() * 1e3, 4), "algbw_GBs": round(nbytes / dt.item() / 1e9, 1),
-                "busbw_GBs": round(2 * (n - 1) / n * nbytes / dt.item() / 1e9, 1), "ranks": n, "collective": "all_reduce(SUM) of the flat f32 gradient buffer, RCCL"}
+                "busbw_GBs": round(2 * (n - 1) / n * nbytes / dt.item() / 1e9, 1), "ranks": n,
+                "collective": "all_reduce(SUM) of the flat f32 gradient buffer, " + ("gloo through pinned host memory (dry-run transport, not RCCL)" if gloo else "RCCL")}
 
     def extra(self):
         if self.vol_tag != "96^3":         # conv FLOPs scale with the voxel count; the ViT / head GEMMs with d_cross and the patch size (not tabulated)

@@ -210,12 +210,17 @@ class _MidLinearFn(torch.autograd.Function):
     def forward(ctx, mid_in, mid_out, weight, bias):
         B, H, W, C = mid_in.shape
         S = weight.shape[0]
-        out = torch.zeros((B, 2 * C, S), dtype=torch.float32, device=mid_in.device)
+        out = torch.empty((B, 2 * C, S), dtype=torch.float32, device=mid_in.device)
         wt = weight.detach().float().t().contiguous()          # (HW, S): one 16-byte load per row in the kernel
-        call("gfe_mid_linear_fwd", ptr(mid_in), ptr(mid_out), ptr(wt), ptr(out), B, H * W, C, S, stream())
+        import ctypes
+        nch = ctypes.c_int(0)
+        call("gfe_mid_linear_plan", B, H * W, ctypes.byref(nch))
+        ws = torch.empty(nch.value * out.numel(), dtype=torch.float32, device=mid_in.device)     # one partial slab per block of rows
+        call("gfe_mid_linear_fwd", ptr(mid_in), ptr(mid_out), ptr(wt), ptr(bias.detach().float().contiguous()), ptr(out), ptr(ws),
+             B, H * W, C, S, stream())
         ctx.save_for_backward(mid_in, mid_out)
         ctx.S = S
-        return out + bias.detach().float()
+        return out
 
     @staticmethod
     def backward(ctx, dout):
@@ -283,7 +288,8 @@ class _DwConvSiluFn(torch.autograd.Function):
         sw, sb = _grad_slot(ctx.w_ref), (None if b_ is None else _grad_slot(ctx.b_ref))
         dw = sw if sw is not None else torch.zeros_like(w_)
         db = None if b_ is None else (sb if sb is not None else torch.zeros_like(b_))
-        call("gfe_dwconv1d_silu_bwd", ptr(x_), ED, ptr(w_), ptr(b_), ptr(d), ptr(dx), ED, ptr(dw), ptr(db), B, L, ED, w_.shape[-1], stream())
+        ws = torch.empty(B * 5 * ED, dtype=torch.float32, device=d.device)          # per-sample partial rows (summed in sample order)
+        call("gfe_dwconv1d_silu_bwd", ptr(x_), ED, ptr(w_), ptr(b_), ptr(d), ptr(dx), ED, ptr(dw), ptr(db), ptr(ws), B, L, ED, w_.shape[-1], stream())
         return dx, (None if sw is not None else dw), (None if sb is not None or b_ is None else db)
 
 
@@ -342,7 +348,7 @@ class FlatAdam:
         tab["off"], tab["len"], tab["tid"] = zip(*rec)
         self.chunks = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
         self.nchunks = len(rec)
-        self.norm2 = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        self.norm2 = torch.zeros(len(self.params) + self.nchunks, dtype=torch.float32, device=dev)     # per-tensor norms | per-chunk partials
         self.offs, self.sizes = offs, sizes
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
         self.t = 0
@@ -388,8 +394,8 @@ class FlatAdam:
         scale = allreduce_grads_(self.flat_g, world_size, group, force=getattr(self, "force_collective", False))   # SUM over ranks; the mean is folded into grad_scale
         self.t += 1
         self.epoch[0] += 1
-        self.norm2.zero_()
+        nt = len(self.params)
         call("gfe_clip_adam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.flat_p16),
-             ptr(self.chunks), self.nchunks, ptr(self.norm2), scale, self.max_norm, self.lr, self.betas[0], self.betas[1],
-             self.eps, self.t, stream())
+             ptr(self.chunks), self.nchunks, ptr(self.norm2), nt, self.norm2.data_ptr() + 4 * nt, scale, self.max_norm, self.lr,
+             self.betas[0], self.betas[1], self.eps, self.t, stream())
         # parameters are rewritten by the kernel (no version bump): the registered bf16 shadows stay current by construction

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 40
+#define GFE_ABI_VERSION 41
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -90,13 +90,18 @@ int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void*
                    float* hstate, float* sdelta, float* ckpt,
                    int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
                    int64_t ld_z, int64_t ld_bc, int a_is_log, void* stream);
-/*   dA_ws (ED, 16), dB_ws / dC_ws (B, L, 16), dD_ws / dbias_ws (ED) f32: zeroed, accumulated atomically; qstate: workspace like hstate
- *   (nchunks > 1); ckpt, sdelta: as left by gfe_sscan2_fwd with the same T. */
+/*   dA_ws (ED, 16), dB_ws / dC_ws (B, L, 16), dD_ws / dbias_ws (ED) f32; qstate: workspace like hstate (nchunks > 1); ckpt, sdelta: as
+ *   left by gfe_sscan2_fwd with the same T.
+ *   part_vec (B * nchunks * ED * 18 floats) and part_bc (B * (ED/32) * L * 32 floats), both or neither: with them NOTHING is added
+ *   atomically -- every block stores its contributions there and a second launch sums them in a fixed order (run-to-run identical
+ *   gradients): dA_ws / dD_ws / dbias_ws are ADDED to (they may be gradient buffers), the dB_ws / dC_ws rows are overwritten (no zero fill
+ *   needed).  Both NULL: f32 atomics, and all five buffers must be zero on entry (large B x L, where part_bc would be 128 B per
+ *   (channel group, b, t)). */
 int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm,
                    const float* D, const void* z, const float* delta_bias, const void* dy, const void* yscan,
                    void* du, void* ddelta, void* dz,
                    float* dA_ws, float* dB_ws, float* dC_ws, float* dD_ws, float* dbias_ws,
-                   const float* ckpt, float* qstate, const float* sdelta,
+                   const float* ckpt, float* qstate, const float* sdelta, float* part_vec, float* part_bc,
                    int64_t B, int64_t L, int64_t ED, int T, int delta_softplus, int dtype, int bc_dtype,
                    int64_t ld_z, int64_t ld_bc, int64_t ld_dbc, int a_is_log, void* stream);
 
@@ -313,10 +318,12 @@ int gfe_vit_embed(const float* tok, const float* cls, const float* pos, float* x
 
 /* Combine_classfier_vit_mid (classify/classifier.py:329-333): Linear(H*W -> S) over cat([mid_input, mid_output], dim=1),
  * evaluated on the generator's channels-last mid features without materialising the concat:
- *   out[b][src*C + c][s] = sum_hw mid_src[b][hw][c] * W[s][hw]      (bias and the final transpose are host-side views)
- * mid_in, mid_out: (B, HW, C) bf16; Wt: the weight TRANSPOSED to (HW, S) f32 (a row's S weights are one 16-byte load);
- * out_zeroed: (B, 2C, S) f32, zero on entry (atomic accumulation). S == 4, 256 % (C/8) == 0. */
-int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt, float* out_zeroed,
+ *   out[b][src*C + c][s] = bias[s] + sum_hw mid_src[b][hw][c] * W[s][hw]      (the final transpose is a host-side view)
+ * mid_in, mid_out: (B, HW, C) bf16; Wt: the weight TRANSPOSED to (HW, S) f32 (a row's S weights are one 16-byte load); bias (S) or NULL;
+ * out: (B, 2C, S) f32, overwritten.  ws: nchunks * 2B * C * S floats with nchunks from gfe_mid_linear_plan: one partial slab per block of
+ * rows, summed in a fixed order by a second launch (no atomics: run-to-run identical).  S == 4, 256 % (C/8) == 0. */
+int gfe_mid_linear_plan(int64_t B, int64_t HW, int* nchunks);
+int gfe_mid_linear_fwd(const void* mid_in, const void* mid_out, const float* Wt, const float* bias, float* out, float* ws,
                        int64_t B, int64_t HW, int64_t C, int64_t S, void* stream);
 
 /* Weight gradient of the above: dW[s][hw] = sum_{b,c} dout[b][c][s] * mid[b][hw][c]; dout: (B, 2C, S) f32; dW: (S, HW) f32. */
@@ -412,24 +419,28 @@ int gfe_bce_sigmoid(const float* logits, const float* y, float* loss, float* dlo
 
 /* Per-PARAMETER clip_grad_norm_(p, max_norm) followed by one Adam step (classify_mamba.py:64, 106-108) over flat f32
  * buffers holding every trainable tensor back to back.  chunks: device array of {int64 offset, int32 length, int32 tensor_id}
- * (16 B each), no chunk crossing a tensor boundary.  norm2_zeroed: (n_tensors) f32, zero on entry.  grad_scale multiplies g
+ * (16 B each), sorted by tensor id, no chunk crossing a tensor boundary.  norm2: (ntensors) f32 and partials: (nchunks) f32, both
+ * overwritten: every chunk leaves its sum of squares, one block per tensor adds its chunks' partials in a fixed order (no atomics: the
+ * clip factor is bit-identical on every rank and in every run, so data-parallel replicas cannot drift apart).  grad_scale multiplies g
  * first (1/world_size after an all-reduce SUM).  p_bf16: optional flat bf16 copy of p refreshed in the same pass.
  * lr / betas / eps are doubles: the bias corrections 1 - beta^step are formed in double on the host, as torch.optim.Adam does. */
 int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, const void* chunks, int64_t nchunks,
-                  float* norm2_zeroed, float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps,
+                  float* norm2, int64_t ntensors, float* partials, float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps,
                   int64_t step, void* stream);
 
 /* RMSNorm (cross_atten/mamba.py:408-418): y = x * rsqrt(mean(x^2, -1) + eps) * w over (rows, dim) f32; rstd (rows) is kept for
- * the backward: dx = rstd*(dy*w - x*rstd^2*mean(dy*w*x)), dw_zeroed += sum_rows dy*x*rstd (f32 atomics). */
+ * the backward: dx = rstd*(dy*w - x*rstd^2*mean(dy*w*x)), dw_accum += sum_rows dy*x*rstd (column-owner blocks: one owner and one
+ * summation order per element, no atomics). */
 int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t rows, int64_t dim, float eps, void* stream);
-int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_zeroed,
+int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_accum,
                     int64_t rows, int64_t dim, void* stream);
 
 /* Depthwise causal Conv1d(k = 4, padding = 3, [:L]) + bias + SiLU on (B, L, ED) f32 (cross_atten/mamba.py:128-131, 208-212);
- * w: (ED, 1, 4) as nn.Conv1d.weight, bias (ED) or NULL.  Backward: dx, and dw_zeroed / db_zeroed accumulated over the batch. */
+ * w: (ED, 1, 4) as nn.Conv1d.weight, bias (ED) or NULL.  Backward: dx, and dw_accum / db_accum += the sum over the batch, formed from
+ * per-sample partial rows in ws (B * 5 * ED floats) in sample order by a second launch (no atomics). */
 int gfe_dwconv1d_silu_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
-int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_zeroed, float* db_zeroed,
-                          int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
+int gfe_dwconv1d_silu_bwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* dy, float* dx, int64_t lddx, float* dw_accum, float* db_accum,
+                          float* ws, int64_t B, int64_t L, int64_t ED, int64_t KS, void* stream);
 
 /* Sparse mixture-of-experts MLP, cross_atten/jamba.py:441-535 (SparseMoEBlock: router -> softmax -> top-k -> per-expert
  * down(silu(gate(x)) * up(x)) -> weighted sum), row f-2.  csrc/moe.hip: the (token, expert) pairs are sorted by expert on the device

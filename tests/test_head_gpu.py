@@ -102,6 +102,39 @@ def test_cross_attention_ff_embedder_vs_reference_fixture():
     assert rel_err(ne.to(DEV)(tt(fx["ne.x"], device=DEV)), tt(fx["ne.out"])) < 1e-6
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_self_attention_on_the_small_sdpa_kernel_vs_f64_math(causal):
+    """SelfAttention (sd_cross_atten.py:7-37) runs on gfe_sdpa_small (no torch-math attention left in the module): forward and every
+    gradient against the reference's formula evaluated in f64; sizes outside the kernel raise instead of leaving the HIP path."""
+    import math
+    from cross_atten.sd_cross_atten import CrossAttention, SelfAttention
+    g = torch.Generator().manual_seed(3)
+    sa = SelfAttention(n_heads=4, d_embed=64).to(DEV)
+    x = torch.randn(3, 37, 64, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(3, 37, 64, generator=g).to(DEV)
+    o = sa(x, causal_mask=causal)
+    (o * w).sum().backward()
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in sa.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    qkv = x64 @ p64["in_proj.weight"].t() + p64["in_proj.bias"]
+    q, k, v = [t.view(3, 37, 4, 16).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    wt = q @ k.transpose(-1, -2)
+    if causal:
+        wt = wt.masked_fill(torch.ones_like(wt, dtype=torch.bool).triu(1), -torch.inf)
+    wt = torch.softmax(wt / math.sqrt(16), dim=-1)
+    ref = (wt @ v).transpose(1, 2).reshape(3, 37, 64) @ p64["out_proj.weight"].t() + p64["out_proj.bias"]
+    (ref * w.double().cpu()).sum().backward()
+    assert rel_err(o, ref.float()) < 1e-5
+    assert rel_err(x.grad, x64.grad.float()) < 1e-5
+    for kname, pp in sa.named_parameters():
+        assert rel_err(pp.grad, p64[kname].grad.float()) < 1e-5, kname
+    with pytest.raises(NotImplementedError):
+        sa(torch.randn(1, 65, 64, device=DEV))
+    ca = CrossAttention(n_heads=2, d_embed=16, d_cross=24).to(DEV)
+    with pytest.raises(NotImplementedError):
+        ca(torch.randn(2, 3, 16, device=DEV), torch.randn(2, 6, 24, device=DEV))
+
+
 def test_embedding_offsets_bit_exact():
     from cross_atten.mamba_transformer import Cross_mamba_both
     fx = golden("t0_head_ops.npz")

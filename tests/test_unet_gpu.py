@@ -555,6 +555,37 @@ def test_resident_transposed_conv_ragged_shapes(shape, full, monkeypatch):
     assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
 
 
+@pytest.mark.parametrize("shape,full", [((1, 5, 9, 7), True), ((2, 12, 12, 12), True), ((3, 9, 20, 17), False), ((1, 24, 24, 24), True)])
+def test_streamed_multiclass_transposed_conv_statistics(shape, full):
+    """the 8-class streamed transposed conv (Cin = 256 does not fit the LDS-resident kernel) with ONE 64-channel group keeps one
+    GroupNorm-partial slot per tile; a persistent block's work range that ended inside a tile's classes made two blocks store to the same
+    slot (with <= 256 work items every class was its own block: seven eighths of the sums were lost).  f_maps = (64, 256) reaches it.
+    Partials from the kernel's epilogue against the separate statistics pass, output against torch fp32."""
+    from gfe_hip import nn_ops as K
+    from pytorch3dunet.unet3d.buildingblocks import TransposeConvUpsampling
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + H * 10 + W)
+    up = TransposeConvUpsampling(256, 64).to(DEV)
+    with torch.no_grad():
+        up.upsample.conv_transposed.weight.copy_(torch.randn(256, 64, 3, 3, 3, generator=g) / (27 * 256 / 8) ** 0.5)
+    x = torch.randn(B, D, H, W, 256, generator=g).to(BF).to(DEV)
+    osz = [2 * n if full else 2 * n - 1 for n in (D, H, W)]
+    skip = torch.randn(B, *osz, 64, generator=g).to(BF).to(DEV)
+    with torch.no_grad():
+        y = up(skip, x)
+        wq = up.upsample.conv_transposed.weight.to(BF).float()
+        ref = F.conv_transpose3d(x.float().permute(0, 4, 1, 2, 3), wq, stride=2, padding=1)
+        if list(ref.shape[2:]) != osz:
+            ref = F.interpolate(ref, size=osz)
+        ref = ref.permute(0, 2, 3, 4, 1) + skip.float()
+    assert rel_err(y, ref) < 1e-2
+    assert getattr(y, "gn_partials", None) is not None, "the producer did not tag its output with GroupNorm partials"
+    gamma, beta = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    s1, t1 = K.groupnorm_scale_shift(y, gamma, beta, 8)                    # from the epilogue's partials
+    s0, t0 = K.groupnorm_scale_shift(y.clone(), gamma, beta, 8)            # the separate statistics pass
+    assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5, (rel_err(s1, s0), rel_err(t1, t0))
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 24), (1, 13, 9, 20), (1, 8, 8, 8), (1, 3, 5, 2)])
 def test_first_block_collapsed_conv2_matches_the_mfma_path(shape):
     """The first ResNetBlock (one-channel input, 64 features): conv2(GroupNorm(conv1(x))) computed as a one-channel 27-tap convolution
