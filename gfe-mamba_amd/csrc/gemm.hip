@@ -9,6 +9,7 @@
 // ds_read_b128 fragment read takes the ideal 4 LDS cycles (tools/lds_bank_model.py; a 144-B padded stride costs 8).  Register-prefetched double buffering (global loads of tile k+1 fly under the MFMAs
 // of tile k).  f32 accumulate; epilogue: +bias, exact-erf GELU, +residual, bf16 or f32 store, or f32 atomics for split-K.
 #include "common.h"
+#include "gemm_dma.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -342,6 +343,13 @@ int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
     p.ksplit = (int)ks; p.atomic = nsplit > 1;
     if (nsplit <= 1) p.part = nullptr;
     if (p.part && (p.ldc & 3)) return GFE_ERR_SHAPE;          // the reduction reads / writes C 16 bytes at a time
+    if (nsplit == 1 && p.a_mode == 0 && p.b_mode == 0) {      // plain bf16 x bf16, K-major: the persistent LDS-DMA main loop (gemm_dma.hip)
+        GemmDmaArgs d;
+        d.A = p.A; d.B = p.B; d.C = p.C; d.bias = p.bias; d.res = p.res;
+        d.lda = p.lda; d.ldb = p.ldb; d.ldc = p.ldc; d.ldres = p.ldres;
+        d.M = p.M; d.N = p.N; d.K = p.K; d.out_f32 = p.out_f32; d.res_f32 = p.res_f32; d.act = p.act;
+        if (gemm_dma_usable(d)) return gemm_dma_launch(d, st);
+    }
     int rc;
     switch (p.a_mode) {
         case 0: rc = gemm_launch_b<0>(p, nsplit, st); break;

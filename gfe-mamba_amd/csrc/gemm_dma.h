@@ -1,0 +1,16 @@
+// Interface between gemm.hip (dispatch, operand modes, split-K) and gemm_dma.hip (the persistent LDS-DMA main loop for the plain
+// bf16 x bf16 K-major shape: every nn.Linear forward of the inference pipelines, vit_pytorch_diy/vit_3d.py:41-46, 50).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+struct GemmDmaArgs {
+    const void* A; const void* B; void* C; const float* bias; const void* res;
+    int64_t lda, ldb, ldc, ldres;
+    int M, N, K;
+    int out_f32, res_f32, act;
+};
+
+// true: shape / alignment / size limits of the DMA kernel hold (gemm_dma_launch may be called)
+bool gemm_dma_usable(const GemmDmaArgs& a);
+int gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st);

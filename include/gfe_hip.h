@@ -243,6 +243,10 @@ int gfe_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 int gfe_gemm_ex(const void* A, int64_t lda, int a_mode, const void* B, int64_t ldb, int b_mode, void* C, int64_t ldc,
                 int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres, int res_f32,
                 int act, int out_f32, int split_k, float* splitk_ws, void* stream);
+/* Diagnostic: how many GEMM calls of this process ran on the persistent LDS-DMA main loop (csrc/gemm_dma.hip: plain bf16 x bf16 K-major
+ * operands, M >= 512, N % 128 == 0, K % 64 == 0, one K range; everything else stays on gemm_nt_kernel).  GFE_GEMM_NO_DMA=1 turns it off. */
+int gfe_gemm_dma_launches(void);
+
 
 /* Exact-f32 GEMM on the f32 matrix cores for the trainable head's small Linears (the reference trains the head in fp32:
  * classify_mamba.py:69-74; Mamba projections mamba.py:204, 235-238, 223; q / out projections sd_cross_atten.py:42-45; GEGLU FF

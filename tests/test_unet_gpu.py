@@ -49,6 +49,49 @@ def test_gemm_epilogues_and_splitk():
     assert torch.equal(K.cast(f, BF), f.to(BF)) and torch.equal(K.cast(f.to(BF), torch.float32), f.to(BF).float())
 
 
+@pytest.mark.parametrize("M,N,K_", [(512, 128, 64), (1000, 256, 128), (2085, 512, 512), (777, 384, 1024), (13832, 1536, 512), (4099, 512, 2048), (600, 2048, 192)])
+def test_gemm_dma_main_loop(M, N, K_, monkeypatch):
+    """The persistent LDS-DMA main loop (csrc/gemm_dma.hip; every nn.Linear forward of the inference pipelines, vit_3d.py:41-46, 50): ragged
+    last row tile, one-unit tiles (K = 64), every epilogue (bias, exact-erf GELU, f32 / bf16 residual, f32 / bf16 output), a strided A view
+    (the q block of a qkv buffer) and a strided C, against an f64 product of the same bf16 operands -- and bit-identical to itself on a
+    second run (the unit stream crosses tile boundaries with counted waits: a mis-count would show as rare wrong tiles)."""
+    import gfe_hip
+    from gfe_hip import nn_ops as K
+    monkeypatch.setenv("GFE_GEMM_DMA_ALL", "1")             # (the dispatch keeps shapes with < 2 tiles per CU on gemm_nt_kernel: a speed rule)
+    g = torch.Generator().manual_seed(M + N + K_)
+    wide = torch.randn(M, K_ + 64, generator=g).to(BF).to(DEV)
+    a = wide[:, 32:32 + K_]                                           # row stride K + 64, 64-byte offset
+    b = (torch.randn(N, K_, generator=g) / K_ ** 0.5).to(BF).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ref = a.double() @ b.double().t()
+    n0 = gfe_hip.lib().gfe_gemm_dma_launches()
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    K.gemm_nt(a, b, out=o32)
+    assert gfe_hip.lib().gfe_gemm_dma_launches() == n0 + 1, "the shape did not take the DMA main loop"
+    assert rel_err(o32, ref) < 2e-5
+    o16 = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt(a, b, out=o16)
+    assert rel_err(o16, ref) < 5e-3                                                        # bf16 output rounding
+    wide_c = torch.zeros(M, N + 128, dtype=torch.float32, device=DEV)
+    K.gemm_nt(a, b, bias=bias, res=res, act=1, out=wide_c[:, 64:64 + N])
+    want = F.gelu(ref + bias.double()) + res.double()
+    assert rel_err(wide_c[:, 64:64 + N], want) < 2e-5
+    assert wide_c[:, :64].abs().max().item() == 0 and wide_c[:, 64 + N:].abs().max().item() == 0      # nothing outside the view
+    gelu_only = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt(a, b, bias=bias, act=1, out=gelu_only)
+    assert rel_err(gelu_only, F.gelu(ref + bias.double())) < 5e-3
+    r16 = res.to(BF)
+    got = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    K.gemm_nt(a, b, res=r16, out=got)
+    assert rel_err(got, ref + r16.double()) < 2e-5
+    again = torch.empty_like(got)
+    for _ in range(3):
+        K.gemm_nt(a, b, res=r16, out=again)
+        assert torch.equal(again, got)
+    assert gfe_hip.lib().gfe_gemm_dma_launches() == n0 + 8
+
+
 @pytest.mark.parametrize("C,shape", [(8, (2, 8, 8, 8)), (16, (1, 6, 8, 4)), (64, (2, 8, 16, 16)), (128, (1, 4, 8, 24)), (256, (1, 5, 8, 8))])
 def test_groupnorm_conv3_relu_residual(C, shape):
     """GroupNorm -> Conv3d k3 p1 -> (+residual) -> ReLU for every channel width of the generator, odd sizes included."""
