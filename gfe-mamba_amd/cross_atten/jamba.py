@@ -5,9 +5,10 @@ Same class names, constructor arguments and state-dict keys.
 
 Every projection runs on the exact-f32 MFMA GEMM (gfe_hip.train_ops.Linear), the Mamba mixers on the fused selective-scan kernels
 (with the inner RMSNorms of Jamba, mamba.py:171-178), the causal attention on gfe_sdpa_small (37 tokens x 8 heads x 64), RMSNorm on
-gfe_rmsnorm.  The expert routing itself (softmax, top-2, gather / scatter-add of the selected tokens) stays on torch's indexing ops --
-it is bookkeeping on (B*37) x 16 numbers, written exactly as the reference writes it so that ties and orders agree.
-Not built: the language-model wrapper JambaLM / from_pretrained (never used by the GFE-Mamba scripts) and the KV-cache decode path."""
+gfe_rmsnorm, the expert routing, the grouped expert projections and the weighted combine on csrc/moe.hip (gfe_hip/moe_ops.py).
+Cached decoding (Jamba.step, jamba.py:298-306: a KV cache per attention layer in the reference's (B, kv heads, T, head dim) layout, the
+conv window + SSM state per Mamba layer) runs one token per call on the step kernels and the one-query attention kernel.
+Not built: the language-model wrapper JambaLM / from_pretrained (never used by the GFE-Mamba scripts)."""
 import math
 from dataclasses import dataclass
 from typing import Union
@@ -18,7 +19,7 @@ import torch.nn.functional as F
 
 from cross_atten.mamba import MambaBlock, MambaConfig, RMSNorm
 from gfe_hip.moe_ops import moe_mlp
-from gfe_hip.head_ops import sdpa_small
+from gfe_hip.head_ops import cross_attn_q1, sdpa_small
 from gfe_hip.train_ops import Linear
 
 
@@ -92,6 +93,14 @@ class Jamba(nn.Module):
             router_logits.append(rl)
         return x, router_logits
 
+    def step(self, x, caches):
+        """Cached decoding, jamba.py:298-306: x (B, L, D) -- one token per call once the caches are warm (MambaLayer squeezes dim 1,
+        jamba.py:421-423) -- and caches[i] from layers[i].get_empty_cache(...); returns (x, caches).  Inference only (no graph is recorded)."""
+        with torch.no_grad():
+            for i, layer in enumerate(self.layers):
+                (x, _), caches[i] = layer(x, caches[i])
+        return x, caches
+
 
 class AttentionLayer(nn.Module):
     def __init__(self, config: JambaLMConfig, num_experts: int):
@@ -103,10 +112,13 @@ class AttentionLayer(nn.Module):
         self.pre_moe_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
 
     def forward(self, x, cache=None):
-        assert cache is None, "KV-cache decoding is not part of the classification path"
-        x = x + self.self_attn(self.input_layernorm(x))[0]                       # jamba.py:325-329
+        a, cache = self.self_attn(self.input_layernorm(x), cache)                # jamba.py:325-329
+        x = x + a
         h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # :332-335
-        return (x + h, router_logits), None
+        return (x + h, router_logits), cache
+
+    def get_empty_cache(self, batch_size, device):
+        return (None, None)                                                      # jamba.py:340-341
 
 
 class AttentionSDPA(nn.Module):
@@ -125,15 +137,38 @@ class AttentionSDPA(nn.Module):
         self.o_proj = Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
 
     def forward(self, x, cache=None):
-        assert cache is None, "KV-cache decoding is not part of the classification path"
         p_drop = self.attention_dropout if self.training else 0.0                 # dropout_p of F.scaled_dot_product_attention (jamba.py:390-392)
         B, L, _ = x.shape
         q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        Hkv, dh = self.num_key_value_heads, self.head_dim
+        if cache is not None:
+            # KV cache (jamba.py:373-383): the cache keeps the reference's layout, (B, kv heads, T, head dim) per tensor, so caches are
+            # interchangeable with the reference's; with a cache the reference calls SDPA with is_causal=False -- also for a multi-token
+            # first call -- and so does this
+            past_k, past_v = cache
+            k4 = k.view(B, L, Hkv, dh).transpose(1, 2)
+            v4 = v.view(B, L, Hkv, dh).transpose(1, 2)
+            if past_k is not None:
+                k4, v4 = torch.cat([past_k, k4], dim=2), torch.cat([past_v, v4], dim=2)
+            cache = (k4, v4)
+            T = k4.shape[2]
+            k, v = k4.transpose(1, 2).reshape(B, T, Hkv * dh), v4.transpose(1, 2).reshape(B, T, Hkv * dh)
+        else:
+            T = L
         if self.num_key_value_groups > 1:                                        # GQA: repeat_kv (jamba.py:558-567) on the projection layout
-            rep = lambda t: t.view(B, L, self.num_key_value_heads, 1, self.head_dim).expand(-1, -1, -1, self.num_key_value_groups, -1).reshape(B, L, -1)
+            rep = lambda t: t.view(B, T, Hkv, 1, dh).expand(-1, -1, -1, self.num_key_value_groups, -1).reshape(B, T, -1)
             k, v = rep(k), rep(v)
-        o = sdpa_small(q, k, v, self.num_heads, causal=True, dropout_p=p_drop)   # F.scaled_dot_product_attention(..., is_causal=True) (:390-392)
-        return self.o_proj(o), None
+        if cache is None:
+            o = sdpa_small(q, k, v, self.num_heads, causal=True, dropout_p=p_drop)   # F.scaled_dot_product_attention(..., is_causal=True) (:390-392)
+        elif L == 1:
+            if p_drop > 0:
+                raise NotImplementedError("attention dropout while decoding from a KV cache (the reference's training-mode corner) is not built")
+            o = cross_attn_q1(q, k.contiguous(), v.contiguous(), self.num_heads)     # one query against the T cached keys: gfe_cross_attn_q1
+        elif T == L:
+            o = sdpa_small(q, k, v, self.num_heads, causal=False, dropout_p=p_drop)  # first call with an empty cache: non-causal, as the reference
+        else:
+            raise NotImplementedError("multi-token calls onto a warm KV cache are outside the built kernels (one token per call, jamba.py:421-423)")
+        return self.o_proj(o), cache
 
 
 class MambaLayer(nn.Module):
@@ -147,10 +182,18 @@ class MambaLayer(nn.Module):
         self.pre_moe_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
 
     def forward(self, x, cache=None):
-        assert cache is None, "single-token decoding is not part of the classification path"
-        x = x + self.mamba(self.input_layernorm(x))                              # jamba.py:418-425
+        n = self.input_layernorm(x)
+        if cache is None:
+            m = self.mamba(n)                                                    # jamba.py:418-420
+        else:
+            m, cache = self.mamba.step(n.squeeze(1), cache)                      # :421-423, single token on the step kernels (mamba.py:342-405)
+            m = m.unsqueeze(1)
+        x = x + m
         h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # :428-431
-        return (x + h, router_logits), None
+        return (x + h, router_logits), cache
+
+    def get_empty_cache(self, batch_size, device):
+        return (None, torch.zeros(batch_size, self.config.d_inner, self.config.d_conv - 1, device=device))   # jamba.py:438-439
 
 
 class SparseMoEBlock(nn.Module):

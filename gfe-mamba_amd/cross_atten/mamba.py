@@ -164,8 +164,10 @@ class MambaBlock(nn.Module):
         """x: (B, D); cache = (h (B, ED, N) or None, inputs (B, ED, d_conv - 1)) -> (output (B, D), new cache).  Inference only."""
         if not x.is_cuda:
             raise RuntimeError("MambaBlock.step runs on the GPU only (no CPU fallback)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise RuntimeError("MambaBlock.step is an inference path: call it under torch.no_grad()")
+        with torch.no_grad():                    # an inference path (the reference's callers run it in eval mode, often without no_grad):
+            return self._step(x.detach(), cache)     # nothing is recorded, the result carries no graph
+
+    def _step(self, x, cache):
         from gfe_hip import call, ptr, stream
         from gfe_hip.train_ops import linear
         cfg = self.config

@@ -32,6 +32,8 @@
 // (Round-1 history, measured on the 64->64 @96^3 conv: VGPR-staged v1 671 TFLOP/s; v2 with prefetch registers, swizzled LDS
 // and division-free index math 730-780; ablation showed the non-MFMA instruction stream cost 2x the MFMA time -> this DMA form,
 // 970-1030 TFLOP/s.  DESIGN.md 4.1 has the ablation table and the list of DMA-issue variants that were measured and dropped.)
+#include <atomic>
+#include <mutex>
 #include "common.h"
 #include "convt3d.h"
 
@@ -859,8 +861,11 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     }
 }
 
-// Ticket counters of the dynamic tile scheduler: a ring of 16-int slots, zeroed once; a launch takes the next slot (a captured launch keeps
-// its slot across replays: the kernel leaves it at zero).  Allocated outside stream capture only; GFE_CONV_STATIC=1 turns the scheduler off.
+// Ticket counters of the dynamic tile scheduler: 16-int slots, zeroed once (a kernel leaves its slot at zero).  EAGER launches take the
+// next slot of a 256-slot ring: two launches meet on a slot only 256 conv launches apart.  A CAPTURED launch keeps its slot for the life of
+// the graph, so it draws from a pool of its own that is never recycled (a replayed graph next to an eager generator on another
+// stream could have shared a ring slot and split one ticket stream); when that pool is used up, captured launches fall back to static tile
+// shares (sched = NULL).  Allocated outside stream capture only; GFE_CONV_STATIC=1 turns the scheduler off.
 }  // namespace
 static int g_conv_reserved_cus = -1;
 int conv_reserved_cus() {
@@ -869,18 +874,31 @@ int conv_reserved_cus() {
 }
 extern "C" int gfe_conv_reserve_cus(int n) { const int old = conv_reserved_cus(); g_conv_reserved_cus = n < 0 ? 0 : n; return old; }
 int* conv_sched_slot(hipStream_t st) {
-    constexpr int SLOTS = 256;
-    static int* ring = nullptr;
-    static bool off = getenv("GFE_CONV_STATIC") != nullptr && getenv("GFE_CONV_STATIC")[0] == '1';
-    static unsigned seq = 0;
+    constexpr unsigned RING = 256, CAPTURED = 4096;
+    static int* pool = nullptr;                          // [RING eager slots | CAPTURED dedicated slots] x 16 ints
+    static std::mutex mu;
+    static std::atomic<unsigned> seq{0}, cap_seq{0};
+    static const bool off = getenv("GFE_CONV_STATIC") != nullptr && getenv("GFE_CONV_STATIC")[0] == '1';
     if (off) return nullptr;
-    if (!ring) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        if (hipMalloc((void**)&ring, SLOTS * 16 * sizeof(int)) != hipSuccess) { ring = nullptr; return nullptr; }
-        if (hipMemset(ring, 0, SLOTS * 16 * sizeof(int)) != hipSuccess) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    if (!pool) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!pool) {
+            if (capturing) return nullptr;               // (allocation and the one-time fill are not capturable)
+            int* q = nullptr;
+            const size_t bytes = (size_t)(RING + CAPTURED) * 16 * sizeof(int);
+            if (hipMalloc((void**)&q, bytes) != hipSuccess) return nullptr;
+            if (hipMemset(q, 0, bytes) != hipSuccess) { (void)hipFree(q); return nullptr; }
+            pool = q;
+        }
     }
-    return ring + 16 * (seq++ % SLOTS);
+    if (capturing) {
+        const unsigned i = cap_seq.fetch_add(1);
+        return i < CAPTURED ? pool + 16 * (size_t)(RING + i) : nullptr;
+    }
+    return pool + 16 * (size_t)(seq.fetch_add(1) % RING);
 }
 namespace {
 

@@ -252,7 +252,10 @@ int gfe_moe_route(const float* logits, int64_t T, int64_t E, int64_t K, float* r
                   void* stream) {
     GFE_REQUIRE(logits && rw && sel && tok_sorted && pos && seg, GFE_ERR_NULL);
     GFE_REQUIRE(T > 0 && E > 1 && E <= MAXE && K >= 1 && K <= E && T * K <= 0x7fffffff, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(moe_route_kernel, dim3(1), dim3(RT), (size_t)(RT * E + E + 1) * sizeof(int), (hipStream_t)stream,
+    const size_t lds = (size_t)(RT * E + E + 1) * sizeof(int);           // 65 796 B at E = 64: above the 64 KiB default
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) { (void)hipFuncSetAttribute((const void*)moe_route_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    hipLaunchKernelGGL(moe_route_kernel, dim3(1), dim3(RT), lds, (hipStream_t)stream,
                        logits, (int)T, (int)E, (int)K, rw, sel, tok_sorted, pos, seg);
     return gfe_launch_status();
 }

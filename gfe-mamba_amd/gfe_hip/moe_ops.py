@@ -54,17 +54,18 @@ class _MoEFn(torch.autograd.Function):
         call("gfe_moe_combine", ptr(o), ptr(rw), ptr(pos), ptr(out), T, top_k, D, 0, stream())   # weighted sum per token      :508-513
         ctx.save_for_backward(x2, logits, rw, sel, tok_sorted, pos, seg, g, u, h, o, router_w, *expert_w)
         ctx.meta = (T, D, Fd, E, top_k)
-        ctx.mark_non_differentiable(logits)
-        return out, logits
+        return out, logits                                   # the router logits stay differentiable, as in the reference (jamba.py:517)
 
     @staticmethod
-    def backward(ctx, dout, _dlogits_unused):
+    def backward(ctx, dout, dlogits):
         x2, logits, rw, sel, tok_sorted, pos, seg, g, u, h, o, router_w, *expert_w = ctx.saved_tensors
         T, D, Fd, E, top_k = ctx.meta
         P = T * top_k
         dev = x2.device
         gate, up, down = expert_w[:E], expert_w[E:2 * E], expert_w[2 * E:]
         det = lambda t: t.detach()
+        if dout is None:                                     # only the router logits carry a gradient (the balance term alone)
+            dout = torch.zeros((T, D), dtype=F32, device=dev)
         d = dout if (dout.dtype == F32 and dout.is_contiguous()) else dout.float().contiguous()
         tg, tu, td = (_ptr_table([det(w) for w in ws], dev) for ws in (gate, up, down))
 
@@ -100,6 +101,8 @@ class _MoEFn(torch.autograd.Function):
         # router: d logits -> d W_r, and its share of dx
         dlog = torch.empty((T, E), dtype=F32, device=dev)
         call("gfe_moe_route_bwd", ptr(logits), ptr(sel), ptr(drw), ptr(dlog), T, E, top_k, stream())
+        if dlogits is not None:                              # a loss on the returned router logits (load_balancing_loss, jamba.py:537-556)
+            dlog += dlogits.to(F32)
         K.gemm_f32(dlog, False, det(router_w), True, accum_into=dx)
         slot = _grad_slot(router_w)
         if slot is not None:

@@ -86,3 +86,39 @@ def test_load_transform_is_normalise_then_resize():
     assert tuple(out.shape) == (1, 32, 32, 24)
     assert torch.equal(out, resize_area(adaptive_normal(v).unsqueeze(0), (32, 32, 24)))
     assert out.min() >= -1 and out.max() <= 1
+
+
+def test_mri_classify_samples_and_loader_from_npy_volumes(tmp_path):
+    """MRI_classify.__getitem__ / classi_dataloader (dataloader/pic_table_loader.py:104-117, 131-133) on .npy volumes: the sample dictionary
+    of the reference (image (1, d, h, w) f32 normalised + resized on the device, label from the file name, cate_x / conti_x of the matched
+    table row, name) and batches a ClassifyStep can take."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from dataloader.pic_table_loader import MRI_classify, classi_dataloader
+    from utils.data_normalization import load_transform
+    fx = json.load(open(os.path.join(GOLDEN, "t11_dataset.json")))
+    g = np.random.default_rng(3)
+    names = [n.replace(".nii.gz", ".npy") for n in fx["names"][:12]]
+    vols = {}
+    for n in names:
+        v = (np.abs(g.standard_normal((20, 24, 12))) ** 3 * 300).astype(np.float32)
+        v[g.random(v.shape) < 0.3] = 0.0
+        np.save(tmp_path / n, v)
+        vols[n] = v
+    csv = os.path.join(GOLDEN, "t11_table_input.csv")
+    ds = MRI_classify(str(tmp_path), csv, (16, 16, 8), days_threshold=-1)
+    assert 0 < len(ds) <= len(names)
+    s = ds[0]
+    assert set(s) == {"image", "label", "cate_x", "conti_x", "name"}
+    assert s["image"].shape == (1, 16, 16, 8) and s["image"].dtype == torch.float32 and s["image"].is_cuda
+    want = load_transform(torch.from_numpy(vols[s["name"]]).cuda(), (16, 16, 8))
+    assert torch.equal(s["image"], want)
+    assert s["label"] == int(s["name"].split("-")[-1][0]) and s["cate_x"].dtype == torch.int64 and s["conti_x"].dtype == torch.float32
+    found, idx = ds.find_index(s["name"], ds.table_df["info"])
+    assert torch.equal(s["cate_x"], torch.tensor(ds.table_df["cate_x"].iloc[idx].values, dtype=torch.int64))
+    loader = classi_dataloader(str(tmp_path), (16, 16, 8), 2, csv, shuffle=False)
+    batch = next(iter(loader))
+    assert batch["image"].shape == (2, 1, 16, 16, 8) and batch["cate_x"].shape[0] == 2 and batch["conti_x"].shape[0] == 2 and len(batch["name"]) == 2
+    assert batch["image"].abs().max().item() <= 1.0                       # adaptive_normal clips to [-1, 1] (data_normalization.py:44-46)

@@ -216,3 +216,60 @@ def test_cross_jamba_both_at_the_classify_configuration_vs_reference_fixture():
     # f32 everywhere except the K / V projections over the (bf16) image condition
     assert e_pred < 5e-3 and e_loss < 2e-3
     assert errs[len(errs) // 2][0] < 5e-3 and errs[0][0] < 3e-2
+
+
+@pytest.mark.gpu
+def test_jamba_cached_decoding_reproduces_the_full_forward():
+    """Jamba.step / MambaLayer / AttentionSDPA with caches (cross_atten/jamba.py:298-306, 373-383, 421-423; VERDICT r03 missing #2): feeding
+    the tokens one at a time through the caches (Mamba conv window + state on the step kernels, a KV cache in the reference's
+    (B, kv heads, T, head dim) layout with the one-query attention kernel) must reproduce the full-sequence forward position by position:
+    the Mamba recurrence is causal, the cached attention of token t sees keys 0..t = the causal mask's row t, the MLPs are per token."""
+    from cross_atten.jamba import Jamba, JambaLMConfig
+    import gfe_hip.det_init as det
+    cfg = JambaLMConfig(d_model=64, n_layers=6, mlp_size=128, num_attention_heads=8, num_key_value_heads=8, num_experts=4, num_experts_per_tok=2,
+                        inner_layernorms=True)
+    m = Jamba(cfg)
+    m.load_state_dict(det.det_state_dict(m.state_dict(), seed=43, prefix="jamstep."))
+    m = m.cuda().eval()
+    kinds = [type(l).__name__ for l in m.layers]
+    assert "AttentionLayer" in kinds and "MambaLayer" in kinds
+    B, L = 3, 11
+    x = torch.randn(B, L, 64, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        full, _ = m(x)
+    caches = [l.get_empty_cache(B, x.device) for l in m.layers]
+    outs = []
+    for t in range(L):                                   # (no torch.no_grad here: the step path must not need it)
+        o, caches = m.step(x[:, t:t + 1].contiguous(), caches)
+        outs.append(o)
+    got = torch.cat(outs, dim=1)
+    e = rel_err(got, full)
+    print("Jamba token-by-token cached decoding vs the full forward: %.2e" % e)
+    assert e < 1e-4
+    ia = kinds.index("AttentionLayer")
+    k_cache, v_cache = caches[ia]
+    assert k_cache.shape == (B, 8, L, 8) and v_cache.shape == (B, 8, L, 8)        # the reference's cache layout (jamba.py:366-383)
+    im = kinds.index("MambaLayer")
+    assert caches[im][0].shape == (B, cfg.d_inner, cfg.d_state) and caches[im][1].shape == (B, cfg.d_inner, cfg.d_conv - 1)
+
+
+@pytest.mark.gpu
+def test_router_logits_are_differentiable_like_the_references():
+    """SparseMoEBlock returns its router logits (jamba.py:517) and load_balancing_loss (jamba.py:537-556) differentiates through
+    them; the fused MoE node must pass that gradient on to the router weight and the tokens (alone, and together with the output's)."""
+    from cross_atten.jamba import JambaLMConfig, SparseMoEBlock, load_balancing_loss
+    cfg = JambaLMConfig(d_model=64, n_layers=2, mlp_size=96, num_experts=4, num_experts_per_tok=2)
+    g = torch.Generator().manual_seed(9)
+    blk = SparseMoEBlock(cfg, num_experts=4, num_experts_per_tok=2).cuda()
+    x = torch.randn(2, 9, 64, generator=g).cuda().requires_grad_(True)
+    out, rl = blk(x)
+    assert rl.requires_grad
+    load_balancing_loss([rl], 4, 2).backward()                                          # the balance term ALONE
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = blk.router.weight.detach().double().cpu().requires_grad_(True)
+    rl64 = x64.reshape(-1, 64) @ w64.t()
+    assert rel_err(rl, rl64.float()) < 1e-5
+    load_balancing_loss([rl64], 4, 2).backward()
+    assert rel_err(blk.router.weight.grad, w64.grad.float()) < 1e-4 and rel_err(x.grad, x64.grad.float()) < 1e-4
+    for e in blk.experts:                                                                # nothing flows into the experts from this term
+        assert e.gate_proj.weight.grad is None or e.gate_proj.weight.grad.abs().max() == 0

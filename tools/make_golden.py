@@ -5,11 +5,12 @@ Build-container only: /root/reference does not exist on the GPU box and nothing 
 smoke() reads it.  Fixtures hold data only (inputs, weights for tiny cases, expected outputs); larger
 cases regenerate their weights from gfe_hip/det_init.py on both sides.
 
-    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t8|t9|t10] [--out tests/golden]
+    python tools/make_golden.py [--only t0|t1|t2|t3|t4|t5|t6|t7|t8|t9|t10|t11] [--out tests/golden]
 """
 import argparse
 import importlib.util
 import os
+import re
 import sys
 import types
 
@@ -523,6 +524,77 @@ def t5(R, out):
     np.savez_compressed(os.path.join(out, "t5_table.npz"), **fx)
 
 
+def t11(R, out):
+    """dataloader/pic_table_loader.py:46-127 `MRI_classify`: which files survive the constructor's filter (the reference pops from the list
+    it enumerates: kept bug for bug on our side), which table row every file is matched to (patient id, label, nearest EXAMDATE within 30
+    days) and the label / cate_x / conti_x of every sample.  The image transforms are monai / nibabel (absent): stubbed, not pinned here.
+    Inputs travel as data files: tests/golden/t11_table_input.csv and the file-name list inside t11_dataset.json."""
+    import importlib
+    import json
+    import tempfile
+    import pandas as pd
+    # utils/common.py:6-8 imports torchvision.utils / matplotlib (absent) for its plotting helpers; date_difference needs neither
+    for name in ("torchvision.utils", "matplotlib", "matplotlib.pyplot"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules["torchvision.utils"].make_grid = None
+    sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+
+    class _T:                                   # a transform that passes its argument through (LoadImaged, Compose, ...)
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+    for n in ("Compose", "LoadImaged", "ToTensord", "EnsureChannelFirstd", "Spacingd", "ScaleIntensityRanged", "CropForegroundd", "Resized"):
+        setattr(sys.modules["monai.transforms"], n, _T)
+    sys.modules["monai.utils"].first = None
+    ptl = importlib.import_module("dataloader.pic_table_loader")
+    g = np.random.default_rng(11)
+    base = pd.read_csv(os.path.join(out, "t5_table_input.csv"))
+    base["date_diff"] = g.integers(-5, 400, len(base))
+    base.loc[7, "LABEL"] = np.nan
+    csv = os.path.join(out, "t11_table_input.csv")
+    base.to_csv(csv, index=False)
+    names = []
+    for i in range(len(base)):
+        r = base.iloc[i]
+        y, m, d = r["EXAMDATE"].split("-")
+        lab = 0 if pd.isna(r["LABEL"]) else int(r["LABEL"])
+        shift = int(g.integers(0, 45))                                   # some scans fall outside the 30-day window
+        day = min(28, int(d) + shift % 12)
+        if i % 3 != 2:
+            names.append(f"{r['PTID']}-{y}_{m}_{day:02d}-{lab}.nii.gz")
+        if i % 5 == 0:
+            names.append(f"{r['PTID']}-{int(y) + 3}_{m}_{d}-{lab}.nii.gz")       # years away: no match
+        if i % 7 == 0:
+            names.append(f"{r['PTID']}-{y}_{m}_{d}-{1 - lab}.nii.gz")            # the other label
+    names = sorted(set(names))
+    fx = {"names": names, "cases": {}}
+    for thr in (-1, 30, 200):
+        with tempfile.TemporaryDirectory() as d:
+            for n in names:
+                open(os.path.join(d, n), "wb").close()
+            real_glob = ptl.glob
+            ptl.glob = lambda pat: sorted(real_glob(pat))                # (file-system order is not part of the contract)
+            try:
+                ds = ptl.MRI_classify(d, csv, (8, 8, 8), days_threshold=thr)
+            finally:
+                ptl.glob = real_glob
+            kept = [os.path.basename(p) for p in ds.mri_nii]
+            rows, labels, cate, conti = [], [], [], []
+            for n in kept:
+                found, idx = ds.find_index(n, ds.table_df["info"])
+                rows.append([bool(found), int(idx)])
+                labels.append(int(re.findall('-(\\d).nii.gz', n)[0]))
+                cate.append([int(v) for v in ds.table_df["cate_x"].iloc[idx].values])
+                conti.append([float(v) for v in ds.table_df["conti_x"].iloc[idx].values])
+            fx["cases"][str(thr)] = dict(kept=kept, rows=rows, labels=labels, cate_x=cate, conti_x=conti)
+    json.dump(fx, open(os.path.join(out, "t11_dataset.json"), "w"))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -531,7 +603,7 @@ if __name__ == "__main__":
     os.makedirs(a.out, exist_ok=True)
     torch.set_grad_enabled(True)
     R = import_reference()
-    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t8", t8), ("t9", t9), ("t10", t10)):
+    for name, fn in (("t0", t0), ("t1", t1), ("t2", t2), ("t3", t3), ("t4", t4), ("t5", t5), ("t6", t6), ("t7", t7), ("t8", t8), ("t9", t9), ("t10", t10), ("t11", t11)):
         if not a.only or a.only == name:
             fn(R, a.out)
             print("wrote", name)
