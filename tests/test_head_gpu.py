@@ -61,14 +61,15 @@ def test_token_by_token_step_reproduces_the_references_forward():
     print("token-by-token step vs the reference's forward %.2e, vs the fused full-sequence path %.2e" % (e_ref, e_full))
     assert e_ref < 1e-5 and e_full < 1e-5
     # the state the steps leave behind is the scan's final state: one more token must continue the sequence, not restart it
+    warm = list(caches)                                  # (Mamba.step writes the new caches into the list it is given)
     with torch.no_grad():
-        o2, caches2 = m.step(x[:, 0].contiguous(), caches)
+        o2, caches2 = m.step(x[:, 0].contiguous(), list(warm))
         y1, h1 = m.layers[0].mixer.ssm_step(torch.ones(B, cfg.d_inner, device=DEV), None)
         y2, h2 = m.layers[0].mixer.ssm_step(torch.ones(B, cfg.d_inner, device=DEV), h1)
     assert not torch.allclose(o2, outs[0]) and caches2[0][0].shape == (B, cfg.d_inner, cfg.d_state)
     assert torch.isfinite(y2).all() and not torch.allclose(y1, y2)
     # an inference path that callers of the reference run in eval mode WITHOUT no_grad: it must work there too, and records nothing
-    o3, _ = m.step(x[:, 0].contiguous(), caches)
+    o3, _ = m.step(x[:, 0].contiguous(), list(warm))
     assert torch.equal(o3, o2) and not o3.requires_grad
 
 
