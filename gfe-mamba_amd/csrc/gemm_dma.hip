@@ -34,11 +34,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
-constexpr int DBM = 256, DBN = 128, DBK = 64, DRING = 3;
+constexpr int DBN = 128, DBK = 64;
 constexpr int DCOMPUTE = 8, DLOADERS = 4, DTHREADS = (DCOMPUTE + DLOADERS) * 64;               // 8 compute waves + 4 loader waves
-constexpr int DA_BYTES = DBM * 128, DB_BYTES = DBN * 128, DSTAGE = DA_BYTES + DB_BYTES;      // 48 KB per ring slot, 144 KB in all
-constexpr int DA_PIECES = DBM / 8 / DLOADERS, DB_PIECES = DBN / 8 / DLOADERS;                 // 1 KiB pieces per LOADER wave and unit: 8 + 4
-constexpr int DNPW = DA_PIECES + DB_PIECES;
+constexpr int DB_BYTES = DBN * 128, DB_PIECES = DBN / 8 / DLOADERS;                            // B image of a unit: 16 KB, 4 pieces per loader wave
+
+// Two block shapes, by the number NJ of 16-column MFMA tiles a compute wave owns:
+//   NJ = 4: 256 x 128 block, waves 4 (M) x 2 (N), wave tile 64 x 64, 48 KB per unit, 3-slot ring (144 KB)   -- >= 2 tiles per CU
+//   NJ = 2: 128 x 128 block, waves 2 (M) x 4 (N), wave tile 64 x 32, 32 KB per unit, 4-slot ring (128 KB)   -- grids of 1.5 .. 4 tiles per
+//           CU (the 3-D ViT's N = 512 projections: 436 tiles), where the 256-row block would leave most CUs with ONE tile
+template <int NJ> struct Geo {
+    static constexpr int WN = DBN / (16 * NJ), WM = DCOMPUTE / WN;
+    static constexpr int BM = WM * 64, G = 16 * NJ;                  // rows per block, columns per wave
+    static constexpr int RING = NJ == 4 ? 3 : 4, AHEAD = RING - 1;   // ring slots, units in flight
+    static constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + DB_BYTES;
+    static constexpr int A_PIECES = BM / 8 / DLOADERS, NPW = A_PIECES + DB_PIECES;   // DMA instructions per loader wave and unit
+};
 
 struct DmaParams {
     const bf16_t* A; const bf16_t* B; void* C; const float* bias; const void* res;
@@ -110,8 +120,10 @@ __device__ unsigned long long g_gdma_stamps[32];
 // Timeline (tau = barrier intervals after the prologue; unit u): group 0 reads at 2u and multiplies at 2u+1; group 1 reads at 2u+1 and
 // multiplies at 2u+2; the loaders issue unit u+2 at 2u (its slot, (u+2) % 3 = (u-1) % 3, was last read at 2u-1) and wait at the end of
 // 2u+1 for unit u+1, which group 0 reads at 2u+2.  All twelve waves execute 2 U + 2 barriers.
-template <bool OUT_F32>
+template <bool OUT_F32, int NJ>
 __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p) {
+    typedef Geo<NJ> Gm;
+    constexpr int DBM = Gm::BM, DRING = Gm::RING, DA_BYTES = Gm::A_BYTES, DSTAGE = Gm::STAGE, DA_PIECES = Gm::A_PIECES, DNPW = Gm::NPW;
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,8 +151,8 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
 #pragma unroll
         for (int i = 0; i < DB_PIECES; ++i) {
             const int rho = 8 * (lw + DLOADERS * i) + (lane >> 3);                          // LDS row of the B image
-            const int g = rho >> 6, j = (rho >> 4) & 3, r = rho & 15;
-            b_row[i] = g * 64 + (r >> 2) * 16 + j * 4 + (r & 3);                             // the source row it holds (epilogue layout, see above)
+            const int g = rho / Gm::G, j = (rho % Gm::G) >> 4, r = rho & 15;
+            b_row[i] = g * Gm::G + (r >> 2) * (4 * NJ) + j * 4 + (r & 3);                    // the source row it holds (epilogue layout, see above)
         }
         unsigned pa[DA_PIECES], pb[DB_PIECES];
         int pf_t = t_first, pf_k = 0;
@@ -163,85 +175,87 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
 #endif
             if (++pf_k == nk) { pf_k = 0; pf_t += nbx; }
         };
-        issue_unit(0);
-        issue_unit(1);
-        // unit 0 landed (with fewer than two units in the block: everything)
-        if (U >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(DNPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        int s2 = 2;
+        // keep(n): wait until at most n UNITS' pieces of this wave are still in flight (everything older has landed), then the barrier
+        auto keep_barrier = [&](int n) {
+            if (n >= 2 && Gm::AHEAD >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * DNPW) : "memory");
+            else if (n >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(DNPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+#pragma unroll
+        for (int u = 0; u < Gm::AHEAD; ++u) issue_unit(u);             // prologue: AHEAD units in flight
+        keep_barrier(min(U, Gm::AHEAD) - 1);                           // unit 0 has landed
+        int s2 = Gm::AHEAD;
         for (int u = 0; u < U; ++u) {
-            issue_unit(s2);                                            // tau = 2u: unit u + 2
+            issue_unit(s2);                                            // tau = 2u: unit u + AHEAD, into the slot unit u - 1 was read from
             if (++s2 == DRING) s2 = 0;
             asm volatile("s_barrier" ::: "memory");
-            // tau = 2u + 1: unit u + 1 must have landed before the barrier; only unit u + 2's pieces (if any) may stay in flight
-            if (u + 2 < U) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(DNPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            // tau = 2u + 1: unit u + 1 must have landed before the barrier; the units behind it (up to AHEAD - 1 of them) stay in flight
+            keep_barrier(min(Gm::AHEAD - 1, max(0, U - (u + 2))));
         }
         asm volatile("s_barrier" ::: "memory");                        // tau = 2U: group 1's last matrix interval
         return;
     }
 
     // ======================================================================= compute waves
-    constexpr int NST = OUT_F32 ? 16 : 8;
-    (void)NST;
     const int lq = lane >> 4, lr = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / Gm::WN, wn = wave % Gm::WN;
     // fragment addresses (bytes inside a ring slot): lane constants; the k-half ks flips bit 6 of the chunk term
     const unsigned a_off = (unsigned)(wm * 64 + lr) * 128 + (unsigned)((lq ^ (lr & 7)) * 16);
-    const unsigned b_off = DA_BYTES + (unsigned)(wn * 64 + lr) * 128 + (unsigned)((lq ^ (lr & 7)) * 16);
+    const unsigned b_off = DA_BYTES + (unsigned)(wn * Gm::G + lr) * 128 + (unsigned)((lq ^ (lr & 7)) * 16);
     const __amdgpu_buffer_rsrc_t rsC = make_rsrc_b(p.C, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rsR = make_rsrc_b(p.res ? p.res : p.C, p.res ? p.res_bytes : 0u);
 
     // ---- the epilogue of a finished tile: lane holds C[m = m0 + wm*64 + i*16 + lr][n = n0 + wn*64 + lq*16 + (4 j + reg)], 16 consecutive
     // columns per i; it runs inside the NEXT tile's first read interval, i.e. beside the SIMD partner's matrix interval.
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
     auto epilogue = [&](int t) {
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-        const int nb = tn * DBN + wn * 64 + lq * 16;
-        float bv[16];
+        constexpr int NV = 4 * NJ;                                   // consecutive output columns of this lane: 16 or 8
+        const int nb = tn * DBN + wn * Gm::G + lq * NV;
+        float bv[NV];
         if (p.bias) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NJ; ++q) {
                 const float4 b4 = *reinterpret_cast<const float4*>(p.bias + nb + 4 * q);
                 bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) bv[q] = 0.f;
+            for (int q = 0; q < NV; ++q) bv[q] = 0.f;
         }
-        v4u_t rv[2][4];                                               // residual rows, requested one row tile ahead
-        auto res_load = [&](int i, v4u_t (&dst)[4]) {
+        v4u_t rv[2][NJ];                                               // residual rows, requested one row tile ahead
+        auto res_load = [&](int i, v4u_t (&dst)[NJ]) {
             const unsigned m = (unsigned)(tm * DBM + wm * 64 + i * 16 + lr);
             const unsigned ro = m * p.ldres_b + (unsigned)nb * (p.res_f32 ? 4u : 2u);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (p.res_f32 || q < 2) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ro + 16 * q, 0, 0);
+            for (int q = 0; q < NJ; ++q)
+                if (p.res_f32 || q < NJ / 2) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ro + 16 * q, 0, 0);
         };
         if (p.res) res_load(0, rv[0]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (p.res && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
             const unsigned m = (unsigned)(tm * DBM + wm * 64 + i * 16 + lr);
-            float v[16];
+            float v[NV];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bv[4 * j + r];
             if (p.act == 1) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = gelu_erf_fast(v[q]);
+                for (int q = 0; q < NV; ++q) v[q] = gelu_erf_fast(v[q]);
             }
             if (p.res) {
-                const v4u_t (&rr)[4] = rv[i & 1];
+                const v4u_t (&rr)[NJ] = rv[i & 1];
                 if (p.res_f32) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < NJ; ++q) {
                         v[4 * q] += __uint_as_float(rr[q].x); v[4 * q + 1] += __uint_as_float(rr[q].y);
                         v[4 * q + 2] += __uint_as_float(rr[q].z); v[4 * q + 3] += __uint_as_float(rr[q].w);
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < NJ / 2; ++q) {
                         const uint32_t w[4] = {rr[q].x, rr[q].y, rr[q].z, rr[q].w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[8 * q + 2 * e] += bf16lo_to_f32(w[e]); v[8 * q + 2 * e + 1] += bf16hi_to_f32(w[e]); }
@@ -251,14 +265,14 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
             if constexpr (OUT_F32) {
                 const unsigned co = m * p.ldc_b + (unsigned)nb * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NJ; ++q) {
                     const v4u_t d = {__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3])};
                     __builtin_amdgcn_raw_buffer_store_b128(d, rsC, co + 16 * q, 0, 0);
                 }
             } else {
                 const unsigned co = m * p.ldc_b + (unsigned)nb * 2;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < NJ / 2; ++q) {
                     const v4u_t d = {pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
                                      pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7])};
                     __builtin_amdgcn_raw_buffer_store_b128(d, rsC, co + 16 * q, 0, 0);
@@ -287,15 +301,15 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             GD_STAMP(0)
             const uint8_t* st = smem + slot * DSTAGE;
-            bf16x8 af[2][4], bfr[2][4];
+            bf16x8 af[2][4], bfr[2][NJ];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(st + (b_off ^ (ks * 64)) + j * 2048);
+                for (int j = 0; j < NJ; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(st + (b_off ^ (ks * 64)) + j * 2048);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(st + (a_off ^ (ks * 64)) + i * 2048);
             }
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
 #if defined(GFE_GDMA_EXP_NOMFMA)           // timing experiment only (wrong results): fragment reads stay live, no matrix instructions
                         asm volatile("" :: "v"(bfr[ks][j]), "v"(af[ks][i]));
 #else
@@ -340,14 +354,34 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
 
 }  // namespace
 
+static int dma_num_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
+// Block shape for a problem: 4 = 256 x 128 blocks, 2 = 128 x 128 blocks, 0 = not this kernel.  The persistent unit stream needs tiles to
+// pipeline: >= 2 tiles of 256 rows per CU take the big block (fewer operand bytes per flop); grids that would leave most CUs with one
+// such tile (the 3-D ViT's N = 512 projections: 220 tiles on 256 CUs ran 34 / 64 us against gemm_nt_kernel's 26 / 54) take the 128-row
+// block when that gives >= 1.5 tiles per CU; anything smaller stays on gemm_nt_kernel (two 4-wave blocks per CU hide each other's
+// latencies there).  GFE_GEMM_DMA_ALL=1 lifts the size rule (tests / A-B runs), GFE_GEMM_DMA_NJ=2|4 forces a shape.
+static int dma_shape(const GemmDmaArgs& a) {
+    const int64_t ncu = dma_num_cus();
+    const int64_t t256 = ceil_div(a.M, 256) * (a.N / DBN), t128 = ceil_div(a.M, 128) * (a.N / DBN);
+    if (const char* e = getenv("GFE_GEMM_DMA_NJ")) { if (e[0] == '2') return 2; if (e[0] == '4') return 4; }
+    if (t256 >= 2 * ncu) return 4;
+    if (2 * t128 >= 3 * ncu) return 2;
+    return getenv("GFE_GEMM_DMA_ALL") ? (t256 >= ncu ? 4 : 2) : 0;
+}
+
 bool gemm_dma_usable(const GemmDmaArgs& a) {
     if (getenv("GFE_GEMM_NO_DMA")) return false;                                   // A/B switch for measurements
     if (a.M < 512 || a.N % DBN != 0 || a.K % DBK != 0 || a.K < DBK) return false;  // skinny M: the split-K kernel streams the weights better
-    // Two or more 256 x 128 tiles per CU, or the persistent stream has nothing to pipeline: with 220 tiles on 256 CUs (the 3-D ViT's
-    // N = 512 projections) most blocks run ONE tile -- fill latency, 8-32 units and the f32 residual epilogue back to back -- and
-    // gemm_nt_kernel's 436 half-size blocks at two per CU are faster (26 vs 34 us, 54 vs 64 us: tools/gemm_bench.py).  GFE_GEMM_DMA_ALL=1
-    // lifts the rule for measurements.
-    if ((int64_t)ceil_div(a.M, DBM) * (a.N / DBN) < 512 && !getenv("GFE_GEMM_DMA_ALL")) return false;
+    if (dma_shape(a) == 0) return false;
     if (a.lda % 8 || a.ldb % 8) return false;
     if (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) % 16) return false;
     const int64_t esz = a.out_f32 ? 4 : 2;
@@ -368,6 +402,19 @@ extern "C" int gfe_dbg_gdma_stamps(unsigned long long* host_out) { return hipMem
 static int g_dma_launches = 0;
 extern "C" int gfe_gemm_dma_launches(void) { return g_dma_launches; }
 
+template <bool OUT_F32, int NJ>
+static int dma_launch_t(DmaParams& p, const GemmDmaArgs& a, hipStream_t st) {
+    typedef Geo<NJ> Gm;
+    p.ntiles = (int)ceil_div(a.M, Gm::BM) * p.tiles_n;
+    const int ncu = dma_num_cus();
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    constexpr size_t lds = (size_t)Gm::RING * Gm::STAGE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<OUT_F32, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((gemm_dma_kernel<OUT_F32, NJ>), dim3((unsigned)grid), dim3(DTHREADS), lds, st, p);
+    return gfe_launch_status();
+}
+
 int gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
     ++g_dma_launches;
     DmaParams p;
@@ -380,24 +427,8 @@ int gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
     p.res_bytes = a.res ? (unsigned)((int64_t)(a.M - 1) * a.ldres * rsz + (int64_t)a.N * rsz) : 0u;
     p.M = a.M; p.N = a.N; p.K = a.K; p.nk = a.K / DBK;
     p.tiles_n = a.N / DBN;
-    const int tiles_m = (int)ceil_div(a.M, DBM);
-    p.ntiles = tiles_m * p.tiles_n;
     p.res_f32 = a.res_f32; p.act = a.act;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
-    constexpr size_t lds = (size_t)DRING * DSTAGE;
-    static bool attr[2] = {false, false};
-    if (a.out_f32) {
-        if (!attr[1]) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = true; }
-        hipLaunchKernelGGL((gemm_dma_kernel<true>), dim3((unsigned)grid), dim3(DTHREADS), lds, st, p);
-    } else {
-        if (!attr[0]) { (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = true; }
-        hipLaunchKernelGGL((gemm_dma_kernel<false>), dim3((unsigned)grid), dim3(DTHREADS), lds, st, p);
-    }
-    return gfe_launch_status();
+    const int nj = dma_shape(a);
+    if (nj == 4) return a.out_f32 ? dma_launch_t<true, 4>(p, a, st) : dma_launch_t<false, 4>(p, a, st);
+    return a.out_f32 ? dma_launch_t<true, 2>(p, a, st) : dma_launch_t<false, 2>(p, a, st);
 }

@@ -11,7 +11,7 @@ import torch
 from . import call, dtype_code, ptr, stream
 from . import nn_ops as K
 from .scan_ops import sscan2_det_ws, sscan2_plan
-from .train_ops import _grad_slot
+from .train_ops import _grad_slot, _leaf
 
 F32 = torch.float32
 
@@ -82,8 +82,8 @@ class _MambaBlockFn(torch.autograd.Function):
 
         def wgrad(param, a, b):            # param.grad (+)= a^T b, both operands read reduction-major
             slot = _grad_slot(param)
-            if slot is not None:
-                K.gemm_f32(a, True, b, True, accum_into=slot.view(slot.shape[0], -1))
+            if slot is not None:             # a leaf of the backward chain: on the side stream inside train_ops.side_wgrads()
+                _leaf(lambda: K.gemm_f32(a, True, b, True, accum_into=slot.view(slot.shape[0], -1)), slot, a, b)
                 return None
             return K.gemm_f32(a, True, b, True).view(param.shape)
 

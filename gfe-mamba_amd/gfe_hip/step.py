@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from .head_ops import bce_sigmoid
-from .train_ops import Condition, FlatAdam
+from .train_ops import Condition, FlatAdam, side_wgrads
 
 
 def dp_mean_scale(world_size):
@@ -123,7 +123,8 @@ class ClassifyStep:
                 mid_feature = self.head(hin[4], hin[5])
                 pred = self.ft(hin[1], hin[2], mid_feature, Condition([hin[0], hin[6]]))
                 loss = bce_sigmoid(pred.squeeze(1), hin[3])
-                loss.backward()
+                with side_wgrads():                                # weight gradients beside the chain, joined before the region ends
+                    loss.backward()
                 return loss.detach()
 
             Hd.set_dropout_step_counter(self._drop_ctr)
@@ -176,7 +177,8 @@ class ClassifyStep:
                 mid_feature = self.head(mid_input, mid_output)
                 pred = self.ft(x_cat, x_num, mid_feature, Condition([x, pet]))
                 loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
-                loss.backward()
+                with side_wgrads():
+                    loss.backward()
             self.opt.step(self.world_size, self.group)
             self._head_done = torch.cuda.Event()
             self._head_done.record(H)
@@ -199,7 +201,8 @@ class ClassifyStep:
         self.head.train(); self.ft.train()
         pred, _ = self.forward(x, x_cat, x_num, _before_head=self.opt.zero_grad)   # optimizer.zero_grad() (:109), moved behind the frozen generator
         loss = bce_sigmoid(pred.squeeze(1), y)                                     # :104
-        loss.backward()                                                            # :105
+        with side_wgrads():                                                        # (weight gradients on a second stream, joined before the optimizer)
+            loss.backward()                                                        # :105
         self.opt.step(self.world_size, self.group, overlap=self.overlap_update)   # all-reduce, clip (:106-107), Adam (:108)
         return loss.detach()
 
@@ -221,7 +224,8 @@ class ClassifyStep:
                 self.opt.zero_grad()
                 pred, _ = self.forward(self._gin[0], self._gin[1], self._gin[2])
                 loss = bce_sigmoid(pred.squeeze(1), self._gin[3])
-                loss.backward()
+                with side_wgrads():
+                    loss.backward()
                 return loss.detach()
 
             side = torch.cuda.Stream()

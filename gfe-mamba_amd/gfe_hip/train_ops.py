@@ -41,6 +41,50 @@ def _grad_slot(param):
     return g
 
 
+# ---- weight gradients off the backward's critical chain -------------------------------------------------------------------------------
+# The head's backward is a chain of ~150 small dependent launches; in the two-stream step each of them waits for a hole between the frozen
+# generator's persistent conv launches, so the chain's LENGTH is what the step pays.  A weight gradient dW = dy^T x is a
+# leaf of that chain -- nothing in the backward reads it, only the optimizer -- so inside `side_wgrads()` every weight-gradient GEMM whose
+# target is one of the optimizer's own gradient slots is enqueued on a second stream (forked behind its operands' producers, joined
+# before the optimizer): ~35 launches per step leave the chain and run beside it.  Same kernels, same arguments, same results (each slot
+# has one writer; the fixed-order split-K sums are unchanged).  Operands are kept alive until the join, so their memory cannot be handed
+# to a later allocation of the main stream while the side stream still reads it; capturable (fork / join inside the captured region).
+class _Side:
+    on = False
+    stream = None
+    keep = []
+
+
+class side_wgrads:
+    def __enter__(self):
+        if _Side.stream is None:
+            _Side.stream = torch.cuda.Stream()
+        _Side.on = True
+        return self
+
+    def join(self):
+        if _Side.keep:
+            torch.cuda.current_stream().wait_stream(_Side.stream)
+            _Side.keep.clear()
+
+    def __exit__(self, *exc):
+        self.join()
+        _Side.on = False
+        return False
+
+
+def _leaf(fn, slot, *operands):
+    """Run fn() -- a weight-gradient launch accumulating into `slot` -- on the side stream when that is safe (see side_wgrads), else here."""
+    import os
+    if not _Side.on or slot is None or os.environ.get("GFE_NO_SIDE_WGRAD") == "1":
+        return fn()
+    _Side.stream.wait_stream(torch.cuda.current_stream())        # behind everything that produced the operands (and earlier adds to the slot)
+    with torch.cuda.stream(_Side.stream):
+        fn()
+    _Side.keep.extend(operands)
+    return None
+
+
 def _gemm(a16, b16, bias=None):
     """(M, K) x (N, K)^T -> (M, N) f32; zero-pads K to a multiple of 8 and N to a multiple of 4 (tiny test widths only)."""
     Kd, N = a16.shape[1], b16.shape[0]
@@ -107,7 +151,7 @@ class _LinearFn(torch.autograd.Function):
                 dx = K.gemm_f32(d32, False, weight.detach(), True).reshape(xs).to(xdt)    # dy (M, N) . W (N, K) read reduction-major
             if ctx.needs_input_grad[1]:
                 slot = _grad_slot(ctx.w_ref)
-                dw = K.gemm_f32(d32, True, xin, True, accum_into=slot)                     # dy^T . x, both read reduction-major
+                dw = _leaf(lambda: K.gemm_f32(d32, True, xin, True, accum_into=slot), slot, d32, xin)   # dy^T . x, both read reduction-major
                 dw = None if slot is not None else dw.to(weight.dtype)
         elif fast and K._ex_ok(d32):
             if ctx.needs_input_grad[0]:
@@ -115,9 +159,9 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 slot = _grad_slot(ctx.w_ref)                                              # accumulate straight into weight.grad
                 if xT16 is not None and K._ex_ok(xT16):
-                    dw = K.gemm_ex(d32, True, xT16, False, accum_into=slot)               # dy^T . (K, M)^T
+                    dw = _leaf(lambda: K.gemm_ex(d32, True, xT16, False, accum_into=slot), slot, d32, xT16)   # dy^T . (K, M)^T
                 else:
-                    dw = K.gemm_ex(d32, True, xin, True, accum_into=slot)                 # dy^T . x, both read reduction-major
+                    dw = _leaf(lambda: K.gemm_ex(d32, True, xin, True, accum_into=slot), slot, d32, xin)      # dy^T . x, both read reduction-major
                 dw = None if slot is not None else dw.to(weight.dtype)
         else:
             x16 = xin if xin.dtype == BF16 else K.cast(xin, BF16)
@@ -131,7 +175,7 @@ class _LinearFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             slot = _grad_slot(ctx.bias_ref)
             db = slot if slot is not None else torch.empty(N, dtype=torch.float32, device=d32.device)
-            call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), int(slot is not None), stream())
+            _leaf(lambda: call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), int(slot is not None), stream()), slot, d32)
             if slot is not None:
                 db = None
         return dx, dw, db, None, None, None

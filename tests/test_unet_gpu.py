@@ -49,15 +49,17 @@ def test_gemm_epilogues_and_splitk():
     assert torch.equal(K.cast(f, BF), f.to(BF)) and torch.equal(K.cast(f.to(BF), torch.float32), f.to(BF).float())
 
 
+@pytest.mark.parametrize("nj", [4, 2])
 @pytest.mark.parametrize("M,N,K_", [(512, 128, 64), (1000, 256, 128), (2085, 512, 512), (777, 384, 1024), (13832, 1536, 512), (4099, 512, 2048), (600, 2048, 192)])
-def test_gemm_dma_main_loop(M, N, K_, monkeypatch):
+def test_gemm_dma_main_loop(M, N, K_, nj, monkeypatch):
     """The persistent LDS-DMA main loop (csrc/gemm_dma.hip; every nn.Linear forward of the inference pipelines, vit_3d.py:41-46, 50): ragged
     last row tile, one-unit tiles (K = 64), every epilogue (bias, exact-erf GELU, f32 / bf16 residual, f32 / bf16 output), a strided A view
     (the q block of a qkv buffer) and a strided C, against an f64 product of the same bf16 operands -- and bit-identical to itself on a
     second run (the unit stream crosses tile boundaries with counted waits: a mis-count would show as rare wrong tiles)."""
     import gfe_hip
     from gfe_hip import nn_ops as K
-    monkeypatch.setenv("GFE_GEMM_DMA_ALL", "1")             # (the dispatch keeps shapes with < 2 tiles per CU on gemm_nt_kernel: a speed rule)
+    monkeypatch.setenv("GFE_GEMM_DMA_ALL", "1")             # (the dispatch keeps small grids on gemm_nt_kernel: a speed rule)
+    monkeypatch.setenv("GFE_GEMM_DMA_NJ", str(nj))          # both block shapes: 256 x 128 (wave tiles 64 x 64) and 128 x 128 (64 x 32)
     g = torch.Generator().manual_seed(M + N + K_)
     wide = torch.randn(M, K_ + 64, generator=g).to(BF).to(DEV)
     a = wide[:, 32:32 + K_]                                           # row stride K + 64, 64-byte offset

@@ -45,17 +45,21 @@ for name, N, Kd, o in shapes:
     res = torch.randn(m, N, generator=g).cuda() if o.get("res") else None
     out = torch.empty(m, N, dtype=torch.float32 if o.get("f32") else BF, device="cuda")
     fn = lambda: K.gemm_nt(a, b, bias=bias, res=res, act=o.get("act", 0), out=out)
-    t = {"dma": [], "old": []}
+    arms = ("dma256", "dma128", "old")
+    t = {a_: [] for a_ in arms}
     for _ in range(rounds):
-        for arm in ("dma", "old"):
+        for arm in arms:
+            os.environ.pop("GFE_GEMM_NO_DMA", None)
+            os.environ.pop("GFE_GEMM_DMA_NJ", None)
             if arm == "old":
                 os.environ["GFE_GEMM_NO_DMA"] = "1"
             else:
-                os.environ.pop("GFE_GEMM_NO_DMA", None)
+                os.environ["GFE_GEMM_DMA_NJ"] = "4" if arm == "dma256" else "2"
             t[arm].append(timeit(fn))
     os.environ.pop("GFE_GEMM_NO_DMA", None)
+    os.environ.pop("GFE_GEMM_DMA_NJ", None)
     fl = 2.0 * m * N * Kd
-    for arm in ("dma", "old"):
+    for arm in arms:
         v = sorted(t[arm])
         med = v[len(v) // 2]
         print("%s M=%5d N=%4d K=%4d %s: median %7.1f us (min %7.1f)  %6.0f TFLOP/s = %.3f of peak" % (name, m, N, Kd, arm, med, v[0], fl / med / 1e6, fl / med / 1e6 / 2500))
