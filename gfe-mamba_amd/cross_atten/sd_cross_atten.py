@@ -42,16 +42,23 @@ class CrossAttention(nn.Module):
         self.n_heads = n_heads
         self.d_head = d_embed // n_heads
 
-    def forward(self, x, y):
-        """x: (B, Lq, d_embed); y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition.  sd_cross_atten.py:49-70."""
-        b, lq, d = x.shape
-        q = self.q_proj(x)
+    def project_kv(self, y):
+        """k, v = k_proj(y), v_proj(y) (sd_cross_atten.py:52-53) for y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition; they do not
+        depend on the queries, so a caller may compute them early, beside the token stack (Cross_mamba_both.forward)."""
         if isinstance(y, Condition):
             a16, aT16 = y.cond.view(-1, y.d_cross), y.condT
-            k = linear(a16, self.k_proj.weight, self.k_proj.bias, x16=a16, xT16=aT16).view(b, y.keys, d)
-            v = linear(a16, self.v_proj.weight, self.v_proj.bias, x16=a16, xT16=aT16).view(b, y.keys, d)
-        else:
-            k, v = self.k_proj(y), self.v_proj(y)
+            d = self.k_proj.weight.shape[0]
+            k = linear(a16, self.k_proj.weight, self.k_proj.bias, x16=a16, xT16=aT16).view(y.B, y.keys, d)
+            v = linear(a16, self.v_proj.weight, self.v_proj.bias, x16=a16, xT16=aT16).view(y.B, y.keys, d)
+            return k, v
+        return self.k_proj(y), self.v_proj(y)
+
+    def forward(self, x, y, kv=None):
+        """x: (B, Lq, d_embed); y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition (kv: project_kv(y) computed earlier).
+        sd_cross_atten.py:49-70."""
+        b, lq, d = x.shape
+        q = self.q_proj(x)
+        k, v = kv if kv is not None else self.project_kv(y)
         if lq != 1:
             raise NotImplementedError("CrossAttention on the HIP path takes ONE query per sample (gfe_cross_attn_q1: every call of the reference, "
                                       f"mamba_transformer.py:124-126); got {lq} queries -- no torch-math fallback is kept")

@@ -121,7 +121,7 @@ class ClassifyStep:
                 self._drop_ctr.add_(1)
                 self.opt.zero_grad()
                 mid_feature = self.head(hin[4], hin[5])
-                pred = self.ft(hin[1], hin[2], mid_feature, Condition([hin[0], hin[6]]))
+                pred = self.ft(hin[1], hin[2], mid_feature, [hin[0], hin[6]])          # (the condition is built inside, beside the token stack)
                 loss = bce_sigmoid(pred.squeeze(1), hin[3])
                 with side_wgrads():                                # weight gradients beside the chain, joined before the region ends
                     loss.backward()
@@ -175,7 +175,7 @@ class ClassifyStep:
             else:
                 self.opt.zero_grad()
                 mid_feature = self.head(mid_input, mid_output)
-                pred = self.ft(x_cat, x_num, mid_feature, Condition([x, pet]))
+                pred = self.ft(x_cat, x_num, mid_feature, [x, pet])
                 loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
                 with side_wgrads():
                     loss.backward()
@@ -194,7 +194,7 @@ class ClassifyStep:
         if _before_head is not None:
             _before_head()
         mid_feature = self.head(mid_input, mid_output)                             # :102
-        pred = self.ft(x_cat, x_num, mid_feature, Condition([x, pet]))             # :103
+        pred = self.ft(x_cat, x_num, mid_feature, [x, pet])             # :103
         return pred, (mid_input, mid_output, pet)
 
     def train_step(self, x, x_cat, x_num, y):

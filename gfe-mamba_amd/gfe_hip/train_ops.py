@@ -73,6 +73,41 @@ class side_wgrads:
         return False
 
 
+class aux_region:
+    """`with aux_region() as r:` runs its body on the side stream, forked behind everything the current stream has been given so far;
+    `r.join()` (later, on the forking stream) makes that stream wait for it.  For work at the START of a forward that the main chain needs
+    only near its end -- the image condition and its K / V projections (mamba_transformer.py:89-94, sd_cross_atten.py:52-53), which the
+    Mamba stack does not read: 8 launches that the chain then does not wait for.  Autograd runs their backward on the same side stream
+    (the engine replays a node on its forward's stream and orders the streams itself).  GFE_NO_SIDE_WGRAD=1 keeps everything on one stream."""
+
+    def __init__(self):
+        import os
+        # not while a HIP graph is being captured: forking a second stream in the captured FORWARD made this ROCm's capture_end segfault
+        # (whole-step capture, tests/test_head_gpu.py::test_graphed_step_matches_eager_step; the backward's fork -- side_wgrads -- captures
+        # fine).  GFE_AUX_IN_CAPTURE=1 lifts the guard for experiments.
+        self.on = (torch.cuda.is_available() and os.environ.get("GFE_NO_SIDE_WGRAD") != "1"
+                   and (not torch.cuda.is_current_stream_capturing() or os.environ.get("GFE_AUX_IN_CAPTURE") == "1"))
+
+    def __enter__(self):
+        if self.on:
+            if _Side.stream is None:
+                _Side.stream = torch.cuda.Stream()
+            self.main = torch.cuda.current_stream()
+            _Side.stream.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(_Side.stream)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            torch.cuda.current_stream().wait_stream(_Side.stream)
+
+
 def _leaf(fn, slot, *operands):
     """Run fn() -- a weight-gradient launch accumulating into `slot` -- on the side stream when that is safe (see side_wgrads), else here."""
     import os
@@ -358,6 +393,9 @@ class Condition:
         for i, img in enumerate(images):
             assert img.shape[1] == 1, "condition images are single-channel"
             src = img.detach().float().contiguous()
+            if src.is_cuda and not torch.cuda.is_current_stream_capturing():
+                src.record_stream(torch.cuda.current_stream())          # the condition may be built on the side stream (aux_region); under
+                                                                        # capture the inputs are the graph's own static buffers
             call("gfe_transpose_f32_to_bf16", ptr(src), self.cond.data_ptr() + i * D3 * HW * 2, B, HW, D3, n * D3 * HW, HW, stream())
             call("gfe_interleave_rows_bf16", ptr(src), ptr(self.condT), B, HW, D3, B * n * D3, n * D3, i * D3, stream())
 
