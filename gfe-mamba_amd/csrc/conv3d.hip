@@ -732,7 +732,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 // so that the grouping of the partial sums -- and with it every rounding of the statistics -- is a function of the
                 // sample alone: a volume comes out bit-identical whatever batch it rides in (round 2 flushed per run of a block's tiles,
                 // which depends on B: batch 8 differed from batch 1 by 1e-2 of the maximum after twelve layers of flipped bf16 roundings).
-                const bool flush = !next_unit || p.ngroups > 1 || nxt.b != cur.b || nxt.td != cur.td || nxt.th != cur.th || nxt.tw != cur.tw;
+                // Multi-class launches (MC) flush per (tile, class): a block's item range may end inside a tile's classes, so a slot per
+                // tile would be written by two blocks (with <= 256 items every class was its own block and seven eighths of the
+                // sums were lost); rounding the ranges to whole tiles instead cost the parallelism of small launches (27 blocks at batch 1).
+                const bool flush = !next_unit || p.ngroups > 1 || nxt.b != cur.b || nxt.td != cur.td || nxt.th != cur.th || nxt.tw != cur.tw ||
+                                   (MC && nxt.cls != cur.cls);
                 if (flush) {
                     // 16 voxel lanes of a DPP row -> one value; 8 d-plane waves -> LDS; one plain store per (slot, channel, stat)
 #pragma unroll
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                         const int st = tid / WROWS_TAP, c = group * WROWS_TAP + (tid - st * WROWS_TAP);
                         // slot = tile index inside the sample (x class for the multi-group transposed conv, which flushes per class)
                         const int tix = (cur.td * p.nth + cur.th) * p.ntw + cur.tw;
-                        const int slot = p.stats_slot0 + (p.ngroups == 1 ? tix : (MC ? tix * p.ncls + cur.cls : tix));
+                        const int slot = p.stats_slot0 + (MC ? tix * p.ncls + cur.cls : tix);
                         if (c < p.Cout) p.stats[(((size_t)b * p.stats_nblk + slot) * 2 + st) * p.Cout + c] = t;
                     }
                 }
@@ -914,9 +918,6 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     // with the ticket scheduler the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream
     const int nblk = (q.sched && NBLK == 256) ? NBLK - conv_reserved_cus() : NBLK;
     q.tiles_per_block = (int)ceil_div(tiles, nblk);
-    // multi-class work lists keep a tile's classes in ONE block: the GroupNorm partials of a tile have one slot, written by the block that
-    // finishes the tile's last class (a range that ended inside a tile made two blocks store to the same slot: ADVICE r03)
-    if (MC) q.tiles_per_block = (int)(ceil_div(q.tiles_per_block, p.ncls) * p.ncls);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NT, TPS, REG27, STATS, MC, RES1, OUT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -939,8 +940,8 @@ int gfe_convt3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t C
     (void)B;
     const int64_t tps = gfe_conv3d_tiles(D, H, W);
     if (gfe_conv3d_cout_pad(Cout) > 64) return (int)(tps * 8);                // (tile, class) slots
-    const int slots_res = convt_resident_tiles(D, H, W);                      // one slot per tile of a sample, of either kernel's
-    return (int)tps > slots_res ? (int)tps : slots_res;                       // tile grid (the dispatch depends on Cin)
+    const int slots_res = convt_resident_tiles(D, H, W);                      // the resident kernel: one slot per tile of ITS tile grid;
+    return (int)(tps * 8) > slots_res ? (int)(tps * 8) : slots_res;           // the streamed multi-class kernel: (tile, class) slots (the dispatch depends on Cin)
 }
 
 #if defined(GFE_EXP_STAMP)
