@@ -111,7 +111,10 @@ class aux_region:
 def _leaf(fn, slot, *operands):
     """Run fn() -- a weight-gradient launch accumulating into `slot` -- on the side stream when that is safe (see side_wgrads), else here."""
     import os
-    if not _Side.on or slot is None or os.environ.get("GFE_NO_SIDE_WGRAD") == "1":
+    # Not inside a HIP-graph capture: a captured fork / join replays SLOWER than the straight chain on this ROCm (B = 8, head graph: 688 vs
+    # 708 volumes/s; B = 1: 283 vs 300) -- the eager step is where the side stream pays (706 -> 722).
+    if (not _Side.on or slot is None or os.environ.get("GFE_NO_SIDE_WGRAD") == "1"
+            or (torch.cuda.is_current_stream_capturing() and os.environ.get("GFE_AUX_IN_CAPTURE") != "1")):
         return fn()
     _Side.stream.wait_stream(torch.cuda.current_stream())        # behind everything that produced the operands (and earlier adds to the slot)
     with torch.cuda.stream(_Side.stream):
