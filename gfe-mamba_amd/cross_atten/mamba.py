@@ -4,8 +4,9 @@ and state-dict keys (in_proj, conv1d, x_proj, dt_proj, A_log, D, out_proj, norm)
 
 MambaBlock.forward always takes the fused route the reference only reaches through its optional `selective_scan_fn`
 plug-in (mamba.py:243-252): softplus(delta + dt_proj.bias), the scan, D*x and the y*silu(z) gate run in one HIP kernel
-(gfe-mamba_amd/csrc/sscan.hip) in the token-major layout, so the four transposes of mamba.py:245-252 disappear.
-Projections run on the bf16 MFMA GEMM.  `config.pscan` / `config.use_cuda` are accepted and ignored (one path).
+(gfe-mamba_amd/csrc/sscan2.hip for d_state 16, sscan.hip for 4 / 8) in the token-major layout, so the four transposes of mamba.py:245-252
+disappear.  Projections run on the exact-f32 MFMA GEMM (gfe_gemm_f32: the reference trains the head in fp32, classify_mamba.py:69-74); the whole
+block is one autograd node (gfe_hip/mamba_block.py).  `config.pscan` / `config.use_cuda` are accepted and ignored (one path).
 """
 import math
 import os

@@ -423,6 +423,8 @@ def gemm_f32(a, a_t, b, b_t, bias=None, accum_into=None):
     # until ~1024 blocks are in flight, keeping >= 2 k-steps per block and the partial traffic (output bytes x splits) below ~8 MB
     blocks32 = -(-M // 32) * -(-N // 32)
     split_k = max(1, min(8, K // 256, 1024 // blocks32, (8 << 20) // max(1, 4 * M * N)))
+    if os.environ.get("GFE_F32_SPLITK_MAX"):                # experiments: cap the cut (1 = no split-K, no reduction launch)
+        split_k = min(split_k, int(os.environ["GFE_F32_SPLITK_MAX"]))
     if accum_into is not None:
         assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and unit(accum_into) and bias is None
         out = accum_into

@@ -10,7 +10,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def measured_traffic(key, rel=("profiles", "r01", "traffic_v13.json")):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v13.json, profiles/r03/traffic_r03.json:
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v13.json, profiles/r04/traffic_r04.json:
     FETCH_SIZE x2 as the gfx950 correction prescribes + WRITE_SIZE, separate passes); None when the file does not travel with the tree."""
     import json
     import os
@@ -92,8 +92,8 @@ class StepWorkload:
         flops = 2.0 * 27 * 64 * 64 * self.batch * self.vol[0] * self.vol[1] * self.vol[2]
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r03", "traffic_r03.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if (self.batch == 8 and self.vol_tag == "96^3") else None,
-                "traffic_source": "profiles/r03/traffic_r03.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r04", "traffic_r04.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "traffic_source": "profiles/r04/traffic_r04.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
                 "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @%s, ReLU): the launch the step makes three times per "
                           "forward (encoders.0 conv3, decoders.1 conv2 / conv3), timed alone on operands built from encoders.0's lifted tensor and "
                           "conv2 weights -- the step itself collapses encoders.0 conv2 to a one-channel conv (DESIGN 4.1)" % self.vol_tag,
