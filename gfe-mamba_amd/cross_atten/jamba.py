@@ -10,7 +10,7 @@ Cached decoding (Jamba.step, jamba.py:298-306: a KV cache per attention layer in
 conv window + SSM state per Mamba layer) runs one token per call on the step kernels and the one-query attention kernel.
 Not built: the language-model wrapper JambaLM / from_pretrained (never used by the GFE-Mamba scripts)."""
 import math
-from dataclasses import dataclass
+from dataclasses import dataclass, fields
 from typing import Union
 
 import torch
@@ -66,11 +66,9 @@ class JambaLMConfig:
         self.d_inner = self.expand_factor * self.d_model
         if self.dt_rank == 'auto':
             self.dt_rank = math.ceil(self.d_model / 16)
-        self.mamba_config = MambaConfig(d_model=self.d_model, n_layers=0, dt_rank=self.dt_rank, d_state=self.d_state,
-                                        expand_factor=self.expand_factor, d_conv=self.d_conv, dt_min=self.dt_min, dt_max=self.dt_max,
-                                        dt_init=self.dt_init, dt_scale=self.dt_scale, rms_norm_eps=self.rms_norm_eps,
-                                        bias=self.bias, conv_bias=self.conv_bias, inner_layernorms=self.inner_layernorms,
-                                        pscan=self.pscan, use_cuda=self.use_cuda)
+        # the mixer's own record takes every field the two dataclasses share (jamba.py:89-95 passes them one by one); n_layers is unused there
+        shared = {f.name for f in fields(MambaConfig)} & {f.name for f in fields(self)} - {"n_layers"}
+        self.mamba_config = MambaConfig(n_layers=0, **{name: getattr(self, name) for name in sorted(shared)})
 
 
 class Jamba(nn.Module):
@@ -102,20 +100,35 @@ class Jamba(nn.Module):
         return x, caches
 
 
-class AttentionLayer(nn.Module):
-    def __init__(self, config: JambaLMConfig, num_experts: int):
+class _MixerThenMoE(nn.Module):
+    """What the two layer kinds share (jamba.py:308-340, 400-439): pre-norm token mixer + residual, pre-norm (routed) MLP + residual.
+    Sub-module names are the reference's, so state dicts load either way."""
+
+    def __init__(self, config: JambaLMConfig, num_experts: int, mixer_name: str, mixer: nn.Module):
         super().__init__()
-        self.self_attn = AttentionSDPA(config)
-        num_experts_per_tok = config.num_experts_per_tok if num_experts > 1 else 1
-        self.moe = SparseMoEBlock(config, num_experts=num_experts, num_experts_per_tok=num_experts_per_tok)
-        self.input_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
-        self.pre_moe_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
+        self.config = config
+        self.add_module(mixer_name, mixer)
+        top_k = config.num_experts_per_tok if num_experts > 1 else 1                # a single expert is not routed
+        self.moe = SparseMoEBlock(config, num_experts=num_experts, num_experts_per_tok=top_k)
+        for name in ("input_layernorm", "pre_moe_layernorm"):
+            self.add_module(name, RMSNorm(config.d_model, eps=config.rms_norm_eps))
+
+    def mix(self, n, cache):
+        raise NotImplementedError
 
     def forward(self, x, cache=None):
-        a, cache = self.self_attn(self.input_layernorm(x), cache)                # jamba.py:325-329
-        x = x + a
-        h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # :332-335
+        m, cache = self.mix(self.input_layernorm(x), cache)
+        x = x + m
+        h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # jamba.py:332-335, 428-431
         return (x + h, router_logits), cache
+
+
+class AttentionLayer(_MixerThenMoE):
+    def __init__(self, config: JambaLMConfig, num_experts: int):
+        super().__init__(config, num_experts, "self_attn", AttentionSDPA(config))
+
+    def mix(self, n, cache):
+        return self.self_attn(n, cache)                                          # jamba.py:325-329
 
     def get_empty_cache(self, batch_size, device):
         return (None, None)                                                      # jamba.py:340-341
@@ -171,26 +184,15 @@ class AttentionSDPA(nn.Module):
         return self.o_proj(o), cache
 
 
-class MambaLayer(nn.Module):
+class MambaLayer(_MixerThenMoE):
     def __init__(self, config: JambaLMConfig, num_experts: int):
-        super().__init__()
-        self.config = config
-        self.mamba = MambaBlock(config=config.mamba_config)
-        num_experts_per_tok = config.num_experts_per_tok if num_experts > 1 else 1
-        self.moe = SparseMoEBlock(config, num_experts=num_experts, num_experts_per_tok=num_experts_per_tok)
-        self.input_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
-        self.pre_moe_layernorm = RMSNorm(config.d_model, eps=config.rms_norm_eps)
+        super().__init__(config, num_experts, "mamba", MambaBlock(config=config.mamba_config))
 
-    def forward(self, x, cache=None):
-        n = self.input_layernorm(x)
+    def mix(self, n, cache):
         if cache is None:
-            m = self.mamba(n)                                                    # jamba.py:418-420
-        else:
-            m, cache = self.mamba.step(n.squeeze(1), cache)                      # :421-423, single token on the step kernels (mamba.py:342-405)
-            m = m.unsqueeze(1)
-        x = x + m
-        h, router_logits = self.moe(self.pre_moe_layernorm(x))                   # :428-431
-        return (x + h, router_logits), cache
+            return self.mamba(n), None                                           # jamba.py:418-420
+        m, cache = self.mamba.step(n.squeeze(1), cache)                          # :421-423, single token on the step kernels (mamba.py:342-405)
+        return m.unsqueeze(1), cache
 
     def get_empty_cache(self, batch_size, device):
         return (None, torch.zeros(batch_size, self.config.d_inner, self.config.d_conv - 1, device=device))   # jamba.py:438-439

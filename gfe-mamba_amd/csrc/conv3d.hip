@@ -915,8 +915,9 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
     q.sched = MC ? nullptr : conv_sched_slot(st);
-    // with the ticket scheduler the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream
-    const int nblk = (q.sched && NBLK == 256) ? NBLK - conv_reserved_cus() : NBLK;
+    // the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream (with or without the ticket
+    // scheduler: on a CU-masked stream -- gfe_stream_create_cu_mask -- blocks beyond the mask's CUs would only queue up for a second round)
+    const int nblk = NBLK == 256 ? NBLK - conv_reserved_cus() : NBLK;
     q.tiles_per_block = (int)ceil_div(tiles, nblk);
     const dim3 grid((unsigned)ceil_div(tiles, q.tiles_per_block));
     static bool attr_set = false;

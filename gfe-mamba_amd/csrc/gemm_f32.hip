@@ -18,6 +18,7 @@
 // exposed memory round trip (one tile of prefetch), so these launch-bound shapes (<= 300 rows) want MANY SMALL blocks with DEEP
 // k-steps: T = 32 with 128-deep tiles unless 64 x 64 x 32 tiles already fill the chip.  split_k > 1: blockIdx.z takes a K range and adds with f32 atomics (atomics cost more than they save
 // beyond a few splits: 2.4 MB of output x 8 splits is 15 us of atomic traffic).
+#include <cstdlib>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -141,9 +142,202 @@ __global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __res
     }
 }
 
+
+// ---- the in-block K split ("ks") path: the head's launch-bound shapes (M <= ~300 rows, both operands 16-byte aligned, K % 16 == 0) ----
+// One block owns one output tile and its waves cut K between them; nothing is staged in LDS: a lane loads 16 bytes per operand row
+// straight into registers and the four k values it holds feed four MFMAs.  The f32 MFMA reduces over k = lane >> 4 of both operands,
+// so giving MFMA i of a 16-deep group the k values {4 (lane >> 4) + i} of A *and* of B is the same sum in another (fixed) order.
+//   K-major operand (row r, 16-byte load at k = kbase + 4 (lane >> 4)):  element i -> MFMA i of the group;
+//   reduction-major B (BTR; element (n, k) at B[k * ldb + n]): one 16-byte load per MFMA i at k = kbase + 4 (lane >> 4) + i covers
+//   columns n0 + 4 (lane & 15) .. + 3 = the wave's four column tiles (tile j holds column 4 (lane & 15) + j: a permutation the
+//   epilogue undoes by storing the four tiles of a row as one 16-byte vector).
+// Rows / columns beyond M / N are clamped on the load side (their products are never stored).  The waves' partial tiles are summed in a
+// fixed binary tree through LDS (bit-reproducible, no second launch, no atomics); wave 0 adds bias / the accumulation target and stores.
+// Against the staged kernel above at the head's sizes (the round-4 trace of the step, profiles/r04): its K-major tile stores hit LDS
+// 8-way bank conflicts, every 128-deep k-step exposed a barrier pair and a memory round trip, K was cut over the GRID with a reduction
+// launch behind 33 of the 88 products of a step, and the one-column-block dgrad of dt_proj (N = 32, K = 1024) ran on 10 blocks for 18 us.
+template <int NA, int NB, bool BTR, int GB>
+__global__ __launch_bounds__(1024) void gemm_f32_ks_kernel(const GemmF32Params p, const int kw) {
+    static_assert(!BTR || NB == 4, "reduction-major B: a 16-byte load spans the wave's four column tiles");
+    constexpr int TM = 16 * NA, TN = 16 * NB, NBV = BTR ? 4 : NB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ks_smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(ks_smem);           // [slot][tile][lane], nw / 2 slots: half of the waves' tiles per round
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = w * kw, kend = min(p.K, kbeg + kw);
+    const float* ap[NA];
+    const float* bp[BTR ? 1 : NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) ap[a] = p.A + (size_t)min(m0 + 16 * a + lr, p.M - 1) * p.lda + 4 * lq;
+    if constexpr (BTR) bp[0] = p.B + (size_t)(4 * lq) * p.ldb + min(n0 + 4 * lr, p.N - 4);
+    else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bp[b] = p.B + (size_t)min(n0 + 16 * b + lr, p.N - 1) * p.ldb + 4 * lq;
+    }
+    auto load = [&](int k, f32x4 (&av)[GB][NA], f32x4 (&bv)[GB][NBV]) {
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int kg = k + 16 * g;
+#if defined(GFE_KS_EXP_NOLOAD)   // timing experiment only: operands never loaded
+            if (false) {
+#else
+            if (kg < kend) {                                  // wave-uniform
+#endif
+#pragma unroll
+                for (int a = 0; a < NA; ++a) av[g][a] = *reinterpret_cast<const f32x4*>(ap[a] + kg);
+#pragma unroll
+                for (int i = 0; i < NBV; ++i) {
+                    if constexpr (BTR) bv[g][i] = *reinterpret_cast<const f32x4*>(bp[0] + (size_t)(kg + i) * p.ldb);
+                    else bv[g][i] = *reinterpret_cast<const f32x4*>(bp[i] + kg);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) av[g][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NBV; ++i) bv[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    f32x4 ca[GB][NA], cb[GB][NBV], na[GB][NA], nb_[GB][NBV];
+    if (kbeg < kend) load(kbeg, ca, cb);
+    for (int k = kbeg; k < kend; k += 16 * GB) {
+        const bool more = k + 16 * GB < kend;
+        if (more) load(k + 16 * GB, na, nb_);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        float bval;
+                        if constexpr (BTR) bval = cb[g][i][b]; else bval = cb[g][b][i];
+#if defined(GFE_KS_EXP_NOMFMA)    // timing experiment only: one fma per MFMA
+                        acc[a][b][0] = fmaf(ca[g][a][i], bval, acc[a][b][0]);
+#else
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[g][a][i], bval, acc[a][b], 0, 0, 0);
+#endif
+                    }
+        if (more) {
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) ca[g][a] = na[g][a];
+#pragma unroll
+                for (int i = 0; i < NBV; ++i) cb[g][i] = nb_[g][i];
+            }
+        }
+    }
+    // fixed binary tree over the waves: round `half`: waves [half, 2 half) park their tiles, waves [0, half) add them
+#if defined(GFE_KS_EXP_NOTREE)   // timing experiment only: the waves' tiles are never summed
+    for (int half = 0; half >= 1; half >>= 1) {
+#else
+    for (int half = nw >> 1; half >= 1; half >>= 1) {
+#endif
+        if (w >= half && w < 2 * half) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) red[((w - half) * NA * NB + a * NB + b) * 64 + lane] = acc[a][b];
+        }
+        __syncthreads();
+        if (w < half) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] += red[(w * NA * NB + a * NB + b) * 64 + lane];
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (w != 0) return;
+    // D: row = 4 (lane >> 4) + reg, col = lane & 15 of the tile
+    if constexpr (BTR) {
+        const int n = n0 + 4 * lr;                            // the four tiles of a row: columns n .. n + 3
+        if (n >= p.N) return;
+        const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+        f32x4 bv4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv4 = f32x4{p.bias[n], p.bias[n + 1], p.bias[n + 2], p.bias[n + 3]};
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * a + 4 * lq + r;
+                if (m >= p.M) continue;
+                float* c = p.C + (size_t)m * p.ldc + n;
+                f32x4 v = f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]} + bv4;
+                if (vec) {
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+                    *reinterpret_cast<f32x4*>(c) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c[j] = p.accumulate ? v[j] + c[j] : v[j];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int n = n0 + 16 * b + lr;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 16 * a + 4 * lq + r;
+                    if (m >= p.M) continue;
+                    float* c = p.C + (size_t)m * p.ldc + n;
+                    const float v = acc[a][b][r] + bv;
+                    *c = p.accumulate ? v + *c : v;
+                }
+        }
+    }
+}
+
+struct KsPlan { int na, nw, kw; };
+// true: the shape takes the in-block K split (operands aligned for 16-byte loads, K-major A, K a multiple of 16, launch-bound size)
+bool ks_plan(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, int64_t M, int64_t N, int64_t K, KsPlan* out) {
+    static const bool off = getenv("GFE_F32_NO_KS") != nullptr;       // experiments: the staged kernel everywhere
+    if (off || a_tr || (K & 15) || ((uintptr_t)A & 15) || (lda & 3) || ((uintptr_t)B & 15) || (ldb & 3)) return false;
+    if (b_tr && ((N & 3) || N < 4)) return false;
+    if (ceil_div(M, 64) * ceil_div(N, 64) >= 512) return false;       // enough 64 x 64 tiles to fill the chip: the staged kernel's ground
+    // the head's row counts only (B x 37 tokens, B rows).  The frozen generator's own f32 products -- the per-sample effective weights of
+    // the collapsed conv1 -> GroupNorm -> conv2 chains, 27 * Cout rows by B * Cin columns -- stay on the staged kernel, whose K cut does not
+    // depend on the batch: a volume must come out bit for bit the same whatever batch it rides in (tests/test_configs_gpu.py), and the number
+    // of waves per tile below is a function of the tile count
+    if (M > 512) return false;
+    const int64_t groups = K / 16;
+    KsPlan pl;
+    pl.na = 2;
+    if (b_tr && ceil_div(M, 32) * ceil_div(N, 64) * (groups < 16 ? groups : 16) < 2048) pl.na = 1;
+    const int64_t tiles = b_tr ? ceil_div(M, 16 * pl.na) * ceil_div(N, 64) : ceil_div(M, 32) * ceil_div(N, 32);
+    // few tiles and a long K (x_proj forward, dt_proj dgrad, the 8-row feed-forward's second product): 16 waves per tile are not enough
+    // parallelism and each would walk > 2 batches -- the staged kernel with K cut over the grid measured faster there (9.0 vs 12.5 us,
+    // 8.5 vs 9.4, 10.3 vs 16.5: profiles/r04/gemm_f32_shapes.txt)
+    if (tiles < 32 && groups > 32) return false;
+    int nw = 1;
+    while (nw < 16 && tiles * nw < 2048 && 2 * nw <= groups) nw *= 2;
+    static const char* nw_env = getenv("GFE_F32_KS_NW");               // experiments: a fixed number of waves per block
+    if (nw_env) { nw = atoi(nw_env); while (nw > 1 && nw > groups) nw >>= 1; }
+    pl.nw = nw;
+    pl.kw = (int)(ceil_div(groups, nw) * 16);
+    if (out) *out = pl;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gfe_gemm_f32_inblock(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, int64_t M, int64_t N, int64_t K) {
+    return ks_plan(A, lda, a_tr, B, ldb, b_tr, M, N, K, nullptr) ? 1 : 0;
+}
 
 int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, float* C, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, float* splitk_ws, void* stream) {
@@ -156,6 +350,16 @@ int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t 
     // 16-byte loads: 16-byte aligned base and leading dimension; a thread's 8 elements run along k (K-major) or along rows
     p.a_vec = ((uintptr_t)A % 16 == 0) && lda % 4 == 0;
     p.b_vec = ((uintptr_t)B % 16 == 0) && ldb % 4 == 0;
+    KsPlan ks;
+    if (ks_plan(A, lda, a_tr, B, ldb, b_tr, M, N, K, &ks)) {
+        p.a_vec = p.b_vec = 1; p.ksplit = (int)K; p.part = nullptr;
+        const dim3 block(64 * ks.nw);
+        const size_t slot = 1024;                                      // one 16 x 16 f32 tile
+        if (!b_tr) hipLaunchKernelGGL((gemm_f32_ks_kernel<2, 2, false, 2>), dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32)), block, (ks.nw / 2) * 4 * slot, (hipStream_t)stream, p, ks.kw);
+        else if (ks.na == 2) hipLaunchKernelGGL((gemm_f32_ks_kernel<2, 4, true, 1>), dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 32)), block, (ks.nw / 2) * 8 * slot, (hipStream_t)stream, p, ks.kw);
+        else hipLaunchKernelGGL((gemm_f32_ks_kernel<1, 4, true, 2>), dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 16)), block, (ks.nw / 2) * 4 * slot, (hipStream_t)stream, p, ks.kw);
+        return gfe_launch_status();
+    }
     p.ksplit = (int)(ceil_div(ceil_div(K, split_k), 128) * 128);
     const unsigned nz = (unsigned)ceil_div(K, p.ksplit);
     p.part = nz > 1 ? splitk_ws : nullptr;

@@ -421,10 +421,15 @@ def gemm_f32(a, a_t, b, b_t, bias=None, accum_into=None):
     # launch-bound sizes: the kernel uses 32 x 32 x 128 tiles below 512 blocks of 64 x 64; a block's time is its number of 128-deep
     # k-steps (one exposed memory round trip + 32 f32 MFMAs each), so K is split -- range partials + a fixed-order sum, bit-reproducible --
     # until ~1024 blocks are in flight, keeping >= 2 k-steps per block and the partial traffic (output bytes x splits) below ~8 MB
-    blocks32 = -(-M // 32) * -(-N // 32)
-    split_k = max(1, min(8, K // 256, 1024 // blocks32, (8 << 20) // max(1, 4 * M * N)))
-    if os.environ.get("GFE_F32_SPLITK_MAX"):                # experiments: cap the cut (1 = no split-K, no reduction launch)
-        split_k = min(split_k, int(os.environ["GFE_F32_SPLITK_MAX"]))
+    # The head's own shapes (aligned operands, K-major a, K % 16 == 0) never get here: gfe_gemm_f32_inblock says the kernel cuts K between the
+    # waves of ONE block per output tile and sums them in LDS (no reduction launch, no workspace).
+    if lib().gfe_gemm_f32_inblock(ptr(a), ld(a), int(a_t), ptr(b), ld(b), int(b_t), M, N, K):
+        split_k = 1
+    else:
+        blocks32 = -(-M // 32) * -(-N // 32)
+        split_k = max(1, min(8, K // 256, 1024 // blocks32, (8 << 20) // max(1, 4 * M * N)))
+        if os.environ.get("GFE_F32_SPLITK_MAX"):            # experiments: cap the cut (1 = no split-K, no reduction launch)
+            split_k = min(split_k, int(os.environ["GFE_F32_SPLITK_MAX"]))
     if accum_into is not None:
         assert accum_into.dtype == torch.float32 and accum_into.shape == (M, N) and unit(accum_into) and bias is None
         out = accum_into

@@ -4,11 +4,18 @@ One process per GPU; with world_size > 1 the batch is sharded over ranks and the
 (RCCL over xGMI) BEFORE the per-parameter clip, which makes the update identical to a single-process step on the
 global batch (BCELoss is a batch mean).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
+from . import call, lib
 from .head_ops import bce_sigmoid
 from .train_ops import Condition, FlatAdam, side_wgrads
+
+
+# CUs the pipelined step hands to the head's streams (ClassifyStep.head_cus; GFE_HEAD_CUS overrides; 0 = no split)
+HEAD_CUS_DEFAULT = 0
 
 
 def dp_mean_scale(world_size):
@@ -70,8 +77,13 @@ def allreduce_grads_(flat_grad, world_size, group=None, force=False):
 
 
 class ClassifyStep:
-    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None, overlap_update=None, force_collective=False):
+    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None, overlap_update=None, force_collective=False, head_cus=None):
         self.gen, self.head, self.ft = gen.eval(), head, ft
+        # train_step_pipelined: CUs the head's streams own (a multiple of 8 = the same number from every XCD; 0 = both streams share the
+        # chip and the head only runs in the gaps between conv launches).  GFE_HEAD_CUS overrides.
+        env = os.environ.get("GFE_HEAD_CUS")
+        self.head_cus = int(env) if env not in (None, "") else (HEAD_CUS_DEFAULT if head_cus is None else int(head_cus))
+        self._gen_stream = None
         self.all_params = list(head.parameters()) + list(ft.parameters())          # classify_mamba.py:57-61
         self.opt = FlatAdam(self.all_params, lr=lr, max_norm=max_norm)             # Adam(lr=1e-4) + per-parameter clip
         self.opt.force_collective = bool(force_collective)                         # all_reduce even in a one-rank group
@@ -90,12 +102,44 @@ class ClassifyStep:
     # gaps of the generator's persistent conv kernels instead of having the chip to themselves.  Same arithmetic, same order of
     # updates, one generator forward and one head step per call -- measured 15.9 -> 13.8 ms/step at 8 volumes (tools/pipeline_probe.py).
     def _generate_async(self, x):
-        """Generator forward on the current stream; returns (x, outputs, event recorded behind them, (version, address) of x)."""
-        with torch.no_grad():
-            outs = self.gen(x, output_vit_mid=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        """Generator forward on the current stream -- or, with head_cus > 0, on the stream that owns the other 256 - head_cus CUs, ordered
+        behind the current stream; returns (x, outputs, event recorded behind them, (version, address) of x)."""
+        GS = self._gen_stream
+        if GS is None:
+            with torch.no_grad():
+                outs = self.gen(x, output_vit_mid=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            return x, outs, ev, (x._version, x.data_ptr())
+        GS.wait_stream(torch.cuda.current_stream())
+        old = lib().gfe_conv_reserve_cus(self.head_cus)            # the persistent conv kernels launch one block per CU of THIS stream
+        try:
+            with torch.cuda.stream(GS), torch.no_grad():
+                x.record_stream(GS)
+                outs = self.gen(x, output_vit_mid=True)
+                ev = torch.cuda.Event()
+                ev.record(GS)
+        finally:
+            lib().gfe_conv_reserve_cus(old)
         return x, outs, ev, (x._version, x.data_ptr())
+
+    def _split_streams(self):
+        """Head / side / generator streams on disjoint CU sets (gfe_stream_create_cu_range): the head's chain of ~230 small launches gets
+        head_cus CUs of its own -- the same slots of every XCD -- and advances all the time; the persistent conv kernels fill the rest.
+        Without the split a conv block occupies a whole CU (496 of 512 registers per SIMD lane, 155 of 160 KB LDS), so the head only ran in
+        the gaps between conv launches and cost the step the length of its dependent chain."""
+        import ctypes
+        from . import train_ops
+
+        def masked(lo, hi):
+            h = ctypes.c_void_p()
+            call("gfe_stream_create_cu_range", lo, hi, ctypes.byref(h))
+            return torch.cuda.ExternalStream(h.value)
+
+        n = self.head_cus
+        self._head_stream = masked(0, n)
+        train_ops._Side.stream, train_ops._Side.masked = masked(0, n), True    # weight-gradient leaves and the image condition: the head's CUs too
+        self._gen_stream = masked(n, 256)
 
     def join(self):
         """Make the current stream wait for a head step that train_step_pipelined left running on the head stream."""
@@ -149,7 +193,13 @@ class ClassifyStep:
         the head stream: `join()` -- or any device synchronisation -- before reading it or the parameters from another stream)."""
         G = torch.cuda.current_stream()
         if getattr(self, "_head_stream", None) is None:
-            self._head_stream = torch.cuda.Stream()
+            if self.head_cus > 0:
+                self._split_streams()
+            else:
+                from . import train_ops
+                if train_ops._Side.masked:                      # an earlier step object confined the side stream to its head CUs
+                    train_ops._Side.stream, train_ops._Side.masked = None, False
+                self._head_stream = torch.cuda.Stream()
         H = self._head_stream
         # Whatever the caller enqueues on its stream from here on (refilling the previous call's input buffers, the usual
         # double-buffered loader) is ordered behind the previous head step, which still read them.  Inputs of THIS call must stay
@@ -157,6 +207,8 @@ class ClassifyStep:
         prev = getattr(self, "_head_done", None)
         if prev is not None:
             G.wait_event(prev)
+            if self._gen_stream is not None:
+                self._gen_stream.wait_event(prev)
         pf = getattr(self, "_prefetched", None)
         # the announced batch is recognised by identity AND content version AND address: a loader that refills the same tensor in place
         # (or a new tensor at a recycled address) gets a fresh generator forward, never the previous batch's outputs

@@ -52,6 +52,7 @@ def _grad_slot(param):
 class _Side:
     on = False
     stream = None
+    masked = False           # the stream is confined to a step's head CUs (ClassifyStep._split_streams)
     keep = []
 
 

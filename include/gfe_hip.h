@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 41
+#define GFE_ABI_VERSION 42
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -164,6 +164,14 @@ int gfe_conv3d_tiles(int64_t D, int64_t H, int64_t W);
  * 256 - n blocks, i.e. leave n CUs to the kernels of another stream (the head of the previous batch in the two-stream step; a conv block
  * fills a CU's registers and LDS, nothing else can share it).  Returns the previous value.  Process-wide; default 0 or GFE_CONV_RESERVE_CUS. */
 int gfe_conv_reserve_cus(int n);
+
+/* A HIP stream whose kernels run only on CU-mask bits lo .. hi-1 of the 256 (hipExtStreamCreateWithCUMask; bit i = CU slot i / 8 of XCD
+ * i % 8, so ranges that are multiples of 8 take the same CUs from every XCD).  The two-stream step runs the head of batch k on bits
+ * 0 .. n-1 and the generator of batch k+1 on bits n .. 255 with gfe_conv_reserve_cus(n): the head's latency-bound chain then advances all
+ * the time instead of only in the gaps between conv launches that fill every CU.  The handle is a hipStream_t (wrap it with
+ * torch.cuda.ExternalStream); destroy it with gfe_stream_destroy once nothing is queued on it. */
+int gfe_stream_create_cu_range(int lo, int hi, void** stream);
+int gfe_stream_destroy(void* stream);
 /* GroupNorm-partial slots per sample one gfe_conv3d_igemm call with stats_ws writes (see above). Host-only. */
 int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout);
 
@@ -259,6 +267,12 @@ int gfe_gemm_dma_launches(void);
  *   is accumulated into. */
 int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, float* C, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, const float* bias, int accumulate, int split_k, float* splitk_ws, void* stream);
+
+/* 1 when gfe_gemm_f32 takes the in-block K split for these operands (K-major A, both operands 16-byte aligned with leading dimensions
+ * that are multiples of 4, K % 16 == 0, launch-bound size; reduction-major B also N % 4 == 0): one block per output tile, its waves cut
+ * K between them and sum their tiles in a fixed tree through LDS -- split_k / splitk_ws are then ignored (no reduction launch, nothing to
+ * allocate).  0: the staged kernel with the caller's split_k.  Same sums either way up to f32 summation order; both are bit-reproducible. */
+int gfe_gemm_f32_inblock(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, int64_t M, int64_t N, int64_t K);
 
 /* out[b][c][r] = in[b][r][c], bf16 (operand re-layout for dgrad / wgrad). */
 int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream);

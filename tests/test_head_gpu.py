@@ -357,11 +357,12 @@ def test_head_alone_on_the_references_generator_outputs_meets_fp32_tolerance():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(296, 512, 512), (37, 2048, 512), (300, 64, 1024), (8, 1, 512), (37, 40, 25), (5, 8, 8), (2048, 512, 296)])
+@pytest.mark.parametrize("M,N,K", [(296, 512, 512), (37, 2048, 512), (300, 64, 1024), (8, 1, 512), (37, 40, 25), (5, 8, 8), (2048, 512, 296),
+                                   (296, 2048, 512), (296, 32, 1024), (296, 1024, 32), (296, 1024, 64), (8, 4096, 512), (19, 36, 48), (296, 512, 2048)])
 def test_gemm_f32_exact_modes(M, N, K):
     """gfe_gemm_f32 (f32 MFMA): every operand layout, bias, accumulation and split-K against an f64 matmul: f32-exact (<= 2e-6 of the
     largest |sum|), any sizes / alignments (the 1-wide logit layer, the 25/37-wide test models)."""
-    from gfe_hip import nn_ops as K_
+    from gfe_hip import nn_ops as K_, call, ptr, stream
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
     a, b, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
     ref = a.double() @ b.double().t()
@@ -375,6 +376,20 @@ def test_gemm_f32_exact_modes(M, N, K):
             acc = torch.full((M, N), 0.5, device=DEV)
             K_.gemm_f32(aa, a_t, bb, b_t, accum_into=acc)
             assert (acc.double().cpu() - ref - 0.5).abs().max().item() <= 2e-6 * scale, (a_t, b_t, "accumulate")
+            if not a_t:
+                # a column range of a wider matrix as the target (mamba_block writes d delta_r into [d delta_r | dB | dC] in place), twice: the
+                # in-block K split (16-byte aligned operands) and, from an operand shifted by one float, the staged kernel -- and bit-repeatable
+                wide = torch.full((M, N + 7), -3.0, device=DEV)
+                call("gfe_gemm_f32", ptr(aa), aa.stride(0), 0, ptr(bb), bb.stride(0), int(b_t), ptr(wide) + 4 * 3, N + 7, M, N, K, None, 0, 1, None, stream())
+                assert (wide[:, 3:3 + N].double().cpu() - ref).abs().max().item() <= 2e-6 * scale and (wide[:, :3] == -3).all() and (wide[:, 3 + N:] == -3).all()
+                again = K_.gemm_f32(aa, a_t, bb, b_t, bias=bias.to(DEV))
+                assert torch.equal(out, again)
+                if K > 1:
+                    pad = torch.zeros(aa.numel() + 1, device=DEV)
+                    pad[1:] = aa.reshape(-1)
+                    shifted = pad[1:].view(aa.shape)
+                    out2 = K_.gemm_f32(shifted, a_t, bb, b_t, bias=bias.to(DEV))
+                    assert (out2.double().cpu() - ref - bias.double()).abs().max().item() <= 2e-6 * scale, (a_t, b_t, "unaligned")
 
 
 @pytest.mark.gpu
@@ -525,18 +540,19 @@ def test_pipelined_step_matches_serial_step():
     kw = dict(vol=(32, 32, 32), f_maps=(8, 16, 32), dim=64, depth=2, heads=8, vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128), seed=3)
     batches = [[t.cuda() for t in det.det_inputs(2, (32, 32, 32), seed=50 + i)] for i in range(4)]
     outs = []
-    for mode in ("serial", "pipelined", "pipelined_unannounced"):
+    # "pipelined_cus": head / side streams on 16 CUs of their own (two per XCD), the generator's on the other 240 (gfe_stream_create_cu_range)
+    for mode in ("serial", "pipelined", "pipelined_unannounced", "pipelined_cus"):
         gen, head, ft = build_models(**kw)
         for m in ft.modules():
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
-        st = ClassifyStep(gen, head, ft)
+        st = ClassifyStep(gen, head, ft, head_cus=16 if mode == "pipelined_cus" else 0)
         losses = []
         for i, b in enumerate(batches):
             if mode == "serial":
                 losses.append(st.train_step(*b))
             else:
-                nxt = batches[i + 1][0] if (mode == "pipelined" and i + 1 < len(batches)) else None
+                nxt = batches[i + 1][0] if (mode != "pipelined_unannounced" and i + 1 < len(batches)) else None
                 losses.append(st.train_step_pipelined(*b, x_next=nxt))
         st.join()
         torch.cuda.synchronize()
