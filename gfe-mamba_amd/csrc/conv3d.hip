@@ -361,9 +361,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #endif
             GFE_STAMP(2);
             // refill the buffers nobody reads any more: next stage's weights, and (once per unit) the next unit's tile
-            auto issue_dma = [&]() {
+            auto issue_dma = [&](bool do_w, bool do_a) {
 #if !defined(GFE_EXP_NOW)      // timing experiment only: weights are never restaged
-            if (!a_wave) {
+            if (!a_wave && do_w) {
                 if (s + 1 < nstage) w_dma(cur, group, slab, s + 1, (gstage + 1) & 1);
                 else if (next_unit) w_dma(nxt, group1, slab1, 0, (gstage + 1) & 1);
             }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // 2 pieces per stage (1.93), every wave 1/8 of the tile in "its" stage (1.79), all DMA on the weight waves (1.67), block-
             // staggered burst stage (no change), and an address-arithmetic-free burst with the tile origin in the scalar offset
             // (2.11: the 64 misses then sit in front of the next stages' weight pieces in the CU's in-order vector-memory path)
-            if constexpr (A_BUFS == 2) { if (a_wave && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE); }
+            if constexpr (A_BUFS == 2) { if (a_wave && do_a && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE); }
 #endif
             };
             // 27-tap path: the first tap's fragment reads go out BEFORE the DMA instructions, so their LDS round trip runs under the 3 (weight
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #else
             constexpr bool DMA_LATE = REG27;
 #endif
-            if constexpr (!DMA_LATE) issue_dma();
+            if constexpr (!DMA_LATE) issue_dma(true, true);
 
             GFE_STAMP(3);
             const uint8_t* wb = sW + (gstage & 1) * (W_PIECES * 1024) + wbase;
@@ -416,7 +416,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #else
                 if constexpr (PIPE) { frag_load(0, 0); __builtin_amdgcn_sched_barrier(0); }
 #endif
-                if constexpr (DMA_LATE) { issue_dma(); __builtin_amdgcn_sched_barrier(0); }
+                // The activation waves' tile burst (stage 0) goes out after the first tap's MFMAs: the weight waves' three pieces for the next
+                // stage are then in the CU's in-order vector-memory queue AHEAD of the burst's 64 HBM misses, and the burst's ~1 100 issue
+                // cycles start under the partner wave's MFMAs: 64->64 @96^3 1.389-1.399 -> 1.382-1.384 ms, +stats 1.427-1.444 -> 1.418-1.427,
+                // 128->128 @48^3 0.689-0.700 -> 0.683-0.699 (alternating runs, profiles/r04/conv_tile_burst_ab.txt).  After the SECOND tap it is
+                // 12 % slower: the burst then runs past the stage's MFMAs and the activation waves trail into the barrier.
+#if defined(GFE_EXP_A_AFTER)    // experiments: another tap, or -1 = together with the weight pieces (round 2's order)
+                constexpr int A_AFTER = PIPE ? GFE_EXP_A_AFTER : -1;
+#else
+                constexpr int A_AFTER = PIPE ? 0 : -1;
+#endif
+                if constexpr (DMA_LATE) { issue_dma(true, A_AFTER < 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     const int set = PIPE ? (tl & 1) : 0;
@@ -433,6 +443,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                             for (int i = 0; i < 2 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (DMA_LATE && A_AFTER >= 0) { if (tl == A_AFTER) { issue_dma(false, true); __builtin_amdgcn_sched_barrier(0); } }
                     } else {
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_setprio(1);
