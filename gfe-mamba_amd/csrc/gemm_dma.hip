@@ -380,7 +380,11 @@ static int dma_shape(const GemmDmaArgs& a) {
 
 bool gemm_dma_usable(const GemmDmaArgs& a) {
     if (getenv("GFE_GEMM_NO_DMA")) return false;                                   // A/B switch for measurements
-    if (a.M < 512 || a.N % DBN != 0 || a.K % DBK != 0 || a.K < DBK) return false;  // skinny M: the split-K kernel streams the weights better
+    // Skinny M: the split-K kernel streams the weights better -- below half a 256-row tile.  From 129 rows up a wide product (dma_shape still
+    // wants >= 2 tiles per CU) reads its weight panel once per 256 rows here, twice per 128-row tile there: the generator ViT's un-patchify
+    // projection (200 x 147 456 x 512, vit.py:91-95) 104 -> ~50 us, the generator 9.61-9.68 -> 9.56 ms (GFE_GEMM_DMA_MINM=512: the old rule).
+    static const int min_m = getenv("GFE_GEMM_DMA_MINM") ? atoi(getenv("GFE_GEMM_DMA_MINM")) : 129;
+    if (a.M < min_m || a.N % DBN != 0 || a.K % DBK != 0 || a.K < DBK) return false;
     if (dma_shape(a) == 0) return false;
     if (a.lda % 8 || a.ldb % 8) return false;
     if (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) % 16) return false;

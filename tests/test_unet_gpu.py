@@ -50,7 +50,7 @@ def test_gemm_epilogues_and_splitk():
 
 
 @pytest.mark.parametrize("nj", [4, 2])
-@pytest.mark.parametrize("M,N,K_", [(512, 128, 64), (1000, 256, 128), (2085, 512, 512), (777, 384, 1024), (13832, 1536, 512), (4099, 512, 2048), (600, 2048, 192)])
+@pytest.mark.parametrize("M,N,K_", [(512, 128, 64), (1000, 256, 128), (2085, 512, 512), (777, 384, 1024), (13832, 1536, 512), (4099, 512, 2048), (600, 2048, 192), (200, 16384, 512)])
 def test_gemm_dma_main_loop(M, N, K_, nj, monkeypatch):
     """The persistent LDS-DMA main loop (csrc/gemm_dma.hip; every nn.Linear forward of the inference pipelines, vit_3d.py:41-46, 50): ragged
     last row tile, one-unit tiles (K = 64), every epilogue (bias, exact-erf GELU, f32 / bf16 residual, f32 / bf16 output), a strided A view
