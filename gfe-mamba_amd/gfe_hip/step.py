@@ -232,6 +232,8 @@ class ClassifyStep:
                 with side_wgrads():
                     loss.backward()
             self.opt.step(self.world_size, self.group)
+            if os.environ.get("GFE_EXP_HEAD_SPIN"):            # experiment: a spinning kernel of that many clock cycles appended to the head's chain
+                torch.cuda._sleep(int(os.environ["GFE_EXP_HEAD_SPIN"]))
             self._head_done = torch.cuda.Event()
             self._head_done.record(H)
         if x_next is not None:
