@@ -321,6 +321,9 @@ bool ks_plan(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb,
     // parallelism and each would walk > 2 batches -- the staged kernel with K cut over the grid measured faster there (9.0 vs 12.5 us,
     // 8.5 vs 9.4, 10.3 vs 16.5: profiles/r04/gemm_f32_shapes.txt)
     if (tiles < 32 && groups > 32) return false;
+    // (Measured and dropped: 64 x 32 tiles for the K-major form and 32 x 64 for every reduction-major shape -- a quarter less operand traffic,
+    // half the waves: in_proj forward 17.9 -> 19.2 us, out_proj forward 13.0 -> 19.7, in_proj dgrad 16.4 -> 23.9.  These launches are bound by
+    // how many independent load streams are in flight, not by the bytes.)
     int nw = 1;
     while (nw < 16 && tiles * nw < 2048 && 2 * nw <= groups) nw *= 2;
     static const char* nw_env = getenv("GFE_F32_KS_NW");               // experiments: a fixed number of waves per block
