@@ -108,6 +108,7 @@ struct ConvParams {
     int relu;
     float* stats; int stats_nblk, stats_slot0;  // GroupNorm partials of the OUTPUT: (B, stats_nblk, 2, Cout) f32, slot = slot0 + tile-in-sample
     int ntd, nth, ntw, tiles_per_block;
+    int brick;                                 // single-class launches: tile order inside a sample -- 0: tw fastest; 1: bricks of 4 (w) x 4 (h) x 2 (d) tiles
     int toff[27];                              // LDS byte offset of each tap inside the halo tile
     int txor[27];                              // 32 when the tap shifts the row parity (swizzle term), else 0
     // multi-class launches (the 8 parity classes of a transposed conv in ONE launch, work item = (tile, class)): class c uses taps
@@ -238,6 +239,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         TilePos q;
         q.cls = 0;
         if constexpr (MC) { q.cls = t % p.ncls; t /= p.ncls; }
+        if (!MC && p.brick) {
+            // 32 consecutive work items = one 4 x 4 x 2 brick of tiles: what the 32 blocks of an XCD work on at one time then shares halo faces in
+            // all three directions inside the XCD's L2 (in tw-fastest order the d-neighbour of a tile is 144 items = 4.5 rounds away)
+            const int per = p.ntd * p.nth * p.ntw;
+            q.b = t / per;
+            const int r = t - q.b * per, br = r >> 5, in = r & 31;
+            const int nbw = p.ntw >> 2, nbh = p.nth >> 2;
+            const int bw_ = br % nbw, bh_ = (br / nbw) % nbh, bd_ = br / (nbw * nbh);
+            q.tw = bw_ * 4 + (in & 3); q.th = bh_ * 4 + ((in >> 2) & 3); q.td = bd_ * 2 + (in >> 4);
+            return q;
+        }
         q.tw = t % p.ntw; t /= p.ntw;
         q.th = t % p.nth; t /= p.nth;
         q.td = t % p.ntd; q.b = t / p.ntd;
@@ -604,7 +616,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                             o1 = fmaf(bf16lo_to_f32(pk[2]), wb.x, o1); o1 = fmaf(bf16hi_to_f32(pk[2]), wb.y, o1);
                             o1 = fmaf(bf16lo_to_f32(pk[3]), wb.z, o1); o1 = fmaf(bf16hi_to_f32(pk[3]), wb.w, o1);
                         } else {
+#if defined(GFE_EXP_NT_STORE)     // experiment: streaming (non-temporal) output stores, so that a round's 2 MB of output per XCD does not push the halo faces out of L2
+                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                            __builtin_nontemporal_store((u32x4_t){pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<u32x4_t*>(y_t + o) + h);
+#else
                             reinterpret_cast<uint4*>(y_t + o)[h] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#endif
                         }
                         if constexpr (RES1) {
 #pragma unroll
@@ -926,6 +943,8 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     // persistent blocks: one resident block per CU x 256 CUs, each walking a contiguous tile range
     ConvParams q = p;
     q.sched = MC ? nullptr : conv_sched_slot(st);
+    static const bool brick_on = !(getenv("GFE_CONV_BRICK") != nullptr && getenv("GFE_CONV_BRICK")[0] == '0');     // GFE_CONV_BRICK=0: tw-fastest order
+    q.brick = (!MC && brick_on && p.ntw % 4 == 0 && p.nth % 4 == 0 && p.ntd % 2 == 0) ? 1 : 0;
     // the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream (with or without the ticket
     // scheduler: on a CU-masked stream -- gfe_stream_create_cu_mask -- blocks beyond the mask's CUs would only queue up for a second round)
     const int nblk = NBLK == 256 ? NBLK - conv_reserved_cus() : NBLK;
