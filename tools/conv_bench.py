@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the implicit-GEMM conv kernel alone (for rocprofv3 --pmc passes and A/B timing).
-    python tools/conv_bench.py [C] [D] [B] [iters] [Cin] [stats 0|1]"""
+    python tools/conv_bench.py [C] [D] [B] [iters] [Cin] [stats 0|1] [data random|zeros|const]
+data: what the activations hold -- the clock the chip keeps under matrix load depends on how many operand bits toggle"""
 import os
 import sys
 
@@ -15,8 +16,15 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 CI = int(sys.argv[5]) if len(sys.argv) > 5 else C          # input channels (default: square)
 ST = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False  # 1: the variant that also writes the GroupNorm partials of its output
+DATA = sys.argv[7] if len(sys.argv) > 7 else "random"
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, D, D, D, CI, generator=g).to(torch.bfloat16).cuda()
+if DATA == "zeros":
+    x.zero_()
+elif DATA == "const":
+    x.fill_(0.5)
+elif DATA == "relu":
+    x.clamp_(min=0)
 w32 = K.pack_conv3((torch.randn(C, CI, 3, 3, 3, generator=g) / (27 * CI) ** 0.5).cuda(), torch.float32)
 ss = K.groupnorm_scale_shift(x, torch.ones(CI, device="cuda"), torch.zeros(CI, device="cuda"), 8)
 w, tab = K.fold_groupnorm(w32, ss[0], ss[1], K.CONV3_TAPS, CI, C)
@@ -31,4 +39,4 @@ e1.record()
 e1.synchronize()
 ms = e0.elapsed_time(e1) / iters
 fl = 2.0 * 27 * C * CI * B * D ** 3
-print(f"conv Cin={CI} C={C} D={D} B={B}{' +stats' if ST else ''}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+print(f"conv Cin={CI} C={C} D={D} B={B}{' +stats' if ST else ''} data={DATA}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
