@@ -358,7 +358,7 @@ def test_head_alone_on_the_references_generator_outputs_meets_fp32_tolerance():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(296, 512, 512), (37, 2048, 512), (300, 64, 1024), (8, 1, 512), (37, 40, 25), (5, 8, 8), (2048, 512, 296),
-                                   (296, 2048, 512), (296, 32, 1024), (296, 1024, 32), (296, 1024, 64), (8, 4096, 512), (19, 36, 48), (296, 512, 2048)])
+                                   (296, 2048, 512), (296, 32, 1024), (296, 1024, 32), (296, 1024, 64), (8, 4096, 512), (19, 36, 48), (296, 512, 2048), (40, 24, 16), (500, 96, 4096)])
 def test_gemm_f32_exact_modes(M, N, K):
     """gfe_gemm_f32 (f32 MFMA): every operand layout, bias, accumulation and split-K against an f64 matmul: f32-exact (<= 2e-6 of the
     largest |sum|), any sizes / alignments (the 1-wide logit layer, the 25/37-wide test models)."""
