@@ -80,13 +80,23 @@ __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __re
 }
 
 // ---- mean over tokens ----------------------------------------------------------------------------------------------------
+// block = (64 columns, sample): the four waves take every fourth token (four loads in flight each) and are folded in wave order -- one owner
+// and one summation order per element.  (Round 3's one-thread-per-column loop walked the L tokens as L dependent round trips: 19 us at 37.)
 __global__ __launch_bounds__(256) void mean_tokens_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int L, int dim) {
-    const int b = blockIdx.x;
-    for (int d = threadIdx.x; d < dim; d += 256) {
-        float s = 0.f;
-        for (int t = 0; t < L; ++t) s += x[((size_t)b * L + t) * dim + d];
-        y[(size_t)b * dim + d] = s / (float)L;
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, d = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (d < dim) {
+        const float* xb = x + (size_t)b * L * dim + d;
+        int t = wave;
+        for (; t + 12 < L; t += 16) {
+            a0 += xb[(size_t)t * dim]; a1 += xb[(size_t)(t + 4) * dim]; a2 += xb[(size_t)(t + 8) * dim]; a3 += xb[(size_t)(t + 12) * dim];
+        }
+        for (; t < L; t += 4) a0 += xb[(size_t)t * dim];
     }
+    part[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && d < dim) y[(size_t)b * dim + d] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)L;
 }
 __global__ __launch_bounds__(256) void mean_tokens_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int L, int dim) {
     const int b = blockIdx.y, t = blockIdx.x;
@@ -103,10 +113,20 @@ __global__ __launch_bounds__(256) void cross_attn_q1_fwd_kernel(const float* __r
     const int h = blockIdx.x, b = blockIdx.y, dim = H * dh;
     const float* qp = q + (size_t)b * dim + h * dh;
     float mx = -INFINITY;
+    const bool vec4 = ((dh | dim) & 3) == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0;     // 16-byte rows: four dims per load
     for (int j = threadIdx.x; j < nk; j += 256) {
         const float* kp = k + ((size_t)b * nk + j) * dim + h * dh;
         float s = 0.f;
-        for (int d = 0; d < dh; ++d) s = fmaf(qp[d], kp[d], s);
+        if (vec4) {
+            float s1 = 0.f;
+            for (int d = 0; d < dh; d += 4) {
+                const float4 qv = *reinterpret_cast<const float4*>(qp + d), kv = *reinterpret_cast<const float4*>(kp + d);
+                s = fmaf(qv.x, kv.x, s); s1 = fmaf(qv.y, kv.y, s1); s = fmaf(qv.z, kv.z, s); s1 = fmaf(qv.w, kv.w, s1);
+            }
+            s += s1;
+        } else {
+            for (int d = 0; d < dh; ++d) s = fmaf(qp[d], kp[d], s);
+        }
         s *= scale;
         sp[j] = s;
         mx = fmaxf(mx, s);
@@ -130,11 +150,20 @@ __global__ __launch_bounds__(256) void cross_attn_q1_fwd_kernel(const float* __r
         probs[((size_t)b * H + h) * nk + j] = pj;
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < dh; d += 256) {
-        float o = 0.f;
-        for (int j = 0; j < nk; ++j) o = fmaf(sp[j], v[((size_t)b * nk + j) * dim + h * dh + d], o);
-        out[(size_t)b * dim + h * dh + d] = o;
+    // out = sum_j p_j v_j: the four waves take every fourth key (two chains each) and are folded in wave order (round 3: dh threads walked
+    // all nk keys one dependent load after the other -- 19 of the kernel's 25 us at 192 keys)
+    float* po = scratch + 32;                     // [4][dh]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int d = lane; d < dh; d += 64) {
+        const float* vp = v + (size_t)b * nk * dim + h * dh + d;
+        float o0 = 0.f, o1 = 0.f;
+        int j = wave;
+        for (; j + 4 < nk; j += 8) { o0 = fmaf(sp[j], vp[(size_t)j * dim], o0); o1 = fmaf(sp[j + 4], vp[(size_t)(j + 4) * dim], o1); }
+        if (j < nk) o0 = fmaf(sp[j], vp[(size_t)j * dim], o0);
+        po[wave * dh + d] = o0 + o1;
     }
+    __syncthreads();
+    for (int d = threadIdx.x; d < dh; d += 256) out[(size_t)b * dim + h * dh + d] = (po[d] + po[dh + d]) + (po[2 * dh + d] + po[3 * dh + d]);
 }
 
 // dv = p dout^T, dp = dout . v, ds = p (dp - sum p dp), dq = scale * sum ds k, dk = scale * ds q
@@ -150,10 +179,20 @@ __global__ __launch_bounds__(256) void cross_attn_q1_bwd_kernel(const float* __r
     const float* dop = dout + (size_t)b * dim + h * dh;
     const float* pp = probs + ((size_t)b * H + h) * nk;
     float acc = 0.f;
+    const bool vec4 = ((dh | dim) & 3) == 0 && (((uintptr_t)dout | (uintptr_t)v) & 15) == 0;
     for (int j = threadIdx.x; j < nk; j += 256) {
         const float* vp = v + ((size_t)b * nk + j) * dim + h * dh;
         float dp = 0.f;
-        for (int d = 0; d < dh; ++d) dp = fmaf(dop[d], vp[d], dp);
+        if (vec4) {
+            float dp1 = 0.f;
+            for (int d = 0; d < dh; d += 4) {
+                const float4 gv = *reinterpret_cast<const float4*>(dop + d), vv = *reinterpret_cast<const float4*>(vp + d);
+                dp = fmaf(gv.x, vv.x, dp); dp1 = fmaf(gv.y, vv.y, dp1); dp = fmaf(gv.z, vv.z, dp); dp1 = fmaf(gv.w, vv.w, dp1);
+            }
+            dp += dp1;
+        } else {
+            for (int d = 0; d < dh; ++d) dp = fmaf(dop[d], vp[d], dp);
+        }
         sds[j] = dp;
         acc = fmaf(pp[j], dp, acc);
     }
@@ -167,11 +206,18 @@ __global__ __launch_bounds__(256) void cross_attn_q1_bwd_kernel(const float* __r
         dk[o] = sds[j] * qp[d];
         dv[o] = pp[j] * dop[d];
     }
-    for (int d = threadIdx.x; d < dh; d += 256) {
-        float s = 0.f;
-        for (int j = 0; j < nk; ++j) s = fmaf(sds[j], k[((size_t)b * nk + j) * dim + h * dh + d], s);
-        dq[(size_t)b * dim + h * dh + d] = s;
+    float* pq = scratch + 32;                     // [4][dh]: dq partials of the four waves (every fourth key each), folded in wave order
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int d = lane; d < dh; d += 64) {
+        const float* kp = k + (size_t)b * nk * dim + h * dh + d;
+        float s0 = 0.f, s1 = 0.f;
+        int j = wave;
+        for (; j + 4 < nk; j += 8) { s0 = fmaf(sds[j], kp[(size_t)j * dim], s0); s1 = fmaf(sds[j + 4], kp[(size_t)(j + 4) * dim], s1); }
+        if (j < nk) s0 = fmaf(sds[j], kp[(size_t)j * dim], s0);
+        pq[wave * dh + d] = s0 + s1;
     }
+    __syncthreads();
+    for (int d = threadIdx.x; d < dh; d += 256) dq[(size_t)b * dim + h * dh + d] = (pq[d] + pq[dh + d]) + (pq[2 * dh + d] + pq[3 * dh + d]);
 }
 
 
@@ -604,7 +650,8 @@ int gfe_embed_tokens_bwd(const float* dout, const int64_t* x_cat, const int64_t*
 int gfe_mean_tokens_fwd(const float* x, float* y, int64_t B, int64_t L, int64_t dim, void* stream) {
     GFE_REQUIRE(x && y, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && dim > 0, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(mean_tokens_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, y, (int)L, (int)dim);
+    GFE_REQUIRE(B <= 65535, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(mean_tokens_fwd_kernel, dim3((unsigned)ceil_div(dim, 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, y, (int)L, (int)dim);
     return gfe_launch_status();
 }
 int gfe_mean_tokens_bwd(const float* dy, float* dx, int64_t B, int64_t L, int64_t dim, void* stream) {
@@ -618,7 +665,7 @@ int gfe_cross_attn_q1_fwd(const float* q, const float* k, const float* v, float*
                           int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream) {
     GFE_REQUIRE(q && k && v && out && probs, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && nk > 0 && nk <= 8192 && dh > 0, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(cross_attn_q1_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 32) * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(cross_attn_q1_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 64 + 4 * dh) * sizeof(float), (hipStream_t)stream,
                        q, k, v, out, probs, (int)H, (int)nk, (int)dh, scale);
     return gfe_launch_status();
 }
@@ -626,7 +673,7 @@ int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const 
                           float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream) {
     GFE_REQUIRE(q && k && v && probs && dout && dq && dk && dv, GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && B <= 65535 && H > 0 && nk > 0 && nk <= 8192 && dh > 0, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(cross_attn_q1_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 32) * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(cross_attn_q1_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), (size_t)(nk + 64 + 4 * dh) * sizeof(float), (hipStream_t)stream,
                        q, k, v, probs, dout, dq, dk, dv, (int)H, (int)nk, (int)dh, scale);
     return gfe_launch_status();
 }
