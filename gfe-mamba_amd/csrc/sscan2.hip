@@ -784,9 +784,14 @@ __global__ __launch_bounds__(256) void sscan2_fold_kernel(const S2Bwd p, int nb_
     const int j = (int)(i & 31);
     const int64_t bt = i >> 5;
     const int b = (int)(bt / p.L), t = (int)(bt - (int64_t)b * p.L);
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += p.part_bc[(((size_t)b * G + g) * p.L + t) * 32 + j];
-    (j < 16 ? p.dBws : p.dCws)[(size_t)bt * p.ld_dbc + (j & 15)] = s;
+    // four chains (groups g, g + 1, g + 2, g + 3 of every four), folded in a fixed order: one chain is G dependent L2 round trips (10 us at 32)
+    const float* pb = p.part_bc + ((size_t)b * G * p.L + t) * 32 + j;
+    const size_t gs = (size_t)p.L * 32;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 3 < G; g += 4) { s0 += pb[g * gs]; s1 += pb[(g + 1) * gs]; s2 += pb[(g + 2) * gs]; s3 += pb[(g + 3) * gs]; }
+    for (; g < G; ++g) s0 += pb[g * gs];
+    (j < 16 ? p.dBws : p.dCws)[(size_t)bt * p.ld_dbc + (j & 15)] = (s0 + s1) + (s2 + s3);
 }
 
 template <typename T>

@@ -70,9 +70,13 @@ __global__ __launch_bounds__(256) void mid_linear_fold_kernel(const float* __res
                                                               int nchunks, int64_t n, int S) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float t = 0.f;
-    for (int k = 0; k < nchunks; ++k) t += part[(size_t)k * n + i];
-    out[i] = t + (bias ? bias[i % S] : 0.f);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;            // four chains, fixed fold (one chain = nchunks dependent round trips)
+    int k = 0;
+    for (; k + 3 < nchunks; k += 4) {
+        t0 += part[(size_t)k * n + i]; t1 += part[(size_t)(k + 1) * n + i]; t2 += part[(size_t)(k + 2) * n + i]; t3 += part[(size_t)(k + 3) * n + i];
+    }
+    for (; k < nchunks; ++k) t0 += part[(size_t)k * n + i];
+    out[i] = ((t0 + t1) + (t2 + t3)) + (bias ? bias[i % S] : 0.f);
 }
 
 // ---- head Linear weight gradient: dW[s][hw] = sum_{b,src,c} dout[b][src*C+c][s] * mid_src[b][hw][c] -------------------
