@@ -33,14 +33,16 @@ struct GemmF32Params {
     float* part;             // split-K partials [range][M][N], or NULL (f32 atomics)
 };
 
-// E = T * BK / 256 elements of a T-row x BK-deep operand tile per thread (256 threads).  K-major source: row = t / (BK / E),
-// k = E (t % (BK / E)) + i.  Reduction-major source: k = t / (T / E), row = E (t % (T / E)) + i.  vec: 16-byte loads are legal for this
-// operand (host-checked alignment).
+// E = T * BK / 256 elements of a T-row x BK-deep operand tile per thread (256 threads).  K-major source: row = t % T, k = E (t / T) + i
+// (consecutive lanes take consecutive ROWS: their LDS stores, E k-rows of T + 16 floats apart, then fall on consecutive banks -- with
+// consecutive lanes on consecutive k chunks, 16 (T + 16) floats apart = a multiple of 64 banks, every store was an 8-way conflict; the two
+// k chunks of a wave still share their banks: 2-way).  Reduction-major source: k = t / (T / E), row = E (t % (T / E)) + i.  vec: 16-byte
+// loads are legal for this operand (host-checked alignment).  The (row, k) -> LDS mapping and the k order of the sums are unchanged.
 template <int T, int BK>
 __device__ __forceinline__ void f32_tile_load(const float* __restrict__ base, int64_t ld, int tr, int vec, int row0, int nrows, int k0, int kend, int t, float (&v)[T * BK / 256]) {
     constexpr int E = T * BK / 256;
     int outer, inner, outer_n, inner_n;                      // element i of this thread: base[outer * ld + inner + i]
-    if (!tr) { outer = row0 + t / (BK / E); inner = k0 + E * (t % (BK / E)); outer_n = nrows; inner_n = kend; }
+    if (!tr) { outer = row0 + t % T; inner = k0 + E * (t / T); outer_n = nrows; inner_n = kend; }
     else { outer = k0 + t / (T / E); inner = row0 + E * (t % (T / E)); outer_n = kend; inner_n = nrows; }
     const float* q = base + (size_t)outer * ld + inner;
     if (vec && outer < outer_n && inner + E <= inner_n) {
@@ -58,7 +60,7 @@ template <int T, int BK>
 __device__ __forceinline__ void f32_tile_store(float* __restrict__ s, int tr, int t, const float (&v)[T * BK / 256]) {
     constexpr int E = T * BK / 256, LD = T + 16;
     if (!tr) {
-        const int r = t / (BK / E), k = E * (t % (BK / E));
+        const int r = t % T, k = E * (t / T);
 #pragma unroll
         for (int i = 0; i < E; ++i) s[(k + i) * LD + r] = v[i];
     } else {
@@ -321,6 +323,9 @@ bool ks_plan(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb,
     // parallelism and each would walk > 2 batches -- the staged kernel with K cut over the grid measured faster there (9.0 vs 12.5 us,
     // 8.5 vs 9.4, 10.3 vs 16.5: profiles/r04/gemm_f32_shapes.txt)
     if (tiles < 32 && groups > 32) return false;
+    // K-major B with enough 32 x 32 tiles to fill the chip without cutting K (in_proj forward: 640): the staged kernel in one launch, 15.9 vs
+    // 17.9 us since its tile stores stopped colliding on their LDS banks
+    if (!b_tr && tiles >= 512) return false;
     // (Measured and dropped: 64 x 32 tiles for the K-major form and 32 x 64 for every reduction-major shape -- a quarter less operand traffic,
     // half the waves: in_proj forward 17.9 -> 19.2 us, out_proj forward 13.0 -> 19.7, in_proj dgrad 16.4 -> 23.9.  These launches are bound by
     // how many independent load streams are in flight, not by the bytes.)

@@ -59,10 +59,10 @@ def test_f32_gemm_inblock_rule_is_a_host_side_function_of_shape_and_alignment():
     A, B = 0x7f0000000000, 0x7f0000100000                        # fake 16-byte aligned device addresses (never dereferenced)
     q = lambda M, N, K, a_tr=0, b_tr=0, a=A, b=B, lda=None, ldb=None: L.gfe_gemm_f32_inblock(
         a, lda if lda is not None else (M if a_tr else K), a_tr, b, ldb if ldb is not None else (N if b_tr else K), b_tr, M, N, K)
-    assert q(296, 2048, 512) == 1 and q(296, 512, 1024) == 1 and q(296, 1024, 32) == 1 and q(8, 512, 512) == 1        # forward products
+    assert q(296, 512, 1024) == 1 and q(296, 1024, 32) == 1 and q(8, 512, 512) == 1 and q(8, 4096, 512) == 1           # forward products
     assert q(296, 1024, 512, b_tr=1) == 1 and q(296, 512, 2048, b_tr=1) == 1 and q(296, 1024, 64, b_tr=1) == 1        # dgrad products
     assert q(296, 512, 500) == 0 and q(296, 512, 512, a=A + 4) == 0 and q(296, 512, 512, lda=514) == 0                # K % 16, alignment, ld % 4
     assert q(296, 512, 512, a_tr=1) == 0 and q(296, 30, 512, b_tr=1) == 0                                             # reduction-major A; N % 4
     assert q(6912, 1024, 256, b_tr=1) == 0 and q(513, 512, 512) == 0                                                  # the generator's row counts
     assert q(296, 64, 1024) == 0 and q(296, 32, 1024, b_tr=1) == 0 and q(8, 512, 2048) == 0                           # few tiles, long K
-    assert q(37, 2048, 512) == q(296, 2048, 512) == 1
+    assert q(37, 2048, 512) == 1 and q(296, 2048, 512) == 0                                                          # >= 512 tiles of 32 x 32: one staged launch
