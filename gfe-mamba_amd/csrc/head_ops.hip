@@ -150,17 +150,20 @@ __global__ __launch_bounds__(256) void cross_attn_q1_fwd_kernel(const float* __r
         probs[((size_t)b * H + h) * nk + j] = pj;
     }
     __syncthreads();
-    // out = sum_j p_j v_j: the four waves take every fourth key (two chains each) and are folded in wave order (round 3: dh threads walked
+    // out = sum_j p_j v_j: the four waves take every fourth key (four chains each) and are folded in wave order (round 3: dh threads walked
     // all nk keys one dependent load after the other -- 19 of the kernel's 25 us at 192 keys)
     float* po = scratch + 32;                     // [4][dh]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int d = lane; d < dh; d += 64) {
         const float* vp = v + (size_t)b * nk * dim + h * dh + d;
-        float o0 = 0.f, o1 = 0.f;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
         int j = wave;
-        for (; j + 4 < nk; j += 8) { o0 = fmaf(sp[j], vp[(size_t)j * dim], o0); o1 = fmaf(sp[j + 4], vp[(size_t)(j + 4) * dim], o1); }
-        if (j < nk) o0 = fmaf(sp[j], vp[(size_t)j * dim], o0);
-        po[wave * dh + d] = o0 + o1;
+        for (; j + 12 < nk; j += 16) {
+            o0 = fmaf(sp[j], vp[(size_t)j * dim], o0); o1 = fmaf(sp[j + 4], vp[(size_t)(j + 4) * dim], o1);
+            o2 = fmaf(sp[j + 8], vp[(size_t)(j + 8) * dim], o2); o3 = fmaf(sp[j + 12], vp[(size_t)(j + 12) * dim], o3);
+        }
+        for (; j < nk; j += 4) o0 = fmaf(sp[j], vp[(size_t)j * dim], o0);
+        po[wave * dh + d] = (o0 + o1) + (o2 + o3);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < dh; d += 256) out[(size_t)b * dim + h * dh + d] = (po[d] + po[dh + d]) + (po[2 * dh + d] + po[3 * dh + d]);
@@ -210,11 +213,14 @@ __global__ __launch_bounds__(256) void cross_attn_q1_bwd_kernel(const float* __r
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int d = lane; d < dh; d += 64) {
         const float* kp = k + (size_t)b * nk * dim + h * dh + d;
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int j = wave;
-        for (; j + 4 < nk; j += 8) { s0 = fmaf(sds[j], kp[(size_t)j * dim], s0); s1 = fmaf(sds[j + 4], kp[(size_t)(j + 4) * dim], s1); }
-        if (j < nk) s0 = fmaf(sds[j], kp[(size_t)j * dim], s0);
-        pq[wave * dh + d] = s0 + s1;
+        for (; j + 12 < nk; j += 16) {
+            s0 = fmaf(sds[j], kp[(size_t)j * dim], s0); s1 = fmaf(sds[j + 4], kp[(size_t)(j + 4) * dim], s1);
+            s2 = fmaf(sds[j + 8], kp[(size_t)(j + 8) * dim], s2); s3 = fmaf(sds[j + 12], kp[(size_t)(j + 12) * dim], s3);
+        }
+        for (; j < nk; j += 4) s0 = fmaf(sds[j], kp[(size_t)j * dim], s0);
+        pq[wave * dh + d] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < dh; d += 256) dq[(size_t)b * dim + h * dh + d] = (pq[d] + pq[dh + d]) + (pq[2 * dh + d] + pq[3 * dh + d]);
