@@ -322,7 +322,8 @@ bool ks_plan(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb,
     // few tiles and a long K (x_proj forward, dt_proj dgrad, the 8-row feed-forward's second product): 16 waves per tile are not enough
     // parallelism and each would walk > 2 batches -- the staged kernel with K cut over the grid measured faster there (9.0 vs 12.5 us,
     // 8.5 vs 9.4, 10.3 vs 16.5: profiles/r04/gemm_f32_shapes.txt)
-    if (tiles < 32 && groups > 32) return false;
+    static const bool force_few = getenv("GFE_F32_KS_FEW") != nullptr;     // experiments: the in-block split also for few-tile / long-K shapes
+    if (tiles < 32 && groups > 32 && !force_few) return false;
     // K-major B with enough 32 x 32 tiles to fill the chip without cutting K (in_proj forward: 640): the staged kernel in one launch, 15.9 vs
     // 17.9 us since its tile stores stopped colliding on their LDS banks
     if (!b_tr && tiles >= 512) return false;
