@@ -72,6 +72,9 @@ class ResidualBlock(nn.Module):
         self.norm = RMSNorm(config.d_model, config.rms_norm_eps)
 
     def forward(self, x):
+        if (_fused.usable(self.mixer, x) and self.norm.weight.dtype == torch.float32 and os.environ.get("GFE_MAMBA_UNFUSED") != "1"
+                and os.environ.get("GFE_MAMBA_SPLIT_RESIDUAL") != "1"):
+            return _fused.residual_mamba_block(self.mixer, self.norm, x)     # norm + block + residual add as one autograd node
         return self.mixer(self.norm(x)) + x                      # mamba.py:103
 
     def step(self, x, cache):

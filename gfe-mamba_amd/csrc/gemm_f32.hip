@@ -110,7 +110,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
                 for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    // D: row = 4 (lane >> 4) + reg, col = lane & 15
+    // D: row = 4 (lane >> 4) + reg, col = lane & 15.  An accumulation target is read up front, every element in flight at once (in program
+    // order each read-modify-write would be a dependent round trip: no load moves above the previous element's store).
+    float oldv[NI][NI][4];
+    const bool rmw = p.accumulate && gridDim.z == 1;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * (T / 2) + j * 16 + lr, m = m0 + wm * (T / 2) + i * 16 + 4 * lq + r;
+                oldv[i][j][r] = (rmw && n < p.N && m < p.M) ? p.C[(size_t)m * p.ldc + n] : 0.f;
+            }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
                     const float v = acc[i][j][r] + bv;
                     if (gridDim.z > 1 && p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];   // summed in a fixed order afterwards
                     else if (gridDim.z > 1) atomicAdd(c, v);     // C zeroed by the caller (or a gradient buffer being added to)
-                    else *c = p.accumulate ? v + *c : v;
+                    else *c = v + oldv[i][j][r];
                 }
             }
         }
@@ -237,6 +249,37 @@ __global__ __launch_bounds__(1024) void gemm_f32_ks_kernel(const GemmF32Params p
             }
         }
     }
+    // Wave 0 finishes the tile.  The accumulation target's values are fetched here, all in flight at once and under the tree below (a
+    // read-modify-write per element in program order is a dependent L2 round trip each: no load can move above the previous element's store).
+    float old[NA][NB][4];
+    f32x4 old4[NA][4];
+    const bool vec_c = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+    if (w == 0) {
+        if constexpr (BTR) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + 4 * lr, m = m0 + 16 * a + 4 * lq + r;
+                    old4[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.accumulate && n < p.N && m < p.M) {
+                        const float* c = p.C + (size_t)m * p.ldc + n;
+                        if (vec_c) old4[a][r] = *reinterpret_cast<const f32x4*>(c);
+                        else old4[a][r] = f32x4{c[0], c[1], c[2], c[3]};
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + 16 * b + lr, m = m0 + 16 * a + 4 * lq + r;
+                        old[a][b][r] = (p.accumulate && n < p.N && m < p.M) ? p.C[(size_t)m * p.ldc + n] : 0.f;
+                    }
+        }
+    }
     // fixed binary tree over the waves: round `half`: waves [half, 2 half) park their tiles, waves [0, half) add them
 #if defined(GFE_KS_EXP_NOTREE)   // timing experiment only: the waves' tiles are never summed
     for (int half = 0; half >= 1; half >>= 1) {
@@ -263,7 +306,7 @@ __global__ __launch_bounds__(1024) void gemm_f32_ks_kernel(const GemmF32Params p
     if constexpr (BTR) {
         const int n = n0 + 4 * lr;                            // the four tiles of a row: columns n .. n + 3
         if (n >= p.N) return;
-        const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+        const bool vec = vec_c;
         f32x4 bv4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv4 = f32x4{p.bias[n], p.bias[n + 1], p.bias[n + 2], p.bias[n + 3]};
 #pragma unroll
@@ -273,13 +316,12 @@ __global__ __launch_bounds__(1024) void gemm_f32_ks_kernel(const GemmF32Params p
                 const int m = m0 + 16 * a + 4 * lq + r;
                 if (m >= p.M) continue;
                 float* c = p.C + (size_t)m * p.ldc + n;
-                f32x4 v = f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]} + bv4;
+                const f32x4 v = (f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]} + bv4) + old4[a][r];
                 if (vec) {
-                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
                     *reinterpret_cast<f32x4*>(c) = v;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = p.accumulate ? v[j] + c[j] : v[j];
+                    for (int j = 0; j < 4; ++j) c[j] = v[j];
                 }
             }
     } else {
@@ -294,9 +336,7 @@ __global__ __launch_bounds__(1024) void gemm_f32_ks_kernel(const GemmF32Params p
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * a + 4 * lq + r;
                     if (m >= p.M) continue;
-                    float* c = p.C + (size_t)m * p.ldc + n;
-                    const float v = acc[a][b][r] + bv;
-                    *c = p.accumulate ? v + *c : v;
+                    p.C[(size_t)m * p.ldc + n] = (acc[a][b][r] + bv) + old[a][b][r];
                 }
         }
     }

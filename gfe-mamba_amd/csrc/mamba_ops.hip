@@ -7,7 +7,7 @@ namespace {
 
 // ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w ; one wave per row --------------------------------------------------
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                          float* __restrict__ rstd, int rows, int dim, float eps) {
+                                                          float* __restrict__ rstd, float* __restrict__ xcopy, int rows, int dim, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * dim;
@@ -17,7 +17,12 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     const float r = rsqrtf(s / (float)dim + eps);
     if (lane == 0) rstd[row] = r;
     float* yr = y + (size_t)row * dim;
-    for (int c = lane; c < dim; c += 64) yr[c] = xr[c] * r * w[c];
+    if (xcopy) {                                       // the residual branch's starting value for an accumulating out_proj (gfe_hip/mamba_block.py)
+        float* cr = xcopy + (size_t)row * dim;
+        for (int c = lane; c < dim; c += 64) { const float v = xr[c]; yr[c] = v * r * w[c]; cr[c] = v; }
+    } else {
+        for (int c = lane; c < dim; c += 64) yr[c] = xr[c] * r * w[c];
+    }
 }
 
 // dx = rstd * (g - x * rstd^2 * mean(g * x)),  g = dy * w ;  dw += dy * x * rstd.
@@ -29,7 +34,7 @@ constexpr int RMS_RB = 2;          // rows per wave
 constexpr int RMS_CV = 16;         // columns per lane kept in registers (dim <= 1024)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ rstd,
                                                           const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
-                                                          int rows, int dim, int nrb) {
+                                                          const float* __restrict__ dadd, int rows, int dim, int nrb) {
     __shared__ float colred[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= nrb) {
@@ -70,10 +75,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         s = wave_sum(s);
         const float kk = s * r * r / (float)dim;
         float* dxr = dx + (size_t)row * dim;
+        const float* ar = dadd ? dadd + (size_t)row * dim : nullptr;          // the residual branch's gradient, added here instead of by a launch of its own
 #pragma unroll
         for (int i = 0; i < RMS_CV; ++i) {
             const int c = lane + 64 * i;
-            if (c < dim) dxr[c] = r * (gv[i] * wv[i] - xv[i] * kk);
+            if (c < dim) { const float v = r * (gv[i] * wv[i] - xv[i] * kk); dxr[c] = ar ? v + ar[c] : v; }
         }
     }
 }
@@ -231,21 +237,21 @@ int gfe_mamba_step_ssm(const float* xc, const float* delta, const float* A_log, 
     return gfe_launch_status();
 }
 
-int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t rows, int64_t dim, float eps, void* stream) {
+int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, float* xcopy, int64_t rows, int64_t dim, float eps, void* stream) {
     GFE_REQUIRE(x && w && y && rstd, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && dim > 0, GFE_ERR_SHAPE);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, y, rstd, (int)rows, (int)dim, eps);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, y, rstd, xcopy, (int)rows, (int)dim, eps);
     return gfe_launch_status();
 }
 
-int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_accum,
+int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_accum, const float* dadd,
                     int64_t rows, int64_t dim, void* stream) {
     GFE_REQUIRE(x && w && rstd && dy && dx && dw_accum, GFE_ERR_NULL);
     GFE_REQUIRE(rows > 0 && rows <= 0x3fffffff && dim > 0, GFE_ERR_SHAPE);
     GFE_REQUIRE(dim <= 64 * RMS_CV, GFE_ERR_SHAPE);
     const int nrb = (int)ceil_div(rows, 4 * RMS_RB);
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)(nrb + ceil_div(dim, 64))), dim3(256), 0, (hipStream_t)stream,
-                       x, w, rstd, dy, dx, dw_accum, (int)rows, (int)dim, nrb);
+                       x, w, rstd, dy, dx, dw_accum, dadd, (int)rows, (int)dim, nrb);
     return gfe_launch_status();
 }
 

@@ -35,7 +35,10 @@ def _gemm_into(a, a_t, b, b_t, out):
 
 class _MambaBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, in_w, conv_w, conv_b, x_w, dt_w, dt_b, A_log, D, out_w):
+    def forward(ctx, x, in_w, conv_w, conv_b, x_w, dt_w, dt_b, A_log, D, out_w, norm_w=None, eps=0.0):
+        """norm_w given: x is the residual stream and the node is the whole pre-norm block, mixer(RMSNorm(x)) + x (mamba.py:103): the norm
+        kernel also leaves a copy of x that out_proj accumulates into, and the backward's norm kernel adds the residual branch's gradient --
+        no add launches either way."""
         Bsz, L, Dm = x.shape
         ED, R, N = conv_w.shape[0], dt_w.shape[1], A_log.shape[1]
         W = R + 2 * N
@@ -44,6 +47,13 @@ class _MambaBlockFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         det = lambda p: p.detach()
+        xres = rstd = resid = None
+        if norm_w is not None:
+            xres = x2
+            x2 = torch.empty_like(xres)
+            rstd = torch.empty(Bsz * L, dtype=F32, device=dev)
+            resid = torch.empty_like(xres)
+            call("gfe_rmsnorm_fwd", ptr(xres), ptr(det(norm_w)), ptr(x2), ptr(rstd), ptr(resid), Bsz * L, Dm, float(eps), stream())
         xz = K.gemm_f32(x2, False, det(in_w), False)                                   # (BL, 2 ED) = [xs | z]            mamba.py:204-207
         xc = torch.empty((Bsz * L, ED), dtype=F32, device=dev)
         call("gfe_dwconv1d_silu_fwd", ptr(xz), 2 * ED, ptr(det(conv_w)), ptr(det(conv_b)), ptr(xc), Bsz, L, ED, 4, stream())   # :208-212
@@ -64,14 +74,14 @@ class _MambaBlockFn(torch.autograd.Function):
         fcode = dtype_code(F32)
         call("gfe_sscan2_fwd", ptr(xc), ptr(delta), ptr(det(A_log)), ptr(dbc) + 4 * R, ptr(dbc) + 4 * (R + N), ptr(det(D)), ptr(xz) + 4 * ED,
              ptr(det(dt_b)), ptr(y), ptr(yscan), ptr(hstate), ptr(sdelta), ptr(ckpt), Bsz, L, ED, T, 1, fcode, fcode, 2 * ED, W, 1, stream())
-        out = K.gemm_f32(y, False, det(out_w), False)                                  # :223
-        ctx.save_for_backward(x2, xz, xc, dbc, delta, y, yscan, ckpt, sdelta, in_w, conv_w, conv_b, x_w, dt_w, dt_b, A_log, D, out_w)
+        out = K.gemm_f32(y, False, det(out_w), False, accum_into=resid)                # :223 (+ x: resid holds the stream)
+        ctx.save_for_backward(x2, xz, xc, dbc, delta, y, yscan, ckpt, sdelta, in_w, conv_w, conv_b, x_w, dt_w, dt_b, A_log, D, out_w, xres, rstd, norm_w)
         ctx.meta = (Bsz, L, Dm, ED, R, N, T, nc, x.dtype)
         return out.view(Bsz, L, Dm)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, xz, xc, dbc, delta, y, yscan, ckpt, sdelta, in_w, conv_w, conv_b, x_w, dt_w, dt_b, A_log, D, out_w = ctx.saved_tensors
+        x2, xz, xc, dbc, delta, y, yscan, ckpt, sdelta, in_w, conv_w, conv_b, x_w, dt_w, dt_b, A_log, D, out_w, xres, rstd, norm_w = ctx.saved_tensors
         Bsz, L, Dm, ED, R, N, T, nc, xdt = ctx.meta
         W = R + 2 * N
         dev = x2.device
@@ -121,13 +131,32 @@ class _MambaBlockFn(torch.autograd.Function):
         call("gfe_dwconv1d_silu_bwd", ptr(xz), 2 * ED, ptr(det(conv_w)), ptr(det(conv_b)), ptr(du), ptr(dxz), 2 * ED, ptr(dcw), ptr(dcb), ptr(cws),
              Bsz, L, ED, 4, stream())
         # in_proj
-        dx = K.gemm_f32(dxz, False, det(in_w), True).view(Bsz, L, Dm) if ctx.needs_input_grad[0] else None
+        need_dx = ctx.needs_input_grad[0] or norm_w is not None
+        dx = K.gemm_f32(dxz, False, det(in_w), True) if need_dx else None
         g_in = wgrad(in_w, dxz, x2)
+        g_norm = None
+        if norm_w is not None:
+            # through the norm, plus what reaches the stream directly (the residual): dx_stream = rmsnorm_bwd(d xn) + dout, one launch
+            nslot = _grad_slot(norm_w)
+            dnw = nslot if nslot is not None else torch.zeros_like(norm_w, dtype=F32)
+            dstream = torch.empty_like(xres)
+            call("gfe_rmsnorm_bwd", ptr(xres), ptr(det(norm_w)), ptr(rstd), ptr(dx), ptr(dstream), ptr(dnw), ptr(d2), Bsz * L, Dm, stream())
+            dx = dstream
+            g_norm = None if nslot is not None else dnw
+        dx = dx.view(Bsz, L, Dm) if (dx is not None and ctx.needs_input_grad[0]) else None
         return (dx, g_in, None if sw is not None else dcw, None if sb is not None else dcb, g_xw, g_dtw,
-                None if g_dtb is None else g_dtb, None if g_A is None else g_A.view(ED, N), None if g_D is None else g_D, g_out)
+                None if g_dtb is None else g_dtb, None if g_A is None else g_A.view(ED, N), None if g_D is None else g_D, g_out, g_norm, None)
 
 
 def mamba_block(block, x):
     """MambaBlock.forward (mamba.py:197-225) as ONE autograd node; `usable(block, x)` must hold."""
     return _MambaBlockFn.apply(x, block.in_proj.weight, block.conv1d.weight, block.conv1d.bias, block.x_proj.weight, block.dt_proj.weight,
-                               block.dt_proj.bias, block.A_log, block.D, block.out_proj.weight)
+                               block.dt_proj.bias, block.A_log, block.D, block.out_proj.weight, None, 0.0)
+
+
+def residual_mamba_block(block, norm, x):
+    """ResidualBlock.forward (mamba.py:97-103), mixer(norm(x)) + x, as ONE autograd node: the RMSNorm, the block above and the residual add
+    (whose two launches per layer -- forward add, backward gradient sum -- ride in the norm kernels); `usable(block, x)` must hold and
+    norm.weight must be f32."""
+    return _MambaBlockFn.apply(x, block.in_proj.weight, block.conv1d.weight, block.conv1d.bias, block.x_proj.weight, block.dt_proj.weight,
+                               block.dt_proj.bias, block.A_log, block.D, block.out_proj.weight, norm.weight, norm.eps)

@@ -328,7 +328,7 @@ class _RMSNormFn(torch.autograd.Function):
         w_ = w.detach().float().contiguous()
         y = torch.empty_like(x2)
         rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x2.device)
-        call("gfe_rmsnorm_fwd", ptr(x2), ptr(w_), ptr(y), ptr(rstd), x2.shape[0], x2.shape[1], float(eps), stream())
+        call("gfe_rmsnorm_fwd", ptr(x2), ptr(w_), ptr(y), ptr(rstd), None, x2.shape[0], x2.shape[1], float(eps), stream())
         ctx.save_for_backward(x2, w_, rstd)
         ctx.xs, ctx.w_ref = xs, w
         return y.view(xs)
@@ -340,7 +340,7 @@ class _RMSNormFn(torch.autograd.Function):
         dx = torch.empty_like(x2)
         slot = _grad_slot(ctx.w_ref)
         dw = slot if slot is not None else torch.zeros_like(w_)
-        call("gfe_rmsnorm_bwd", ptr(x2), ptr(w_), ptr(rstd), ptr(d), ptr(dx), ptr(dw), x2.shape[0], x2.shape[1], stream())
+        call("gfe_rmsnorm_bwd", ptr(x2), ptr(w_), ptr(rstd), ptr(d), ptr(dx), ptr(dw), None, x2.shape[0], x2.shape[1], stream())
         return dx.view(ctx.xs), (None if slot is not None else dw), None
 
 

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 42
+#define GFE_ABI_VERSION 43
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -448,9 +448,12 @@ int gfe_clip_adam(float* p, const float* g, float* m, float* v, void* p_bf16, co
 
 /* RMSNorm (cross_atten/mamba.py:408-418): y = x * rsqrt(mean(x^2, -1) + eps) * w over (rows, dim) f32; rstd (rows) is kept for
  * the backward: dx = rstd*(dy*w - x*rstd^2*mean(dy*w*x)), dw_accum += sum_rows dy*x*rstd (column-owner blocks: one owner and one
- * summation order per element, no atomics). */
-int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t rows, int64_t dim, float eps, void* stream);
-int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_accum,
+ * summation order per element, no atomics).
+ * ABI 43, the residual around a pre-norm block (mamba.py:103, `mixer(norm(x)) + x`) without launches of its own: xcopy (nullable) receives a
+ * copy of x -- the buffer an accumulating out_proj then adds the block's output to; dadd (nullable, (rows, dim)) is added to dx -- the
+ * gradient that reaches x through the residual branch. */
+int gfe_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, float* xcopy, int64_t rows, int64_t dim, float eps, void* stream);
+int gfe_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw_accum, const float* dadd,
                     int64_t rows, int64_t dim, void* stream);
 
 /* Depthwise causal Conv1d(k = 4, padding = 3, [:L]) + bias + SiLU on (B, L, ED) f32 (cross_atten/mamba.py:128-131, 208-212);

@@ -357,6 +357,31 @@ def test_head_alone_on_the_references_generator_outputs_meets_fp32_tolerance():
 
 
 @pytest.mark.gpu
+def test_residual_block_as_one_node_equals_norm_block_add(monkeypatch):
+    """ResidualBlock.forward as ONE autograd node (RMSNorm with the residual copy, the fused Mamba block, out_proj accumulating into the
+    copy; backward: the norm kernel adds the residual branch's gradient) against the three-node form mixer(norm(x)) + x: same forward bits
+    and the same gradients for the stream and every parameter (the sums are the same sums: only two add launches per layer are gone)."""
+    from cross_atten.mamba import Mamba, MambaConfig
+    torch.manual_seed(11)
+    m = Mamba(MambaConfig(d_model=64, n_layers=3, use_cuda=True)).to(DEV)
+    x = torch.randn(4, 37, 64, device=DEV)
+    outs = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("GFE_MAMBA_SPLIT_RESIDUAL", split)
+        xi = x.clone().requires_grad_(True)
+        for p_ in m.parameters():
+            p_.grad = None
+        y = m(xi)
+        (y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum().backward()
+        outs.append((y.detach().clone(), xi.grad.clone(), {n: p_.grad.clone() for n, p_ in m.named_parameters()}))
+    (y0, dx0, g0), (y1, dx1, g1) = outs
+    assert torch.equal(y0, y1)
+    assert torch.equal(dx0, dx1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(296, 512, 512), (37, 2048, 512), (300, 64, 1024), (8, 1, 512), (37, 40, 25), (5, 8, 8), (2048, 512, 296),
                                    (296, 2048, 512), (296, 32, 1024), (296, 1024, 32), (296, 1024, 64), (8, 4096, 512), (19, 36, 48), (296, 512, 2048), (40, 24, 16), (500, 96, 4096)])
 def test_gemm_f32_exact_modes(M, N, K):
