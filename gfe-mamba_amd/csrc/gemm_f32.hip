@@ -56,17 +56,23 @@ __device__ __forceinline__ void f32_tile_load(const float* __restrict__ base, in
         for (int i = 0; i < E; ++i) v[i] = (outer < outer_n && inner + i < inner_n) ? q[i] : 0.f;
     }
 }
+// LDS column swizzle of k-row k: columns are XORed with 4 ((k & 3) ^ 2 ((k >> 2) & 1)) -- a permutation of the four 4-float pieces inside
+// every aligned 16-column group.  The MFMA fragment reads take 16 consecutive columns of rows k .. k + 3 (k % 4 == 0), a whole group per
+// row: still one bank per lane.  The reduction-major tile stores (16-byte vectors, lanes 2k and 2k + 1 on row k, 48-float rows) hit every
+// bank-start four times without it; with it the 16 lanes of a store phase cover the 64 banks once.
+__device__ __forceinline__ int f32_swz(int k) { return ((k & 3) ^ ((k >> 1) & 2)) << 2; }
+
 template <int T, int BK>
 __device__ __forceinline__ void f32_tile_store(float* __restrict__ s, int tr, int t, const float (&v)[T * BK / 256]) {
     constexpr int E = T * BK / 256, LD = T + 16;
     if (!tr) {
         const int r = t % T, k = E * (t / T);
 #pragma unroll
-        for (int i = 0; i < E; ++i) s[(k + i) * LD + r] = v[i];
+        for (int i = 0; i < E; ++i) s[(k + i) * LD + (r ^ f32_swz(k + i))] = v[i];
     } else {
         const int k = t / (T / E), r = E * (t % (T / E));
 #pragma unroll
-        for (int j = 0; j < E / 4; ++j) *reinterpret_cast<f32x4*>(&s[k * LD + r + 4 * j]) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+        for (int j = 0; j < E / 4; ++j) *reinterpret_cast<f32x4*>(&s[k * LD + ((r + 4 * j) ^ f32_swz(k))]) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
     }
 }
 
@@ -101,9 +107,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
         for (int kk = 0; kk < FBK; kk += 4) {
             float a[NI], b[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) a[i] = As[(kk + lq) * LD + wm * (T / 2) + i * 16 + lr];       // A[row = lane & 15][k = lane >> 4]
+            for (int i = 0; i < NI; ++i) a[i] = As[(kk + lq) * LD + ((wm * (T / 2) + i * 16 + lr) ^ f32_swz(kk + lq))];       // A[row = lane & 15][k = lane >> 4]
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = Bs[(kk + lq) * LD + wn * (T / 2) + j * 16 + lr];       // B[k = lane >> 4][col = lane & 15]
+            for (int j = 0; j < NI; ++j) b[j] = Bs[(kk + lq) * LD + ((wn * (T / 2) + j * 16 + lr) ^ f32_swz(kk + lq))];       // B[k = lane >> 4][col = lane & 15]
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -359,11 +365,12 @@ bool ks_plan(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb,
     pl.na = 2;
     if (b_tr && ceil_div(M, 32) * ceil_div(N, 64) * (groups < 16 ? groups : 16) < 2048) pl.na = 1;
     const int64_t tiles = b_tr ? ceil_div(M, 16 * pl.na) * ceil_div(N, 64) : ceil_div(M, 32) * ceil_div(N, 32);
-    // few tiles and a long K (x_proj forward, dt_proj dgrad, the 8-row feed-forward's second product): 16 waves per tile are not enough
+    // few tiles and a long K with a K-major B (x_proj forward, the 8-row feed-forward's second product): 16 waves per tile are not enough
     // parallelism and each would walk > 2 batches -- the staged kernel with K cut over the grid measured faster there (9.0 vs 12.5 us,
-    // 8.5 vs 9.4, 10.3 vs 16.5: profiles/r04/gemm_f32_shapes.txt)
+    // 10.3 vs 16.5: profiles/r04/gemm_f32_shapes.txt).  The reduction-major form keeps the in-block split: dt_proj's dgrad writes into a
+    // column range of a wider matrix with no split-K workspace, i.e. 10 staged blocks walking K = 1024 (16 us in the head's own trace)
     static const bool force_few = getenv("GFE_F32_KS_FEW") != nullptr;     // experiments: the in-block split also for few-tile / long-K shapes
-    if (tiles < 32 && groups > 32 && !force_few) return false;
+    if (!b_tr && tiles < 32 && groups > 32 && !force_few) return false;
     // K-major B with enough 32 x 32 tiles to fill the chip without cutting K (in_proj forward: 640): the staged kernel in one launch, 15.9 vs
     // 17.9 us since its tile stores stopped colliding on their LDS banks
     if (!b_tr && tiles >= 512) return false;
