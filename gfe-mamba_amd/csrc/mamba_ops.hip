@@ -64,22 +64,27 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         const float* xr = x + (size_t)row * dim;
         const float* gr = dy + (size_t)row * dim;
         const float r = rstd[row];
-        float xv[RMS_CV], gv[RMS_CV];
+        float xv[RMS_CV], gv[RMS_CV], av[RMS_CV];
+        const float* ar = dadd ? dadd + (size_t)row * dim : nullptr;          // the residual branch's gradient, added here instead of by a launch of its own
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < RMS_CV; ++i) {
             const int c = lane + 64 * i;
             xv[i] = c < dim ? xr[c] : 0.f; gv[i] = c < dim ? gr[c] : 0.f;
+            av[i] = (ar && c < dim) ? ar[c] : 0.f;                             // (fetched with the row, not behind its reduction)
             s = fmaf(gv[i] * wv[i], xv[i], s);
         }
         s = wave_sum(s);
         const float kk = s * r * r / (float)dim;
         float* dxr = dx + (size_t)row * dim;
-        const float* ar = dadd ? dadd + (size_t)row * dim : nullptr;          // the residual branch's gradient, added here instead of by a launch of its own
 #pragma unroll
         for (int i = 0; i < RMS_CV; ++i) {
             const int c = lane + 64 * i;
-            if (c < dim) { const float v = r * (gv[i] * wv[i] - xv[i] * kk); dxr[c] = ar ? v + ar[c] : v; }
+            if (c < dim) {
+                float v = r * (gv[i] * wv[i] - xv[i] * kk);
+                asm volatile("" : "+v"(v));                    // rounded here: the sum below must not contract into an fma (the same bits as a separate add launch)
+                dxr[c] = v + av[i];
+            }
         }
     }
 }
