@@ -419,8 +419,11 @@ int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t 
     p.ksplit = (int)(ceil_div(ceil_div(K, split_k), 128) * 128);
     const unsigned nz = (unsigned)ceil_div(K, p.ksplit);
     p.part = nz > 1 ? splitk_ws : nullptr;
-    // 64 x 64 tiles only when they alone put >= 512 blocks on the chip; otherwise four times as many 32 x 32 blocks, a quarter of the MFMAs each
-    if (ceil_div(M, 64) * ceil_div(N, 64) * nz >= 512)
+    // 64 x 64 tiles when they alone put a block on every CU; otherwise four times as many 32 x 32 blocks, a quarter of the MFMAs each
+    // (from one 64 x 64 tile per CU: the head's weight gradients -- K = 296 token rows, three 128-deep steps of a 32 x 32 tile, each with its
+    // exposed round trip -- took two rounds of 32 x 32 blocks; head graph 1 789 -> 1 768 us per replay; 128 tiles: 1 838.  GFE_F32_T64_MIN: experiments)
+    static const int64_t t64_min = getenv("GFE_F32_T64_MIN") ? atoll(getenv("GFE_F32_T64_MIN")) : 256;
+    if (ceil_div(M, 64) * ceil_div(N, 64) * nz >= t64_min)
         hipLaunchKernelGGL((gemm_f32_kernel<64, 32>), dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64), nz), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<32, 128>), dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), nz), dim3(256), 0, (hipStream_t)stream, p);
