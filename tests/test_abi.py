@@ -64,5 +64,6 @@ def test_f32_gemm_inblock_rule_is_a_host_side_function_of_shape_and_alignment():
     assert q(296, 512, 500) == 0 and q(296, 512, 512, a=A + 4) == 0 and q(296, 512, 512, lda=514) == 0                # K % 16, alignment, ld % 4
     assert q(296, 512, 512, a_tr=1) == 0 and q(296, 30, 512, b_tr=1) == 0                                             # reduction-major A; N % 4
     assert q(6912, 1024, 256, b_tr=1) == 0 and q(513, 512, 512) == 0                                                  # the generator's row counts
-    assert q(296, 64, 1024) == 0 and q(296, 32, 1024, b_tr=1) == 0 and q(8, 512, 2048) == 0                           # few tiles, long K
+    assert q(296, 64, 1024) == 0 and q(8, 512, 2048) == 0                                                             # K-major B, few tiles, long K
+    assert q(296, 32, 1024, b_tr=1) == 1                                                                              # dt_proj's dgrad (no split-K workspace at its call site)
     assert q(37, 2048, 512) == 1 and q(296, 2048, 512) == 0                                                          # >= 512 tiles of 32 x 32: one staged launch
