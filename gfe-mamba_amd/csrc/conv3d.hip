@@ -857,11 +857,32 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     const int b = blockIdx.y, rl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int rho = blockIdx.x * 64 + rl;                    // packed row
     const bool live = rho < CoutPad;
-    for (int t = q; t < 27; t += 4) {
-        float a = 0.f;
-        if (t < ntaps && live)
-            for (int sl = 0; sl < nslab; ++sl) a += T[(((size_t)b * nslab + sl) * ntaps + t) * CoutPad + rho];
-        stv[t][rl] = a;
+    // a quarter's <= 7 taps x nslab partials: every load in flight before the first add (as a loop nest this was 7 x nslab dependent round
+    // trips, most of the launch's 14-16 us); the slabs are still added in slab order, one tap at a time: the same sums as before
+    {
+        constexpr int MAXS = 8;
+        const bool fits = nslab <= MAXS;
+        float v[7][MAXS];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int t = q + 4 * i;
+#pragma unroll
+            for (int sl = 0; sl < MAXS; ++sl)
+                v[i][sl] = (fits && t < 27 && t < ntaps && live && sl < nslab) ? T[(((size_t)b * nslab + sl) * ntaps + t) * CoutPad + rho] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int t = q + 4 * i;
+            if (t >= 27) continue;
+            float a = 0.f;
+            if (fits) {
+#pragma unroll
+                for (int sl = 0; sl < MAXS; ++sl) { if (sl < nslab) a += v[i][sl]; }
+            } else if (t < ntaps && live) {
+                for (int sl = 0; sl < nslab; ++sl) a += T[(((size_t)b * nslab + sl) * ntaps + t) * CoutPad + rho];
+            }
+            stv[t][rl] = a;
+        }
     }
     if (threadIdx.x < 27) {
         // class bits (1 d == 0, 2 d == D-1, 4 h == 0, 8 h == H-1, 16 w == 0, 32 w == W-1) of the faces the tap steps over: the tap leaves
