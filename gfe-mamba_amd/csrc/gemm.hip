@@ -8,6 +8,7 @@
 // owns 4 consecutive n of one m -> 8-byte stores.  LDS rows are 128 B with the 16-B chunks XOR-swizzled by (row & 7): every
 // ds_read_b128 fragment read takes the ideal 4 LDS cycles (tools/lds_bank_model.py; a 144-B padded stride costs 8).  Register-prefetched double buffering (global loads of tile k+1 fly under the MFMAs
 // of tile k).  f32 accumulate; epilogue: +bias, exact-erf GELU, +residual, bf16 or f32 store, or f32 atomics for split-K.
+#include <cstdlib>
 #include "common.h"
 #include "gemm_dma.h"
 
@@ -236,6 +237,127 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     }
 }
 
+// ---- skinny M (<= 256 rows): one block per output tile, its waves cut K between them ("ks") -------------------------------------------
+// The generator's mid ViT (vit.py:14-63: B*26 token rows against 512 ... 2048-wide weights) is 17 of these per forward.  On the tiled kernel
+// above each was a split-K launch over the grid plus a reduction launch (10.7 + 5.3 us at 26 rows): the tile loop's per-step barrier pair and
+// exposed round trip on a handful of k-steps per block.  Here a block owns a 32 x 32 output tile and 1 ... 16 waves each take a K range:
+// the MFMA 16x16x32 operand of a lane IS a 16-byte load of its row (8 consecutive k at 8 (lane >> 4)), so nothing passes through LDS but
+// the waves' partial tiles, summed in a fixed binary tree; wave 0 runs the epilogue (bias, exact-erf GELU, residual, bf16 / f32 store: the
+// tiled kernel's).  The K cut depends on K alone: a row's sums are formed in the same order whatever M is -- a volume's tokens come out bit
+// for bit the same in a batch of 1 and of 8 (tests/test_configs_gpu.py).
+template <int NA, int NB>
+__global__ __launch_bounds__(1024) void gemm_ks_kernel(const GemmParams p, const int kw) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ks_smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(ks_smem);           // [slot][tile][lane], nw / 2 slots
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.y * (16 * NA), n0 = blockIdx.x * (16 * NB);
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* ap[NA];
+    const bf16_t* bp[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ap[i] = p.A + (size_t)min(m0 + 16 * i + lr, p.M - 1) * p.lda + 8 * lq;       // rows / columns past the end: clamped, never stored
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bp[j] = p.B + (size_t)min(n0 + 16 * j + lr, p.N - 1) * p.ldb + 8 * lq;
+    const int kbeg = w * kw, kend = min(p.K, kbeg + kw);
+    constexpr int GB = 4;                                      // 32-deep k-steps fetched per batch
+    for (int k = kbeg; k < kend; k += 32 * GB) {
+        bf16x8 af[GB][NA], bf[GB][NB];
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int kg = k + 32 * g;
+            if (kg < kend) {                                   // wave-uniform
+#pragma unroll
+                for (int i = 0; i < NA; ++i) af[g][i] = *reinterpret_cast<const bf16x8*>(ap[i] + kg);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bf[g][j] = *reinterpret_cast<const bf16x8*>(bp[j] + kg);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            if (k + 32 * g < kend) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[g][j], af[g][i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    for (int half = nw >> 1; half >= 1; half >>= 1) {          // fixed binary tree over the waves
+        if (w >= half && w < 2 * half) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) red[((w - half) * NA * NB + i * NB + j) * 64 + lane] = acc[i][j];
+        }
+        __syncthreads();
+        if (w < half) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] += red[(w * NA * NB + i * NB + j) * 64 + lane];
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (w != 0) return;
+    // lane holds C[m = .. + lr][n = .. + 4 lq + 0..3]
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + 16 * i + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + 16 * j + 4 * lq;
+            if (n >= p.N) continue;                           // N % 4 == 0
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (p.res) {
+                if (p.res_f32) {
+                    const float4 rv = *reinterpret_cast<const float4*>((const float*)p.res + (size_t)m * p.ldres + n);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                } else {
+                    const uint2 rv = *reinterpret_cast<const uint2*>((const bf16_t*)p.res + (size_t)m * p.ldres + n);
+                    v[0] += bf16lo_to_f32(rv.x); v[1] += bf16hi_to_f32(rv.x); v[2] += bf16lo_to_f32(rv.y); v[3] += bf16hi_to_f32(rv.y);
+                }
+            }
+            if (p.out_f32) *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+
+// the shape takes gemm_ks_kernel: <= 256 rows, plain bf16 operands, whole 32-deep k-steps, 16-byte rows, a K that the tiled kernel would
+// have had to cut over the grid (K >= 256) and not the weight-streaming giants (the patch embedding's K = 147 456 keeps its grid-wide split)
+bool gemm_ks_usable(const GemmParams& p) {
+    static const bool off = getenv("GFE_GEMM_NO_KS") != nullptr;
+    if (off || p.a_mode != 0 || p.b_mode != 0 || p.M > 256 || (p.K & 31) || p.K < 256 || p.K > 8192 || p.N > 8192) return false;   // (wide N: the un-patchify projection streams 151 MB of weights once per 256 rows on the DMA loop)
+    if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return false;
+    if (p.act != 0 && p.act != 1) return false;
+    const int64_t esz = p.out_f32 ? 4 : 2;
+    if ((((uintptr_t)p.C) % (4 * esz)) || ((p.ldc * esz) % (4 * esz))) return false;
+    if (p.res && ((((uintptr_t)p.res) % (p.res_f32 ? 16 : 8)) || (p.ldres & 3))) return false;
+    return true;
+}
+int gemm_ks_launch(const GemmParams& p, hipStream_t st) {
+    const int groups = p.K / 32;
+    int nw = 1;
+    while (nw < 16 && 2 * nw <= groups) nw *= 2;               // a function of K alone (see above)
+    const int kw = (int)ceil_div(groups, nw) * 32;
+    hipLaunchKernelGGL((gemm_ks_kernel<2, 2>), dim3((unsigned)ceil_div(p.N, 32), (unsigned)ceil_div(p.M, 32)), dim3(64 * nw), (size_t)(nw / 2) * 4 * 1024, st, p, kw);
+    return gfe_launch_status();
+}
+
 // out[c][r] = in[r][c]  (bf16), 64x64 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                              int R, int Cc, int64_t ldi, int64_t ldo) {
@@ -343,6 +465,7 @@ int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
     p.ksplit = (int)ks; p.atomic = nsplit > 1;
     if (nsplit <= 1) p.part = nullptr;
     if (p.part && (p.ldc & 3)) return GFE_ERR_SHAPE;          // the reduction reads / writes C 16 bytes at a time
+    if (gemm_ks_usable(p)) { p.atomic = 0; p.part = nullptr; return gemm_ks_launch(p, st); }      // skinny M: no grid-wide split, no reduction launch
     if (nsplit == 1 && p.a_mode == 0 && p.b_mode == 0) {      // plain bf16 x bf16, K-major: the persistent LDS-DMA main loop (gemm_dma.hip)
         GemmDmaArgs d;
         d.A = p.A; d.B = p.B; d.C = p.C; d.bias = p.bias; d.res = p.res;

@@ -49,6 +49,36 @@ def test_gemm_epilogues_and_splitk():
     assert torch.equal(K.cast(f, BF), f.to(BF)) and torch.equal(K.cast(f.to(BF), torch.float32), f.to(BF).float())
 
 
+@pytest.mark.parametrize("N,K_", [(512, 512), (1536, 512), (2048, 512), (512, 2048)])
+def test_gemm_skinny_rows_in_block_k_split(N, K_):
+    """gemm_ks_kernel (csrc/gemm.hip; the mid ViT's projections, vit.py:14-63, at B*26 token rows): every epilogue against an f64 product of
+    the same bf16 operands, and a row's result does not depend on how many rows ride along -- the first 26 rows of a 208-row product are bit
+    for bit the 26-row product (what keeps a volume identical in a batch of 1 and of 8)."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(N + K_)
+    a = torch.randn(208, K_, generator=g).to(BF).to(DEV)
+    b = (torch.randn(N, K_, generator=g) / K_ ** 0.5).to(BF).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(208, N, generator=g).to(DEV)
+    ref = a.double() @ b.double().t()
+    for M in (208, 26, 1):
+        am, rm = a[:M], res[:M]
+        o32 = K.gemm_nt(am, b, out_dtype=torch.float32)
+        assert rel_err(o32, ref[:M]) < 2e-5
+        o16 = K.gemm_nt(am, b)
+        assert rel_err(o16, ref[:M]) < 5e-3
+        g1 = K.gemm_nt(am, b, bias=bias, act=1)
+        assert rel_err(g1, F.gelu(ref[:M] + bias.double())) < 5e-3
+        r1 = K.gemm_nt(am, b, bias=bias, res=rm, out_dtype=torch.float32)
+        assert rel_err(r1, ref[:M] + bias.double() + rm.double()) < 2e-5
+        r2 = K.gemm_nt(am, b, res=rm.to(BF), out_dtype=torch.float32)
+        assert rel_err(r2, ref[:M] + rm.to(BF).double()) < 2e-5
+        if M == 208:
+            full = (o32.clone(), g1.clone(), r1.clone())
+        else:
+            assert torch.equal(o32, full[0][:M]) and torch.equal(g1, full[1][:M]) and torch.equal(r1, full[2][:M])
+
+
 @pytest.mark.parametrize("nj", [4, 2])
 @pytest.mark.parametrize("M,N,K_", [(512, 128, 64), (1000, 256, 128), (2085, 512, 512), (777, 384, 1024), (13832, 1536, 512), (4099, 512, 2048), (600, 2048, 192), (200, 16384, 512)])
 def test_gemm_dma_main_loop(M, N, K_, nj, monkeypatch):
