@@ -111,6 +111,10 @@ class _SelectiveScan2(torch.autograd.Function):
              ptr(dD_ws) if D_ is not None else None, ptr(db_ws) if b_ is not None else None,
              ptr(ckpt), ptr(qstate), ptr(sdelta), ptr(pvec), ptr(pbc), Bsz, L, ED, T, int(softplus), dtype_code(dt), dtype_code(B_.dtype), 0, 0, 0, 0, stream())
         to = lambda g, i: None if in_dtypes[i] is None else g.to(in_dtypes[i])
+        if in_dtypes[3] is not None and in_dtypes[3] == in_dtypes[4] and in_dtypes[3] != torch.float32:
+            # dB and dC sit next to each other in the slab: one cast launch for both (the B = 1 step of config 2 is 135 us: every launch shows)
+            bc = slab[ED * 16:ED * 16 + 2 * Bsz * L * 16].to(in_dtypes[3])
+            dB_ws, dC_ws = bc[:Bsz * L * 16], bc[Bsz * L * 16:]
         return (to(du, 0), to(dd, 1), to(dA_ws.view(ED, 16), 2), to(dB_ws.view(Bsz, L, 16), 3), to(dC_ws.view(Bsz, L, 16), 4),
                 to(dD_ws, 5) if D_ is not None else None, to(dz, 6) if z_ is not None else None,
                 to(db_ws, 7) if b_ is not None else None, None, None, None)
