@@ -88,6 +88,34 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- timing fuzz (tools/timing_fuzz.py) -----------------------------------------------------------------------------
+// `make fuzz` builds gfe_hip/libgfe_hip_fuzz.so with -DGFE_TIMING_FUZZ: every GFE_FUZZ() site -- in front of the counted / full
+// s_waitcnt vmcnt waits, in front of and behind the stage barriers, in front of the LDS-DMA bursts and of every ticket draw / read of the
+// persistent kernels -- then parks its WAVE for a pseudo-random time: nothing at 3 of 4 visits, 1..32 x 64 cycles at 1 of 4, and 16k-32k
+// cycles (several tiles) at 1 of 128.  The generator state is one SGPR per wave, seeded from the real-time counter, the block and the wave,
+// so two launches never see the same schedule.  A kernel whose result depends on the relative timing of its waves (a missing wait, an LDS
+// buffer reused one barrier early, a ticket read before it was published) shows up as a bit difference against the product library;
+// a correct one is bit-identical under any schedule.  The product library compiles the sites to nothing.
+#if defined(GFE_TIMING_FUZZ)
+__device__ __forceinline__ unsigned gfe_fuzz_init() {
+    const unsigned t = (unsigned)__builtin_amdgcn_s_memrealtime();
+    unsigned s = t * 2654435761u ^ (blockIdx.x * 40503u + blockIdx.y * 9973u + 1u) * 2246822519u ^ ((threadIdx.x >> 6) + 1u) * 3266489917u;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)s);
+}
+__device__ __forceinline__ void gfe_fuzz_point(unsigned& s) {
+    s = (unsigned)__builtin_amdgcn_readfirstlane((int)(s * 1664525u + 1013904223u));
+    const unsigned r = s >> 20;                                        // 12 bits
+    unsigned n = (r & 3u) == 0u ? ((r >> 2) & 31u) + 1u : 0u;
+    if ((r >> 5) == 127u) n = 256u + ((r & 31u) << 3);
+    for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#define GFE_FUZZ_INIT() unsigned gfe_fz_ = gfe_fuzz_init()
+#define GFE_FUZZ() gfe_fuzz_point(gfe_fz_)
+#else
+#define GFE_FUZZ_INIT() do {} while (0)
+#define GFE_FUZZ() do {} while (0)
+#endif
+
 // ---- zero fill as a KERNEL --------------------------------------------------------------------------------------------------------
 // hipMemsetAsync inside a stream capture becomes a memset NODE, and on this ROCm graph replay does not keep such a node ordered behind
 // the kernel nodes in front of it: when the target block of the graph's private pool had an earlier tenant in the same graph, the

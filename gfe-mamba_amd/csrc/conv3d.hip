@@ -143,6 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
+    GFE_FUZZ_INIT();
 #if defined(GFE_EXP_KPRIO)     // experiment: issue priority over the waves of OTHER kernels that share the SIMD (the head's small launches on the second stream)
     __builtin_amdgcn_s_setprio(GFE_EXP_KPRIO);
 #endif
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     __shared__ int s_ticket;
     const bool dyn = !MC && p.sched != nullptr && upt >= 2;
     auto finish = [&]() {                                    // the last block of the launch leaves the counters at zero for the next one
+        GFE_FUZZ();
         if (dyn && tid == 0) {
             __threadfence();
             if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
@@ -183,8 +185,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     };
     int dyn_first = 0;
     if (dyn) {
+        GFE_FUZZ();
         if (tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
         __syncthreads();
+        GFE_FUZZ();
         dyn_first = xcd_begin + __builtin_amdgcn_readfirstlane(s_ticket);
         __syncthreads();                                     // (thread 0 overwrites the ticket at the top of the first unit)
         if (dyn_first >= xcd_end) { finish(); return; }
@@ -329,7 +333,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
 #if defined(GFE_EXP_WPRIO)     // ... or for the older half (the weight-DMA waves, whose pieces every stage barrier waits for)
     if (!a_wave) __builtin_amdgcn_s_setprio(GFE_EXP_WPRIO);
 #endif
+    GFE_FUZZ();
     if (a_wave) a_dma(cur, 0, 0, 0, A_PER_WAVE); else w_dma(cur, 0, 0, 0, 0);
+    GFE_FUZZ();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
 
@@ -340,7 +346,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         bool next_unit = u + 1 < nunits;
         if (dyn) {
             // first unit of a tile: draw the ticket of the tile after it; last unit (>= one stage barrier later): read it
+            GFE_FUZZ();
             if (ut == 0 && tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
+            GFE_FUZZ();
             if (ut1 == 0) {
                 nxt_t = xcd_begin + __builtin_amdgcn_readfirstlane(*(volatile int*)&s_ticket);
                 next_unit = nxt_t < xcd_end;
@@ -365,15 +373,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // weight waves drain their pieces every stage but the first: at s == 0 everything a wave had issued (weights of this
             // stage, the unit's tile) was drained BEFORE the previous unit's epilogue (below), so that epilogue's stores stay in
             // flight across this barrier instead of being waited for (vmcnt retires in order)
+            GFE_FUZZ();
             if (!a_wave && s > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (A_BUFS == 1) { if (a_wave && s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // the tile issued after the previous unit
             __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): no LDS read of the previous stage is still pending
+            GFE_FUZZ();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");                   // no LDS access is scheduled across the barrier
+            GFE_FUZZ();
 #endif
             GFE_STAMP(2);
             // refill the buffers nobody reads any more: next stage's weights, and (once per unit) the next unit's tile
             auto issue_dma = [&](bool do_w, bool do_a) {
+            GFE_FUZZ();
 #if !defined(GFE_EXP_NOW)      // timing experiment only: weights are never restaged
             if (!a_wave && do_w) {
                 if (s + 1 < nstage) w_dma(cur, group, slab, s + 1, (gstage + 1) & 1);
@@ -493,12 +505,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // (and under the CU's other block); the activation waves wait for it at the next unit's first barrier
             if (next_unit) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                GFE_FUZZ();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                GFE_FUZZ();
                 if (a_wave) a_dma(nxt, slab1, 0, 0, A_PER_WAVE);
             }
+            GFE_FUZZ();
             if (!a_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
+            GFE_FUZZ();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // see the stage barrier: nothing but the epilogue's stores crosses the unit boundary
         }
 
@@ -528,7 +544,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                 pooling = p.pool_y != nullptr;                                  // block-uniform
                 if (pooling) {                                                   // every wave has read its last fragments of this tile
                     __builtin_amdgcn_s_waitcnt(0xc07f);
+                    GFE_FUZZ();
                     __builtin_amdgcn_s_barrier();
+                    GFE_FUZZ();
                     asm volatile("" ::: "memory");
                 }
             }
@@ -737,8 +755,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             if constexpr (RES1 && FAST_OK) {
                 if (pooling) {
                     __builtin_amdgcn_s_waitcnt(0xc07f);
+                    GFE_FUZZ();
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    GFE_FUZZ();
                     if (!(wave & 1)) {                                           // lane -> (h pair xt, w pair, channel quad) of plane pair wave / 2
                         const int xt = lane >> 4, wq = (lane >> 2) & 3, q4 = lane & 3;
                         const uint4* a = reinterpret_cast<const uint4*>(pool_scr + ((((wave * 4 + xt) * 4 + wq) * 4 + q4) << 5));
@@ -785,7 +805,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
                     }
 #pragma unroll
                     for (int i = 0; i < NSTAT; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+                    GFE_FUZZ();
                     __syncthreads();
+                    GFE_FUZZ();
                     if (tid < 2 * WROWS_TAP) {
                         float t = 0.f;
 #pragma unroll
@@ -800,6 +822,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             }
         }
         GFE_STAMP(5);
+        GFE_FUZZ();
         if (!next_unit) break;
         if (ut + 1 == upt) {
             if (dyn) { cur_t = nxt_t; cur = nxt; }

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
+    GFE_FUZZ_INIT();
     const int ntiles = p.B * p.ntd * p.nth * p.ntw;
     // XCD-aware, interleaved tile walk (see conv3d.hip)
     const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
@@ -86,8 +87,10 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
         }
     };
     if (dyn) {
+        GFE_FUZZ();
         if (tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
         __syncthreads();
+        GFE_FUZZ();
         tile_begin = xcd_begin + rfl(s_ticket);
         __syncthreads();
     }
@@ -160,18 +163,21 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
     TilePos cur = decode(tile_begin);
     if (a_wave) { for (int sl = 0; sl < p.nslab; ++sl) a_dma(cur, sl); }
     if (w_prod) w_dma(CONVT_NCLS - 1, 0, 0);
+    GFE_FUZZ();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;
 
     for (int ti = 0; ti < my_tiles; ++ti) {
         bool next_tile = !dyn && ti + 1 < my_tiles;
         TilePos nxt = next_tile ? decode(tile_begin + (ti + 1) * nbx) : cur;
+        GFE_FUZZ();
         if (dyn && tid == 0) s_ticket = atomicAdd(p.sched + xcd, 1);
         int pf_slab = 0;                                          // slabs of the next tile already requested
         // classes in reverse buffer order: the host puts the heavy classes first, the 8-tap class must run LAST here
         for (int ci = CONVT_NCLS - 1; ci >= 0; --ci) {
             const int ntaps = p.c_ntaps[ci], lg = p.c_lg[ci], tap0 = p.c_tap0[ci];
             const int nk = ntaps * p.nslab, nst = (nk + TPS - 1) / TPS;
+            GFE_FUZZ();
             if (dyn && ci == 0) {                                  // seven classes' worth of barriers after the draw
                 const int nt_ = xcd_begin + rfl(*(volatile int*)&s_ticket);
                 next_tile = nt_ < tile_end;
@@ -185,11 +191,14 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
             for (int st = 0; st < nst; ++st, ++gstage) {
                 // st == 0: everything this wave had issued was drained at the end of the previous class (or before the loop); the
                 // first class of a tile additionally needs the tail of the tile prefetch the activation waves issued at the tile end
+                GFE_FUZZ();
                 if (w_prod && st > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the producer's queue holds weight stages only
                 if (a_wave && st == 0 && ci == CONVT_NCLS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                GFE_FUZZ();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                GFE_FUZZ();
                 if (!w_prod && st == 0 && p.res) {
                     // skip-tensor prefetch: the compute waves wait on vmcnt only at the end of a class, so the rows this class's epilogue
                     // adds are requested now (primary destination of the lane's two voxels, exactly as the epilogue computes it) and
@@ -247,12 +256,15 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
                     }
                 }
             }
+            GFE_FUZZ();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // only the epilogue's stores cross the class boundary
             if (ci == 0 && next_tile) {
                 // the slabs the last stages were still reading: request them now, they land under this epilogue
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                GFE_FUZZ();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                GFE_FUZZ();
 #if !defined(CONVT_EXP_NOA)
                 if (a_wave) { while (pf_slab < p.nslab) { a_dma(nxt, pf_slab); ++pf_slab; } }
 #endif
@@ -329,7 +341,9 @@ __global__ __launch_bounds__(NTHREADS) void convt_resident_kernel(const ConvTPar
                 }
             }
             gs[0] = gs[1] = gq[0] = gq[1] = 0.f;
+            GFE_FUZZ();
             __syncthreads();
+            GFE_FUZZ();
             if (tid < 128) {
                 float t = 0.f;
 #pragma unroll

@@ -465,7 +465,15 @@ int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
     p.ksplit = (int)ks; p.atomic = nsplit > 1;
     if (nsplit <= 1) p.part = nullptr;
     if (p.part && (p.ldc & 3)) return GFE_ERR_SHAPE;          // the reduction reads / writes C 16 bytes at a time
-    if (gemm_ks_usable(p)) { p.atomic = 0; p.part = nullptr; return gemm_ks_launch(p, st); }      // skinny M: no grid-wide split, no reduction launch
+    // split_k > 1 with a plain f32 output means "ADD the K ranges into the C the caller initialised" (gfe_hip.h; nn_ops.gemm_ex(accum_into=)):
+    // the in-block kernel used to overwrite C there;
+    // the in-block kernel keeps that contract by taking C itself as its f32 residual: C = C + A.B (one owner lane per element)
+    const bool accumulating = nsplit > 1 && p.out_f32 && p.act == 0 && p.res == nullptr;
+    if (gemm_ks_usable(p)) {                                   // skinny M: no grid-wide split, no reduction launch
+        if (accumulating) { p.res = p.C; p.res_f32 = 1; p.ldres = p.ldc; }
+        p.atomic = 0; p.part = nullptr;
+        return gemm_ks_launch(p, st);
+    }
     if (nsplit == 1 && p.a_mode == 0 && p.b_mode == 0) {      // plain bf16 x bf16, K-major: the persistent LDS-DMA main loop (gemm_dma.hip)
         GemmDmaArgs d;
         d.A = p.A; d.B = p.B; d.C = p.C; d.bias = p.bias; d.res = p.res;

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    GFE_FUZZ_INIT();
 
     // ---- this block's tiles: XCD-contiguous ranges, interleaved over the blocks that share the XCD
     const int G = gridDim.x, bid = blockIdx.x;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
         };
         // keep(n): wait until at most n UNITS' pieces of this wave are still in flight (everything older has landed), then the barrier
         auto keep_barrier = [&](int n) {
+            GFE_FUZZ();
             if (n >= 2 && Gm::AHEAD >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * DNPW) : "memory");
             else if (n >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(DNPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -186,8 +188,10 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
         keep_barrier(min(U, Gm::AHEAD) - 1);                           // unit 0 has landed
         int s2 = Gm::AHEAD;
         for (int u = 0; u < U; ++u) {
+            GFE_FUZZ();
             issue_unit(s2);                                            // tau = 2u: unit u + AHEAD, into the slot unit u - 1 was read from
             if (++s2 == DRING) s2 = 0;
+            GFE_FUZZ();
             asm volatile("s_barrier" ::: "memory");
             // tau = 2u + 1: unit u + 1 must have landed before the barrier; the units behind it (up to AHEAD - 1 of them) stay in flight
             keep_barrier(min(Gm::AHEAD - 1, max(0, U - (u + 2))));
@@ -318,7 +322,9 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             GD_STAMP(2)
 #endif
+            GFE_FUZZ();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (the slot may be restaged once BOTH groups are past this barrier of theirs)
+            GFE_FUZZ();
             __builtin_amdgcn_sched_barrier(0);
             GD_STAMP(3)
             // ======== MFMA interval
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
             GD_STAMP(4)
 #endif
+            GFE_FUZZ();
             asm volatile("s_barrier" ::: "memory");
             GD_STAMP(5)
             if (++slot == DRING) slot = 0;

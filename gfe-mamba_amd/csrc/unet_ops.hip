@@ -259,6 +259,7 @@ __global__ __launch_bounds__(512) void conv3d_c1_k3_kernel(const TI* __restrict_
     __shared__ __attribute__((aligned(16))) float tab0[C];
     __shared__ float red[8 * 16];
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    GFE_FUZZ_INIT();
     const int lq = lane >> 4, lr = lane & 15;
     const int ntd = (D + 7) >> 3, nth = (H + 7) >> 3, ntw = (W + 7) >> 3, ntiles = ntd * nth * ntw;
     const int per = (ntiles + nblk - 1) / nblk, t_begin = blk * per, t_end = min(ntiles, t_begin + per);
@@ -301,11 +302,15 @@ __global__ __launch_bounds__(512) void conv3d_c1_k3_kernel(const TI* __restrict_
     for (int t = t_begin; t < t_end; ++t) {
         const int tw = t % ntw, th = (t / ntw) % nth, td = t / (ntw * nth);
         const int d0 = td * 8, h0 = th * 8, w0 = tw * 8;
+        GFE_FUZZ();
         __syncthreads();                                        // (previous tile's readers are done; first pass: tab0 visible)
+        GFE_FUZZ();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             if (tid + 512 * j < 1000) xt[tid + 512 * j] = pre[j];
+        GFE_FUZZ();
         __syncthreads();
+        GFE_FUZZ();
         if (t + 1 < t_end) fetch(t + 1);
         const int gd = d0 + wave;
         if (gd >= D) continue;                                  // (no barrier below in this iteration)

@@ -120,27 +120,58 @@ def test_config4_generator_128_cubed_batch2_vs_oracle():
     assert max(e) < 1.2e-2, e          # full-tensor maxima of 2 x 128^3 volumes (the T2 / T7 fixtures compare strided slices): measured 7e-3 .. 1e-2
 
 
-def test_batch8_at_96_cubed_equals_eight_batch1_runs():
+def _invariance_report(gen, x, b, fp8, fp1):
+    """what the failing box shows: the first diverging stage in network order, the tiles, the device (VERDICT r04 #1)"""
+    import gen_stages as G
+    d = G.first_divergence({k: v[b:b + 1] for k, v in fp8.items()}, fp1)
+    lines = ["batch-8 vs batch-1 of sample %d: first diverging stage %r, %d cells differ, first (sample, cell): %s" % (b, d[0], d[2], d[1])]
+    again8 = G.first_divergence(fp8, G.fingerprints(G.staged_forward(gen, x)))
+    again1 = G.first_divergence(fp1, G.fingerprints(G.staged_forward(gen, x[b:b + 1])))
+    lines.append("repeat of the batch-8 run: %s; repeat of the batch-1 run: %s" % (
+        "bit-identical" if again8 is None else "DIFFERS at %r (%d cells)" % (again8[0], again8[2]),
+        "bit-identical" if again1 is None else "DIFFERS at %r (%d cells)" % (again1[0], again1[2])))
+    lines.append("device: %s" % (G.device_report(),))
+    return "\n".join(lines)
+
+
+@pytest.mark.parametrize("repeats", [1, 4])
+def test_batch8_at_96_cubed_equals_eight_batch1_runs(repeats):
     """Config 3 / 5's per-GPU share.  Every sample of a batch of 8 must come out BIT FOR BIT as in a batch of one: the persistent conv
     kernels' tile ranges depend on B, but the GroupNorm partial sums are kept per tile of the sample (one slot per tile, summed in slot
     order in f64), the first block's one-channel conv runs a fixed number of blocks per sample, and split-K GEMMs cut K as a function of
     (N, K) alone up to 512 rows -- so nothing a sample's values are rounded through knows about the batch.  (Round 2: per-block partial
-    slots, 1.0e-2 / 1.1e-2 / 6.7e-3 of the tensor maximum apart after twelve layers of flipped bf16 roundings.)"""
+    slots, 1.0e-2 / 1.1e-2 / 6.7e-3 of the tensor maximum apart after twelve layers of flipped bf16 roundings.)
+    Every STAGE is compared (bit fingerprints per conv tile, tools/gen_stages.py), `repeats` times over (ADVICE r04: an N-repeat variant);
+    a failure names the first diverging stage, its tiles, whether either run repeats itself, and the device (round 4: one box of the pool
+    failed this test twice with nothing to go on; tools/timing_fuzz.py is the stress version of the same comparison)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_stages as G
     from gfe_hip.step import build_models
     import gfe_hip.det_init as det
     gen, head, ft = build_models(vol=(96, 96, 96), seed=0)
     x, x_cat, x_num, _ = det.det_inputs(8, (96, 96, 96), seed=77)
     x = x.to(DEV)
-    with torch.no_grad():
-        mi8, mo8, pet8 = gen(x, output_vit_mid=True)
-        mi8, mo8, pet8 = mi8.float().clone(), mo8.float().clone(), pet8.clone()
+    first8 = None
+    for rep in range(repeats):
+        st8 = G.staged_forward(gen, x)
+        mi8, mo8, pet8 = st8["mid_input"].float().clone(), st8["mid_output"].float().clone(), st8["pet"].clone()
+        fp8 = G.fingerprints(st8)
+        del st8
+        if first8 is None:
+            first8 = fp8
+        assert G.first_divergence(first8, fp8) is None, "two batch-8 runs differ: %s\n%s" % (G.first_divergence(first8, fp8), G.device_report())
         worst = [0.0, 0.0, 0.0]
         for b in range(8):
-            mi, mo, pet = gen(x[b:b + 1], output_vit_mid=True)
-            for j, (a, r) in enumerate(((mi8[b:b + 1], mi), (mo8[b:b + 1], mo), (pet8[b:b + 1], pet))):
+            st1 = G.staged_forward(gen, x[b:b + 1])
+            fp1 = G.fingerprints(st1)
+            for j, (a, r) in enumerate(((mi8[b:b + 1], st1["mid_input"]), (mo8[b:b + 1], st1["mid_output"]), (pet8[b:b + 1], st1["pet"]))):
                 worst[j] = max(worst[j], rel_err(a, r))
-    print("batch-8 vs batch-1 rel differences (mid_input, mid_output, pet): %.2e %.2e %.2e" % tuple(worst))
-    assert worst == [0.0, 0.0, 0.0], worst
+            del st1
+            assert G.first_divergence({k: v[b:b + 1] for k, v in fp8.items()}, fp1) is None, _invariance_report(gen, x, b, fp8, fp1)
+        print("batch-8 vs batch-1 rel differences (mid_input, mid_output, pet): %.2e %.2e %.2e" % tuple(worst))
+        assert worst == [0.0, 0.0, 0.0], worst
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

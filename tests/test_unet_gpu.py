@@ -77,6 +77,12 @@ def test_gemm_skinny_rows_in_block_k_split(N, K_):
             full = (o32.clone(), g1.clone(), r1.clone())
         else:
             assert torch.equal(o32, full[0][:M]) and torch.equal(g1, full[1][:M]) and torch.equal(r1, full[2][:M])
+        # gemm_ex(accum_into=...) with plain bf16 K-major operands, M <= 256 and K >= 1024 asks for split_k > 1 with no residual,
+        # which the header defines as "ADD into the C the caller holds"; the in-block kernel used to overwrite the accumulation target
+        if K_ >= 1024:
+            tgt = rm.clone()
+            K.gemm_ex(am, False, b, False, accum_into=tgt)
+            assert rel_err(tgt, ref[:M] + rm.double()) < 2e-5, "accum_into lost the earlier contributions"
 
 
 @pytest.mark.parametrize("nj", [4, 2])

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Timing-fuzz harness for the generator's hand-synchronised kernels (the batch-8 vs batch-1 mismatch that one
+box of the pool showed twice and 18 others never).
+
+The conv / transposed-conv / one-channel conv / LDS-DMA GEMM kernels order their LDS-DMA transfers, LDS reads, ticket hand-offs and stores
+with hand-counted `s_waitcnt vmcnt` waits and raw `s_barrier`s.  If one of those orders is wrong, the result depends on the relative timing
+of a block's waves -- which a normal run on a normal box never varies.  `make -C gfe-mamba_amd/csrc fuzz` builds the same sources with
+-DGFE_TIMING_FUZZ: every wait, barrier, DMA burst and ticket access is preceded by a per-wave pseudo-random `s_sleep` (common.h), so
+every launch sees another interleaving of its waves, including ones no box's clocks would produce.
+
+    python tools/timing_fuzz.py [--iters 200] [--vol 96] [--env K=V ...]
+
+1. child "ref": the PRODUCT library runs the generator at batch 8 and at batch 1 for each of the 8 samples and stores bit-exact
+   fingerprints of every stage output (tools/gen_stages.py: one 64-bit word per conv tile and sample); it also asserts batch 8 == batch 1.
+2. child "fuzz": GFE_HIP_LIB = the fuzz library; --iters times: batch 8, then batch 1 of sample (i mod 8); every stage of every run must
+   reproduce the reference fingerprints bit for bit.  A mismatch prints the first diverging stage in network order and the tiles, and the
+   run goes on (the count and the distinct stages are what localises a race).  --env switches (GFE_CONV_STATIC=1, GFE_CONV_BRICK=0,
+   GFE_GEMM_NO_DMA=1, GFE_CONVT_STREAMED=1) apply to both children, for bisecting.
+Exit code 0 = every fuzzed run bit-identical to the un-fuzzed library."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FUZZ_LIB = os.path.join(ROOT, "gfe-mamba_amd", "gfe_hip", "libgfe_hip_fuzz.so")
+
+
+def child(role, args):
+    sys.path.insert(0, os.path.join(ROOT, "gfe-mamba_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import gfe_hip
+    from gfe_hip.step import build_models
+    import gfe_hip.det_init as det
+    import gen_stages as G
+    vol = (args.vol,) * 3
+    gen, _, _ = build_models(vol=vol, seed=0)
+    x = det.det_inputs(8, vol, seed=77)[0].cuda()
+    lib = os.path.basename(gfe_hip.LIB_PATH)
+
+    def run(xb):
+        st = G.staged_forward(gen, xb)
+        fp = G.fingerprints(st)
+        del st
+        return fp
+
+    if role == "ref":
+        assert "fuzz" not in lib, lib
+        ref8 = run(x)
+        ref1 = [run(x[b:b + 1]) for b in range(8)]
+        bad = []
+        for b in range(8):
+            d = G.first_divergence({k: v[b:b + 1] for k, v in ref8.items()}, ref1[b])
+            if d:
+                bad.append((b, d))
+        again = G.first_divergence(ref8, run(x))
+        torch.save({"ref8": ref8, "ref1": ref1}, args.ref)
+        print(json.dumps({"role": "ref", "lib": lib, "device": G.device_report(), "batch8_vs_batch1_mismatches": [(b, d[0], d[2]) for b, d in bad],
+                          "batch8_repeat_mismatch": again and (again[0], again[2])}), flush=True)
+        return 1 if (bad or again) else 0
+
+    assert "fuzz" in lib, "the fuzz child must load the fuzz library (GFE_HIP_LIB): " + lib
+    ref = torch.load(args.ref)
+    ref8, ref1 = ref["ref8"], ref["ref1"]
+    fails, t0, ms8, ms1 = [], time.time(), [], []
+    for it in range(args.iters):
+        for batch in (8, 1):
+            b = it % 8
+            torch.cuda.synchronize(); t = time.time()
+            fp = run(x if batch == 8 else x[b:b + 1])
+            torch.cuda.synchronize(); (ms8 if batch == 8 else ms1).append((time.time() - t) * 1e3)
+            d = G.first_divergence(ref8 if batch == 8 else ref1[b], fp)
+            if d:
+                fails.append({"iter": it, "batch": batch, "sample": None if batch == 8 else b, "stage": d[0], "cells": d[1], "ncells": d[2]})
+                print("MISMATCH", json.dumps(fails[-1]), flush=True)
+    ms8.sort(); ms1.sort()
+    print(json.dumps({"role": "fuzz", "lib": lib, "iters": args.iters, "runs": 2 * args.iters, "mismatching_runs": len(fails),
+                      "stages": sorted({f["stage"] for f in fails}), "seconds": round(time.time() - t0, 1),
+                      "median_ms_incl_fingerprints": {"batch8": round(ms8[len(ms8) // 2], 1), "batch1": round(ms1[len(ms1) // 2], 1)}}), flush=True)
+    return 1 if fails else 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--vol", type=int, default=96)
+    ap.add_argument("--env", action="append", default=[], help="K=V for both children (bisect switches)")
+    ap.add_argument("--ref", default=os.path.join(ROOT, "gpurun_out", "timing_fuzz_ref.pt"))
+    ap.add_argument("--role", default=None)
+    args = ap.parse_args()
+    if args.role:
+        sys.exit(child(args.role, args))
+    if not os.path.exists(FUZZ_LIB):
+        subprocess.check_call(["make", "-j", "8", "-C", os.path.join(ROOT, "gfe-mamba_amd", "csrc"), "fuzz"])
+    os.makedirs(os.path.dirname(args.ref), exist_ok=True)
+    env = dict(os.environ)
+    for kv in args.env:
+        k, v = kv.split("=", 1)
+        env[k] = v
+    base = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--vol", str(args.vol), "--ref", args.ref]
+    env.pop("GFE_HIP_LIB", None)
+    rc_ref = subprocess.call(base + ["--role", "ref"], env=env)                  # children, never an exec of a GPU-initialised process
+    env["GFE_HIP_LIB"] = FUZZ_LIB
+    rc_fuzz = subprocess.call(base + ["--role", "fuzz"], env=env)
+    print("timing_fuzz: ref rc %d (batch 8 == batch 1 on the product library), fuzz rc %d (%s)" % (
+        rc_ref, rc_fuzz, "every fuzzed run bit-identical" if rc_fuzz == 0 else "MISMATCHES, see above"))
+    sys.exit(1 if (rc_ref or rc_fuzz) else 0)
+
+
+if __name__ == "__main__":
+    main()
