@@ -13,6 +13,9 @@ from cross_atten.sd_cross_atten import CrossAttention
 from gfe_hip.head_ops import LayerNorm, embed_tokens, mean_tokens
 from gfe_hip.train_ops import Condition, Linear, aux_region
 
+import os
+_MATERIALISED_KV = os.environ.get("GFE_XATTN_MATERIALISED") == "1"
+
 
 class Cross_mamba_both(nn.Module):
     def __init__(self, *, categories, num_continuous, dim, depth, heads, dim_head=16, dim_out=1, num_special_tokens=2,
@@ -41,15 +44,19 @@ class Cross_mamba_both(nn.Module):
         assert x_categ.shape[-1] == self.num_categories, f'you must pass in {self.num_categories} values for your categories input'
         if image_condition is None:
             raise ValueError("Cross_mamba_both needs image_condition=[mri, pet] (the reference fails with NameError at :124)")
-        # the image condition and its K / V projections (94 % of the head's FLOPs) do not depend on the token stack: side stream, joined
-        # in front of the cross-attention (gfe_hip.train_ops.aux_region)
-        with aux_region() as aux:
+        # the condition is read in place from the f32 volumes by the one-query cross-attention (no K / V projections, no bf16 copies: round 5)
+        if _MATERIALISED_KV:      # A/B switch (GFE_XATTN_MATERIALISED=1): round 4's path -- bf16 K / V projections of the condition on a side stream
+            with aux_region() as aux:
+                whole_condition = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))
+                kv = self.final_cross.project_kv(whole_condition)
+        else:
             whole_condition = image_condition if isinstance(image_condition, Condition) else Condition(list(image_condition))   # :89-94
-            kv = self.final_cross.project_kv(whole_condition)
+            kv = None
         x = self._tokens(x_categ, x_numer, feature_img)                                           # :97-117, one kernel each way
         x = self.transformer(x)
         x = mean_tokens(x)                                                                        # :122
-        aux.join()
+        if kv is not None:
+            aux.join()
         x = self.final_cross(x, whole_condition, kv=kv) + x                                       # :124
         x = self.final_feed(x) + x                                                                # :125
         return self.to_logits(x.squeeze(1))                                                       # :127-131

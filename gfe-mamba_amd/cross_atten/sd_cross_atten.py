@@ -1,16 +1,17 @@
 """CrossAttention / SelfAttention -- MI355X build of the reference's cross_atten/sd_cross_atten.py (:7-37, :39-70).
-Same constructor arguments and state-dict keys (q_proj, k_proj, v_proj, out_proj / in_proj, out_proj).  The four
-q / out projections run on the exact-f32 MFMA GEMM; the K/V projections of the image condition (94 % of the trainable FLOPs) on the
-bf16 one, reading the bf16 condition buffers of gfe_hip.train_ops.Condition in both GEMM layouts so neither forward nor weight
-gradient re-casts or transposes the 28 MB condition; the one-query softmax attention between them is gfe_cross_attn_q1.
+Same constructor arguments and state-dict keys (q_proj, k_proj, v_proj, out_proj / in_proj, out_proj).  The q / out projections run on
+the exact-f32 MFMA GEMM.  CrossAttention is called with ONE query per sample by the classifier (mamba_transformer.py:122-124); for one
+query the K / V projections of the image condition -- 94 % of the trainable FLOPs in the reference -- fold away algebraically
+(gfe_cross_attn_q1_folded, csrc/xattn_fold.hip): scores = (W_k^T q) . y_j, output = W_v (sum_j p_j y_j) + b_v, exact f32, the condition
+read in place from the f32 volumes.  The materialised path (project_kv + gfe_cross_attn_q1, bf16 K / V GEMMs) is kept for a condition
+that needs its own gradient and for callers that pass precomputed kv.
 
 No torch-math attention is left in these modules (round 4): SelfAttention runs on gfe_sdpa_small (sequences up to 64 tokens, head dim
-<= 64: the sizes of the classifier's token stream), CrossAttention on gfe_cross_attn_q1 (one query per sample = every call the
-reference makes, mamba_transformer.py:124-126); anything else raises instead of silently leaving the HIP path."""
+<= 64: the sizes of the classifier's token stream); CrossAttention with more than one query raises instead of silently leaving the HIP path."""
 import torch
 from torch import nn
 
-from gfe_hip.head_ops import cross_attn_q1, sdpa_small
+from gfe_hip.head_ops import cross_attn_q1, cross_attn_q1_folded, sdpa_small
 from gfe_hip.train_ops import Condition, Linear, linear
 
 
@@ -43,8 +44,9 @@ class CrossAttention(nn.Module):
         self.d_head = d_embed // n_heads
 
     def project_kv(self, y):
-        """k, v = k_proj(y), v_proj(y) (sd_cross_atten.py:52-53) for y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition; they do not
-        depend on the queries, so a caller may compute them early, beside the token stack (Cross_mamba_both.forward)."""
+        """k, v = k_proj(y), v_proj(y) (sd_cross_atten.py:52-53) MATERIALISED, for y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition
+        (bf16 matrix-core operands beyond F32_LINEAR_MAX_K inputs).  Only the multi-query path needs them: with one query per sample
+        forward() never forms K or V (csrc/xattn_fold.hip)."""
         if isinstance(y, Condition):
             a16, aT16 = y.cond.view(-1, y.d_cross), y.condT
             d = self.k_proj.weight.shape[0]
@@ -53,13 +55,28 @@ class CrossAttention(nn.Module):
             return k, v
         return self.k_proj(y), self.v_proj(y)
 
+    @staticmethod
+    def _images(y):
+        """the condition as a list of f32 (B, d_cross, keys_i) matrices whose COLUMNS are the keys: a Condition's volumes in place, or
+        the transpose of a plain (B, Lkv, d_cross) tensor"""
+        if isinstance(y, Condition):
+            return y.images
+        return [y.detach().float().transpose(1, 2).contiguous()]
+
     def forward(self, x, y, kv=None):
-        """x: (B, Lq, d_embed); y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition (kv: project_kv(y) computed earlier).
-        sd_cross_atten.py:49-70."""
+        """x: (B, Lq, d_embed); y: (B, Lkv, d_cross) tensor or a gfe_hip.train_ops.Condition (kv: project_kv(y) computed earlier, multi-query
+        calls only).  sd_cross_atten.py:49-70.
+        Lq == 1 -- every call the classifier makes (mamba_transformer.py:122-124) -- takes the folded kernels: scores = (W_k^T q) . y,
+        output = W_v (sum_j p_j y_j) + b_v, exact f32, the condition read in place, K and V never formed.  Lq > 1 (the reference's
+        Transformer_Cross, corss_ft_transformer.py:123-133, never instantiated by the classify scripts) raises: no torch-math attention is
+        kept in the product modules."""
         b, lq, d = x.shape
         q = self.q_proj(x)
+        if lq == 1 and kv is None and not (torch.is_tensor(y) and y.requires_grad):
+            return self.out_proj(cross_attn_q1_folded(q, self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias,
+                                                      self.n_heads, self._images(y)))
         k, v = kv if kv is not None else self.project_kv(y)
-        if lq != 1:
-            raise NotImplementedError("CrossAttention on the HIP path takes ONE query per sample (gfe_cross_attn_q1: every call of the reference, "
-                                      f"mamba_transformer.py:124-126); got {lq} queries -- no torch-math fallback is kept")
-        return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))              # one kernel each way
+        if lq == 1:
+            return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))           # (a condition that itself wants a gradient)
+        raise NotImplementedError("CrossAttention on the HIP path takes ONE query per sample (every call of the reference's classifier, "
+                                  f"mamba_transformer.py:122-124); got {lq} queries -- no torch-math fallback is kept")

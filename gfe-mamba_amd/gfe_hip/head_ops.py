@@ -2,8 +2,13 @@
 one-query cross attention, LayerNorm over rows, GEGLU + dropout, BCE(sigmoid).  f32, one launch per operator and direction."""
 import torch
 
-from . import call, ptr, stream
-from .train_ops import _grad_slot
+from . import call, lib, ptr, stream
+from .train_ops import _grad_slot, _leaf
+
+
+def call_int(name, *args):
+    """entry points that return a count (>= 0) instead of a status"""
+    return int(getattr(lib(), name)(*args))
 
 
 def _f(t):
@@ -116,6 +121,74 @@ def cross_attn_q1(q, k, v, n_heads):
     _need_cuda(q, "cross_attn_q1")
     assert q.shape[1] == 1
     return _CrossAttnQ1.apply(q, k, v, n_heads)
+
+
+class _CrossAttnQ1Folded(torch.autograd.Function):
+    """q_proj's output -> attention output (before out_proj) of CrossAttention with one query per sample, K / V projections folded away
+    (csrc/xattn_fold.hip): differentiable in q, k_proj.weight, v_proj.weight, v_proj.bias; the condition images carry no gradient (the
+    generator is frozen, classify_mamba.py:100); k_proj.bias gets an exactly-zero gradient (it cannot move a softmax)."""
+
+    @staticmethod
+    def forward(ctx, q, wk, bk, wv, bv, n_heads, *imgs):
+        qs = q.shape
+        E, HW = wk.shape
+        q_ = _f(q).reshape(-1, E)
+        B, H, dh = q_.shape[0], n_heads, E // n_heads
+        ims = [im.detach() for im in imgs]
+        D3 = ims[0].shape[-1]
+        assert all(im.dtype == torch.float32 and im.is_contiguous() and im.numel() == B * HW * D3 for im in ims) and 1 <= len(ims) <= 4
+        keys = len(ims) * D3
+        dev = q_.device
+        wk_, wv_, bv_ = wk.detach(), wv.detach(), (None if bv is None else _f(bv))
+        assert wk_.dtype == torch.float32 and wv_.dtype == torch.float32 and wk_.is_contiguous() and wv_.is_contiguous()
+        nch = call_int("gfe_cross_attn_q1_folded_chunks", HW)
+        r_ws = torch.empty((B, H, HW), dtype=torch.float32, device=dev)
+        part = torch.empty(B * len(ims) * nch * H * D3, dtype=torch.float32, device=dev)
+        p = torch.empty((B, H, keys), dtype=torch.float32, device=dev)
+        c = torch.empty((B, H, HW), dtype=torch.float32, device=dev)
+        o = torch.empty((B, E), dtype=torch.float32, device=dev)
+        ip = [ptr(im) for im in ims] + [None] * (4 - len(ims))
+        call("gfe_cross_attn_q1_folded_fwd", ptr(q_), ptr(wk_), ptr(wv_), ptr(bv_), *ip, len(ims), ptr(r_ws), ptr(part), ptr(p), ptr(c), ptr(o),
+             B, H, dh, HW, D3, stream())
+        ctx.save_for_backward(q_, p, c, *ims)
+        ctx.refs = (wk, bk, wv, bv)
+        ctx.meta = (B, H, dh, HW, D3, qs, r_ws, part)         # the two workspaces are reused by the backward (dc, partials)
+        return o.view(qs)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_, p, c, *ims = ctx.saved_tensors
+        wk, bk, wv, bv = ctx.refs
+        B, H, dh, HW, D3, qs, dc_ws, part = ctx.meta
+        E = H * dh
+        d = dout.float().reshape(B, E).contiguous()
+        dev = d.device
+        ds_ws = torch.empty_like(p)
+        dr = torch.empty_like(c)
+        dq = torch.empty((B, E), dtype=torch.float32, device=dev)
+        ip = [ptr(im) for im in ims] + [None] * (4 - len(ims))
+        call("gfe_cross_attn_q1_folded_bwd", ptr(d), ptr(wk.detach()), ptr(wv.detach()), *ip, len(ims), ptr(p),
+             ptr(dc_ws), ptr(part), ptr(ds_ws), ptr(dr), ptr(dq), B, H, dh, HW, D3, stream())
+        # the weight gradients are leaves of the backward: on the side stream when they go straight into the optimizer's slots (train_ops._leaf)
+        (dwk, own_k), (dwv, own_v) = _acc_target(wk), _acc_target(wv)
+        dbv, own_b = (None, True) if bv is None else _acc_target(bv)
+        fn = lambda: call("gfe_cross_attn_q1_folded_wgrad", ptr(d), ptr(q_), ptr(c), ptr(dr), ptr(dwk), ptr(dwv), ptr(dbv), B, H, dh, HW, stream())
+        if own_k and own_v and own_b:
+            _leaf(fn, dwk, d, q_, c, dr)
+        else:
+            fn()
+        gbk = None
+        if bk is not None and _grad_slot(bk) is None:
+            gbk = torch.zeros_like(bk)                         # exactly zero; a FlatAdam slot simply stays as zero_grad left it
+        return (dq.view(qs), None if own_k else dwk, gbk, None if own_v else dwv, None if (own_b or bv is None) else dbv, None) + (None,) * len(ims)
+
+
+def cross_attn_q1_folded(q, k_weight, k_bias, v_weight, v_bias, n_heads, images):
+    """softmax(q (W_k y + b_k)^T / sqrt(d_head)) (W_v y + b_v) per head for ONE query per sample, q (B, 1, E) -> (B, 1, E), without ever
+    forming K or V (sd_cross_atten.py:49-70 between q_proj and out_proj).  images: list of f32 contiguous (B, HW, D3) tensors, key
+    i*D3 + j = images[i][b, :, j] -- the condition volumes (B, 1, h, w, d) of mamba_transformer.py:89-94 read in place."""
+    _need_cuda(q, "cross_attn_q1_folded")
+    return _CrossAttnQ1Folded.apply(q, k_weight, k_bias, v_weight, v_bias, n_heads, *images)
 
 
 class _SdpaSmall(torch.autograd.Function):

@@ -382,26 +382,51 @@ def dwconv1d_silu(x, conv_weight, conv_bias):
 
 
 class Condition:
-    """bf16 image condition of Cross_mamba_both (mamba_transformer.py:89-94) in the two layouts the K/V GEMMs read:
-    cond (B*keys, d_cross) for the forward, condT (d_cross, B*keys) for the weight gradient."""
+    """Image condition of Cross_mamba_both (mamba_transformer.py:89-94: rearrange 'b c h w d -> b (c d) (h w)' of [mri, pet], keys = the
+    d-slices of every image, d_cross = h*w features each).
+
+    `images` holds what the one-query cross-attention reads (csrc/xattn_fold.hip): each volume as an f32 (B, h*w, d) matrix whose COLUMNS
+    are the keys -- the volume's own memory when it is f32 and contiguous, so building a Condition then launches nothing.
+    `cond` (B, keys, d_cross) / `condT` (d_cross, B*keys) are the bf16 copies the MATERIALISED K / V projections read (forward / weight
+    gradient layout); they are built on first use only (multi-query calls, a condition that wants its own gradient)."""
 
     def __init__(self, images):
         B = images[0].shape[0]
         HW = images[0].shape[2] * images[0].shape[3]
         D3 = images[0].shape[4]
         n = len(images)
-        dev = images[0].device
         self.B, self.keys, self.d_cross = B, n * D3, HW
-        self.cond = torch.empty((B, n * D3, HW), dtype=BF16, device=dev)
-        self.condT = torch.empty((HW, B * n * D3), dtype=BF16, device=dev)
-        for i, img in enumerate(images):
-            assert img.shape[1] == 1, "condition images are single-channel"
+        self.images = []
+        for img in images:
+            assert img.shape[1] == 1 and tuple(img.shape) == (B, 1) + tuple(images[0].shape[2:]), "condition images are single-channel volumes of one shape"
             src = img.detach().float().contiguous()
             if src.is_cuda and not torch.cuda.is_current_stream_capturing():
-                src.record_stream(torch.cuda.current_stream())          # the condition may be built on the side stream (aux_region); under
+                src.record_stream(torch.cuda.current_stream())          # the condition may be built on a side stream (aux_region); under
                                                                         # capture the inputs are the graph's own static buffers
-            call("gfe_transpose_f32_to_bf16", ptr(src), self.cond.data_ptr() + i * D3 * HW * 2, B, HW, D3, n * D3 * HW, HW, stream())
-            call("gfe_interleave_rows_bf16", ptr(src), ptr(self.condT), B, HW, D3, B * n * D3, n * D3, i * D3, stream())
+            self.images.append(src.view(B, HW, D3))
+        self._cond = self._condT = None
+
+    def _materialise(self):
+        B, n, HW = self.B, len(self.images), self.d_cross
+        D3 = self.keys // n
+        dev = self.images[0].device
+        self._cond = torch.empty((B, n * D3, HW), dtype=BF16, device=dev)
+        self._condT = torch.empty((HW, B * n * D3), dtype=BF16, device=dev)
+        for i, src in enumerate(self.images):
+            call("gfe_transpose_f32_to_bf16", ptr(src), self._cond.data_ptr() + i * D3 * HW * 2, B, HW, D3, n * D3 * HW, HW, stream())
+            call("gfe_interleave_rows_bf16", ptr(src), ptr(self._condT), B, HW, D3, B * n * D3, n * D3, i * D3, stream())
+
+    @property
+    def cond(self):
+        if self._cond is None:
+            self._materialise()
+        return self._cond
+
+    @property
+    def condT(self):
+        if self._condT is None:
+            self._materialise()
+        return self._condT
 
 
 class FlatAdam:

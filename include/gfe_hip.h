@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 43
+#define GFE_ABI_VERSION 44
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -403,6 +403,32 @@ int gfe_cross_attn_q1_fwd(const float* q, const float* k, const float* v, float*
                           int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
 int gfe_cross_attn_q1_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                           float* dq, float* dk, float* dv, int64_t B, int64_t H, int64_t nk, int64_t dh, float scale, void* stream);
+
+/* CrossAttention with one query per sample with the K / V projections folded away (cross_atten/sd_cross_atten.py:49-70 as called at
+ * cross_atten/mamba_transformer.py:122-124 on the condition of :89-94; csrc/xattn_fold.hip): nothing of size keys x E is ever formed.
+ *   q (B, E = H*dh) f32 = q_proj's output; Wk, Wv (E, HW) f32 = k_proj.weight / v_proj.weight; bv (E) = v_proj.bias or NULL
+ *   (k_proj.bias shifts every score of a head by the same amount: it drops out of the softmax, its gradient is exactly zero);
+ *   img0..img{n_img-1}: the condition images, each (B, HW, D3) f32 contiguous = the volume (B, 1, h, w, d) itself; key img*D3 + j is the
+ *   (h w)-vector img[b, :, j] (rearrange 'b c h w d -> b (c d) (h w)').
+ *   fwd writes p (B, H, n_img*D3) softmax probabilities, c (B, H, HW) = sum_j p_j y_j (both kept for the backward) and
+ *   o (B, E) = W_v c + b_v = the attention output BEFORE out_proj.  Workspaces: r_ws (B, H, HW), part_ws (B, n_img, chunks(HW), H, D3).
+ *   bwd: d_o (B, E) -> dq (B, E) and dr (B, H, HW) written (dr feeds _wgrad); workspaces dc_ws (B, H, HW), ds_ws (B, H, n_img*D3),
+ *   part_ws as above.  _wgrad ACCUMULATES dWk, dWv (E, HW) and dbv (E) into gradient slots.  Every sum in a fixed order: bit-reproducible.
+ * Limits: H <= 64, D3 <= 256, n_img <= 4, n_img*D3 <= 1024.  16-byte vector accesses when HW % 4 == 0, D3 % 4 == 0 and all bases are
+ * 16-byte aligned, scalar accesses otherwise. */
+int gfe_cross_attn_q1_folded_chunks(int64_t HW);
+int gfe_cross_attn_q1_folded_fwd(const float* q, const float* Wk, const float* Wv, const float* bv,
+                                 const float* img0, const float* img1, const float* img2, const float* img3, int n_img,
+                                 float* r_ws, float* part_ws, float* p, float* c, float* o,
+                                 int64_t B, int64_t H, int64_t dh, int64_t HW, int64_t D3, void* stream);
+int gfe_cross_attn_q1_folded_bwd(const float* d_o, const float* Wk, const float* Wv,
+                                 const float* img0, const float* img1, const float* img2, const float* img3, int n_img,
+                                 const float* p, float* dc_ws, float* part_ws, float* ds_ws, float* dr, float* dq,
+                                 int64_t B, int64_t H, int64_t dh, int64_t HW, int64_t D3, void* stream);
+/* the weight gradients, leaves of the backward (the caller may enqueue them on another stream, behind _bwd):
+ * dWv += d_o (x) c, dbv += sum_b d_o (dbv may be NULL), dWk += q (x) dr, per head; c from _fwd, dr from _bwd. */
+int gfe_cross_attn_q1_folded_wgrad(const float* d_o, const float* q, const float* c, const float* dr, float* dWk, float* dWv, float* dbv,
+                                   int64_t B, int64_t H, int64_t dh, int64_t HW, void* stream);
 
 /* Small multi-head self-attention for Jamba's AttentionSDPA (cross_atten/jamba.py:342-398: F.scaled_dot_product_attention, is_causal
  * when no cache is passed): q, k, v, out (B, L, H*dh) f32, L <= 64, dh <= 64; probs (B, H, L, L) kept for the backward.
