@@ -112,20 +112,19 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
     }
 
     f32x16 oacc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    // All 16 score registers of a lane belong to ONE query row, so the S chain can start from an accumulator that holds -m: the MFMA
-    // delivers S - m and p = exp2(that), no subtraction per score.  m starts at 0 (an arbitrary reference) and is moved at the first block
+    // TRACKED pass: all 16 score registers of a lane belong to ONE query row, so the S chain can start from an accumulator that holds -m: the
+    // MFMA delivers S - m and p = exp2(that), no subtraction per score.  m starts at 0 (an arbitrary reference) and is moved at the first block
     // and whenever a block's maximum exceeds it by more than 2^THR (deferred rescale: p <= 2^THR is harmless in f32 / bf16) -- a
     // wave-uniform branch the steady state does not take.
+    // UNTRACKED pass (round 5, the one that normally runs): the reference stays at m = 0 for the whole row, p = exp2(S) straight out of an S chain
+    // that starts from the constant 0 -- no row maximum, no exchange with lane ^ 32, no ballot, no branch: 13 of the ~60 vector instructions
+    // per 32-key block gone (the kernel is bound by vector issue).  exp2 / bf16 / the f32 accumulators carry 8 exponent bits, so
+    // this is EXACT arithmetic-wise as long as nothing leaves the exponent range: the row sum must end inside [2^-60, 2^100] (then the row's
+    // largest probabilities kept full precision and nothing overflowed); a block in which any row ends outside it -- scores beyond ~ +-60 in
+    // log2 units, which a softmax of LayerNorm'ed tokens does not produce -- is redone by the tracked pass (block-uniform decision through LDS).
     f32x16 negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-    float lsum = 0.f;                          // this lane's share of the row sum
+    float lsum;                                // this lane's share of the row sum
     constexpr float THR = 6.0f;
-
     const int ntile = (p.n + KT - 1) / KT;
     // K/V tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, no staging registers): lane L of a piece fills
     // LDS slot L&7 of row L>>3, so it fetches the source chunk that the image's swizzle assigns to that slot.  Keys >= n lie beyond
@@ -162,12 +161,6 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
         }
     };
 
-    dma(0, 0);
-    if constexpr (RING > 2) { if (ntile > 1) dma(1, 1); }
-    // vmcnt retires in order: leaving the newest tile's pieces outstanding is a COUNTED wait (a vmcnt(0) here would drain the prefetch)
-    if (RING > 2 && ntile > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");   // one tile's pieces stay in flight
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-
     // LDS fragment addresses = a lane-constant offset (computed once, here) + the ring slot and the block's place in the tile, which are
     // compile-time constants because the tile loop is unrolled by RING -> they fold into the ds_read instructions' immediate offsets.
     // (Round 2 recomputed swizzles and a t % RING base per read: 25 of its 122 vector instructions per block.)
@@ -184,7 +177,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
             voff[db][1] = v_off(8 * (g >> 1) + qq + 4, chunk) + 8 * (pp & 1);
         }
     }
-    auto tile = [&](auto slot_c, const int t) {
+    auto tile = [&](auto slot_c, const bool track, const int t) {       // track: wave-uniform (the same value in every wave of the block)
         constexpr int SLOT = decltype(slot_c)::value;
         const uint8_t* sk = smem + SLOT * TILE_BYTES;
         const uint8_t* sv = smem + (RING + SLOT) * TILE_BYTES;
@@ -228,7 +221,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) { asm volatile("" :: "v"(kf[ds])); s[ds] += 1.0f; }
 #else
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);         // (untracked pass: negm stays 0)
 #pragma unroll
             for (int ds = 1; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
 #endif
@@ -256,19 +249,21 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
             // instead -- and the hazard recogniser does not look inside asm: a VALU read of an MFMA result needs 11 software wait states
             // after this 8-pass MFMA, the steady-state path had none, and the chain sometimes read the previous block's p values: spurious,
             // harmless, but run-to-run different moves of m.  Compiler-visible instructions get their s_nops and can be scheduled.)
-            float mx = fmaxf(s[0], s[1]);
-#pragma unroll
-            for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
-                const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
-            }
-            if (kidx == 0 || __builtin_amdgcn_ballot_w64(mx > THR)) {   // move the maximum (mx = -inf, a fully masked block, moves nothing)
-                const float d = (kidx == 0) ? mx : fmaxf(mx, 0.f);       // per row: new m = m + d
-                const float alpha = fast_exp2(-d);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-                lsum *= alpha;
+            if (track) {
+                float mx = fmaxf(s[0], s[1]);
+    #pragma unroll
+                for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
+                    const auto xm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = fmaxf(__uint_as_float(xm[0]), __uint_as_float(xm[1]));
+                }
+                if (kidx == 0 || __builtin_amdgcn_ballot_w64(mx > THR)) {   // move the maximum (mx = -inf, a fully masked block, moves nothing)
+                    const float d = (kidx == 0) ? mx : fmaxf(mx, 0.f);       // per row: new m = m + d
+                    const float alpha = (kidx == 0) ? 1.0f : fast_exp2(-d);       // (first block: O and l are still zero -- and exp2(-d) is inf for a first maximum below -128, 0 * inf = NaN: found by the round-5 fallback test)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+                    lsum *= alpha;
+                }
             }
             float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
@@ -329,17 +324,56 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #endif
     };
     static_assert(RING == 3, "the tile loop is unrolled by the ring depth");
-    for (int t = 0; t < ntile; t += 3) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntile) tile(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < ntile) tile(std::integral_constant<int, 2>{}, t + 2);
+    auto pass = [&](const bool track_c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+        lsum = 0.f;
+        dma(0, 0);
+        if constexpr (RING > 2) { if (ntile > 1) dma(1, 1); }
+        // vmcnt retires in order: leaving the newest tile's pieces outstanding is a COUNTED wait (a vmcnt(0) here would drain the prefetch)
+        if (RING > 2 && ntile > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES_PER_WAVE) : "memory");   // one tile's pieces stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int t = 0; t < ntile; t += 3) {
+            tile(std::integral_constant<int, 0>{}, track_c, t);
+            if (t + 1 < ntile) tile(std::integral_constant<int, 1>{}, track_c, t + 1);
+            if (t + 2 < ntile) tile(std::integral_constant<int, 2>{}, track_c, t + 2);
+        }
+    };
+    float l;
+#if defined(GFE_ATTN_ALWAYS_TRACK)      // A/B switch: round 4's kernel (the tracked pass only)
+    bool track = true;
+#else
+    bool track = false;
+#endif
+    for (;;) {                           // ONE instance of the tile loop in the code (two inlined copies cost 12-19 spilled registers at the 128 limit)
+        pass(track);
+        l = lsum + __shfl_xor(lsum, 32, 64);
+        if (track) break;
+        // every wave has left the last tile's barrier, so nobody reads the ring any more: its first word carries the block's verdict
+        volatile int* flag = reinterpret_cast<volatile int*>(smem);
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        const bool bad = (q0 + (lane_c & 31) < p.n) && !(l >= 8.6736174e-19f && l <= 1.2676506e30f);      // 2^-60 .. 2^100; NaN / inf are "bad"
+        if (tid == 0) *flag = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) *flag = 1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int redo = __builtin_amdgcn_readfirstlane(*flag);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         // (the flag is read before the ring is refilled)
+        if (!redo) break;
+        track = true;
     }
 
     // ---- normalise and store: lane (q, hi) holds d = 32*db + crow(r, hi) of its row
-    const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = (DROP ? p.inv_keep : 1.0f) / l;
-    const int q = q0 + ql;
-    if (p.nlse && hi == 0 && q < p.npad)        // the backward restarts its score chains from this value: exp2(S + nlse) = the normalised probability
+    int lane_o = lane;                            // opaque copy: the row index and the output address are recomputed HERE instead of being kept
+    asm volatile("" : "+v"(lane_o));              // alive (or spilled) across the tile loop as common subexpressions of the prologue's Q address
+    const int q = q0 + (lane_o & 31);
+    if (p.nlse && (lane_o >> 5) == 0 && q < p.npad)        // the backward restarts its score chains from this value: exp2(S + nlse) = the normalised probability
         p.nlse[(size_t)bh * p.npad + q] = q < p.n ? negm[0] - __builtin_amdgcn_logf(l) : -INFINITY;   // (v_log_f32 is log2)
     if (q < p.n) {
         bf16_t* op = p.o + (size_t)b * p.o_batch + (size_t)q * p.o_row + h * AD;
@@ -347,7 +381,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = 32 * db + 8 * r4 + 4 * hi;
+                const int d = 32 * db + 8 * r4 + 4 * (lane_o >> 5);
                 *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf16x2(oacc[db][4 * r4] * inv, oacc[db][4 * r4 + 1] * inv),
                                                                pack_bf16x2(oacc[db][4 * r4 + 2] * inv, oacc[db][4 * r4 + 3] * inv));
             }

@@ -393,6 +393,43 @@ def test_flash_attention_moved_maximum_branch():
     assert e < 2.5e-2, e              # scores of +-200 here: three orders of magnitude beyond a trained ViT's logits
 
 
+@pytest.mark.parametrize("shift", [0.0, -30.0, -70.0, -150.0, 30.0, 55.0, 90.0, 160.0])
+def test_flash_attention_untracked_pass_and_its_fallback(shift):
+    """Round 5: the forward first runs WITHOUT tracking a row maximum (reference m = 0, p = exp2(S) directly) and redoes a block with the
+    tracked pass only when a row's sum of exp2(S) leaves [2^-60, 2^100].  Shift every score of every row by `shift` (log2 units; softmax
+    does not care) by planting a constant component in q and k: 0 / -30 / +30 / +55 stay on the untracked pass with sums far from 1, -70 and 90 sit
+    just beyond its limits, -150 / +160 would underflow to l = 0 / overflow to inf there.  All must match the f64 softmax and, in training
+    mode, give the row statistic -(logsumexp in log2 units) whichever pass produced it; two runs are bit-identical."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(5)
+    B, H, n, dh = 2, 2, 300, 64
+    q = torch.randn(B, n, H, dh, generator=g)
+    k = torch.randn(B, n, H, dh, generator=g)
+    v = torch.randn(B, n, H, dh, generator=g)
+    # last component: q_d = a, k_d = b with a * b * scale * log2(e) = shift (exact powers of two keep the planted product exact in bf16)
+    q[..., -1] = 8.0 if shift >= 0 else -8.0
+    k[..., -1] = abs(shift) / 8.0 / (dh ** -0.5 * 1.4426950408889634)
+    if shift != 0:
+        k[0, 7::13, 0, :-1] *= 3.0                       # some keys well above the row's typical score: rows with sums spread over decades
+    qkv = torch.cat([t.reshape(B * n, H * dh) for t in (q, k, v)], dim=1).to(BF).to(DEV)
+    inner = H * dh
+    o, nlse = K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, n, dh, dh ** -0.5, with_lse=True)
+    o2, nlse2 = K.attention_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, n, dh, dh ** -0.5, with_lse=True)
+    assert torch.equal(o, o2) and torch.equal(nlse, nlse2)
+    assert torch.isfinite(o.float()).all()
+    c = dh ** -0.5 * 1.4426950408889634
+    qs = (qkv[:, :inner].float().cpu() * c).to(BF).double().view(B, n, H, dh).transpose(1, 2)      # the kernel's own rounded operand
+    kd, vd = [t.double().view(B, n, H, dh).transpose(1, 2) for t in qkv.cpu().chunk(3, dim=-1)[1:]]
+    s2 = qs @ kd.transpose(-1, -2)                                                                  # log2 units
+    ref = (torch.softmax(s2 * 0.6931471805599453, dim=-1) @ vd).transpose(1, 2).reshape(B * n, inner)
+    e = rel_err(o, ref)
+    lse2 = torch.logsumexp(s2 * 0.6931471805599453, dim=-1) / 0.6931471805599453                   # (B, H, n)
+    e_l = (nlse.view(B, H, -1)[:, :, :n].double().cpu() + lse2).abs().max().item()
+    print("untracked / fallback pass, scores shifted by %+.0f (log2): rel err %.2e, row statistic abs err %.2e" % (shift, e, e_l))
+    assert e < 6e-3, e
+    assert e_l < 2e-3 * max(1.0, abs(shift) / 16), e_l
+
+
 @pytest.mark.parametrize("B,H,n", [(2, 8, 1729), (1, 2, 64), (1, 3, 65), (2, 1, 127), (1, 2, 300), (1, 1, 1), (1, 2, 513)])
 def test_flash_attention_backward_vs_autograd(B, H, n):
     """gfe_attention_bwd (dK/dV and dQ kernels, no atomics) against f64 autograd through softmax(q k^T / sqrt(d)) v on the same bf16
