@@ -165,9 +165,9 @@ class ScanWorkload:
         t_b = max(t_s - t_f, 1e-6)
         gbs = (self.bytes_fwd + self.bytes_bwd) / (t_s * 1e-3) / 1e9
         from gfe_hip.step_bench import measured_traffic
-        traffic = measured_traffic("scan_b8", ("profiles", "r04", "traffic_r04.json")) if (self.B, self.L, self.ED) == (8, 4096, 1024) else None
+        traffic = measured_traffic("scan_b8") if (self.B, self.L, self.ED) == (8, 4096, 1024) else None
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r04/traffic_r04.json (committed rocprofv3 PMC passes of this command, not this run)",
+                "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r05/traffic_r05.json (committed rocprofv3 PMC passes of this command, not this run)",
                 "kernel": "sscan2_fwd + sscan2_bwd (fused selective scan: state-pair lanes, 4 scan + 4 staging waves per block; one launch each way from B = 8, three each way when L is chunked)",
                 "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                 "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),
@@ -275,13 +275,13 @@ class Vit3dWorkload:
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": self._traffic(),
-                "traffic_source": "profiles/r04/traffic_r04.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.B == 8 else None,
+                "traffic_source": "profiles/r05/traffic_r05.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.B == 8 else None,
                 "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)", "launches_timed": iters,
                 "launch_ms": round(ms, 4), "algorithmic_flops": flops}
 
     def _traffic(self):
         from gfe_hip.step_bench import measured_traffic
-        return measured_traffic("attn_fwd_b8_h8_n1729", ("profiles", "r04", "traffic_r04.json")) if self.B == 8 else None
+        return measured_traffic("attn_fwd_b8_h8_n1729") if self.B == 8 else None
 
     def cpu_baseline(self):
         """oracle.ref_ops.vit3d (torch CPU restatement of vit_3d.py:113-128) on ONE volume."""

@@ -3,7 +3,6 @@ GEGLU :10-13, FeedForward :15-22, NumericalEmbedder :150-163 (same names / keys)
 (Attention, Transformer*, Cross_transformer*, FTTransformer_cross*) are earlier baselines that classify_mamba.py never
 instantiates and are out of scope."""
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from gfe_hip.head_ops import LayerNorm, geglu_dropout
@@ -12,10 +11,7 @@ from gfe_hip.train_ops import Linear
 
 class GEGLU(nn.Module):
     def forward(self, x):
-        if x.is_cuda:
-            return geglu_dropout(x)                   # one kernel each way (gfe_geglu_fwd / _bwd)
-        x, gates = x.chunk(2, dim=-1)
-        return x * F.gelu(gates)
+        return geglu_dropout(x)                       # one kernel each way (gfe_geglu_fwd / _bwd); CPU tensors raise (no CPU fallback)
 
 
 class _FeedForward(nn.Sequential):

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from cross_atten.mamba import MambaBlock, MambaConfig, RMSNorm
 from gfe_hip.moe_ops import moe_mlp
-from gfe_hip.head_ops import cross_attn_q1, sdpa_small
+from gfe_hip.head_ops import cross_attn_q1, sdpa_small, silu_mul
 from gfe_hip.train_ops import Linear
 
 
@@ -94,6 +94,8 @@ class Jamba(nn.Module):
     def step(self, x, caches):
         """Cached decoding, jamba.py:298-306: x (B, L, D) -- one token per call once the caches are warm (MambaLayer squeezes dim 1,
         jamba.py:421-423) -- and caches[i] from layers[i].get_empty_cache(...); returns (x, caches).  Inference only (no graph is recorded)."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError("Jamba.step is inference-only on the HIP path (no backward): call it under torch.no_grad() or detach its input")
         with torch.no_grad():
             for i, layer in enumerate(self.layers):
                 (x, _), caches[i] = layer(x, caches[i])
@@ -229,7 +231,7 @@ class MLP(nn.Module):
         self.up_proj = Linear(self.hidden_dim, self.ffn_dim, bias=False)
 
     def forward(self, x):
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))      # jamba.py:535
+        return self.down_proj(silu_mul(self.gate_proj(x), self.up_proj(x)))      # jamba.py:535: silu(gate) * up, one kernel each way
 
 
 def load_balancing_loss(router_logits, num_experts, num_experts_per_tok):

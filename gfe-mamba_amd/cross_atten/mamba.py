@@ -168,8 +168,14 @@ class MambaBlock(nn.Module):
         """x: (B, D); cache = (h (B, ED, N) or None, inputs (B, ED, d_conv - 1)) -> (output (B, D), new cache).  Inference only."""
         if not x.is_cuda:
             raise RuntimeError("MambaBlock.step runs on the GPU only (no CPU fallback)")
-        with torch.no_grad():                    # an inference path (the reference's callers run it in eval mode, often without no_grad):
-            return self._step(x.detach(), cache)     # nothing is recorded, the result carries no graph
+        # An inference path: the kernels behind it have no backward.  The reference's step is plain differentiable torch code (mamba.py:342-405);
+        # its callers run it in eval mode, often without no_grad -- that works here (nothing is recorded).  A caller who actually WANTS gradients
+        # through it -- grad mode on and an input that requires grad -- gets an error instead of silently detached results (ADVICE r04).
+        if torch.is_grad_enabled() and (x.requires_grad or any(t is not None and torch.is_tensor(t) and t.requires_grad for t in cache)):
+            raise RuntimeError("MambaBlock.step is inference-only on the HIP path (no backward): call it under torch.no_grad() or detach its "
+                               "inputs; to train through single tokens use forward() on a length-1 sequence")
+        with torch.no_grad():
+            return self._step(x.detach(), cache)
 
     def _step(self, x, cache):
         from gfe_hip import call, ptr, stream

@@ -7,7 +7,8 @@ read in place from the f32 volumes.  The materialised path (project_kv + gfe_cro
 that needs its own gradient and for callers that pass precomputed kv.
 
 No torch-math attention is left in these modules (round 4): SelfAttention runs on gfe_sdpa_small (sequences up to 64 tokens, head dim
-<= 64: the sizes of the classifier's token stream); CrossAttention with more than one query raises instead of silently leaving the HIP path."""
+<= 64: the sizes of the classifier's token stream; beyond that it raises); CrossAttention with several queries runs gfe_cross_attn_q1 over
+(sample, query) pairs."""
 import torch
 from torch import nn
 
@@ -68,8 +69,8 @@ class CrossAttention(nn.Module):
         calls only).  sd_cross_atten.py:49-70.
         Lq == 1 -- every call the classifier makes (mamba_transformer.py:122-124) -- takes the folded kernels: scores = (W_k^T q) . y,
         output = W_v (sum_j p_j y_j) + b_v, exact f32, the condition read in place, K and V never formed.  Lq > 1 (the reference's
-        Transformer_Cross, corss_ft_transformer.py:123-133, never instantiated by the classify scripts) raises: no torch-math attention is
-        kept in the product modules."""
+        Transformer_Cross, corss_ft_transformer.py:123-133, never instantiated by the classify scripts) materialises K / V and runs the
+        one-query kernel over (sample, query) pairs (the class stays general, as the reference's is)."""
         b, lq, d = x.shape
         q = self.q_proj(x)
         if lq == 1 and kv is None and not (torch.is_tensor(y) and y.requires_grad):
@@ -78,5 +79,11 @@ class CrossAttention(nn.Module):
         k, v = kv if kv is not None else self.project_kv(y)
         if lq == 1:
             return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))           # (a condition that itself wants a gradient)
-        raise NotImplementedError("CrossAttention on the HIP path takes ONE query per sample (every call of the reference's classifier, "
-                                  f"mamba_transformer.py:122-124); got {lq} queries -- no torch-math fallback is kept")
+        # several queries per sample (the reference's Transformer_Cross, corss_ft_transformer.py:123-133; never on the classify path): every
+        # query is an independent one-query problem over its sample's K / V -- the same kernel on (B * Lq) "samples"; the broadcast of K / V over
+        # the queries (and the sum of their gradients over them) is index glue, the attention arithmetic stays in gfe_cross_attn_q1
+        nk = k.shape[1]
+        kx = k.unsqueeze(1).expand(b, lq, nk, d).reshape(b * lq, nk, d)
+        vx = v.unsqueeze(1).expand(b, lq, nk, d).reshape(b * lq, nk, d)
+        o = cross_attn_q1(q.reshape(b * lq, 1, d), kx, vx, self.n_heads)
+        return self.out_proj(o.view(b, lq, d))

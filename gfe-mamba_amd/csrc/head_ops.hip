@@ -627,6 +627,23 @@ __global__ __launch_bounds__(256) void bce_sigmoid_fwd_kernel(const float* __res
     if (threadIdx.x == 0) loss[0] = s / (float)n;
 }
 
+// exact-erf GELU as an operator of its own (vit_pytorch_diy/vit_3d.py:21 / vit.py:19 inside FeedForward when the module TRAINS: the inference
+// path has it in the GEMM epilogue; under autograd the pre-activation has to survive for the backward): x, y f32 or bf16, 4 values per lane
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k < n) IO<T>::st(y + i + k, gelu_erf_(IO<T>::ld(x + i + k)));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k < n) IO<T>::st(dx + i + k, IO<T>::ld(dy + i + k) * gelu_erf_grad_(IO<T>::ld(x + i + k)));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -741,6 +758,25 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
     }
     GFE_REQUIRE(rows + ceil_div(dim, 64) <= 0x7fffffff, GFE_ERR_SHAPE);
     hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)(rows + ceil_div(dim, 64))), dim3(256), 0, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, (int)rows, (int)dim);
+    return gfe_launch_status();
+}
+
+int gfe_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    GFE_REQUIRE(x && y, GFE_ERR_NULL);
+    GFE_REQUIRE(n > 0, GFE_ERR_SHAPE);
+    int64_t g = ceil_div(n, 1024); if (g > 4096) g = 4096;
+    if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n);
+    else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n);
+    else return GFE_ERR_DTYPE;
+    return gfe_launch_status();
+}
+int gfe_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
+    GFE_REQUIRE(x && dy && dx, GFE_ERR_NULL);
+    GFE_REQUIRE(n > 0, GFE_ERR_SHAPE);
+    int64_t g = ceil_div(n, 1024); if (g > 4096) g = 4096;
+    if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, n);
+    else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+    else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }
 

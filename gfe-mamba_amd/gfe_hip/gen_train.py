@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from . import call, lib, nn_ops as K, ptr, stream
-from .head_ops import layernorm_rows, sdpa_small
+from .head_ops import gelu, layernorm_rows, sdpa_small
 from .nn_ops import BF16
 from .train_ops import linear
 
@@ -349,7 +349,7 @@ def vit_forward_train(vit, img):
         o = sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), attn.heads, causal=False, dropout_p=p_attn)
         x = _dropout(linear(o, attn.to_out[0].weight, attn.to_out[0].bias), attn.to_out[1]) + x
         h = layernorm_rows(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
-        h = _dropout(F.gelu(linear(h, ff.net[1].weight, ff.net[1].bias)), ff.net[3])
+        h = _dropout(gelu(linear(h, ff.net[1].weight, ff.net[1].bias)), ff.net[3])
         x = _dropout(linear(h, ff.net[4].weight, ff.net[4].bias), ff.net[5]) + x
     x = layernorm_rows(x, vit.transformer.norm.weight, vit.transformer.norm.bias, vit.transformer.norm.eps)
     # from_patch_embedding (vit.py:102-110)

@@ -2,7 +2,7 @@
 one-query cross attention, LayerNorm over rows, GEGLU + dropout, BCE(sigmoid).  f32, one launch per operator and direction."""
 import torch
 
-from . import call, lib, ptr, stream
+from . import call, dtype_code, lib, ptr, stream
 from .train_ops import _grad_slot, _leaf
 
 
@@ -311,6 +311,56 @@ def geglu_dropout(x, p_drop=0.0, training=False):
         _DROP_CALLS[0] += 1
         seed = (torch.initial_seed() * 1000003 + _DROP_CALLS[0]) & 0x7FFFFFFFFFFFFFFF
     return _Geglu.apply(x, p, seed, _STEP_CTR[0] if p > 0.0 else None)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x_ = x.detach().contiguous()
+        if x_.dtype not in (torch.float32, torch.bfloat16):
+            x_ = x_.float()
+        y = torch.empty_like(x_)
+        call("gfe_gelu_fwd", ptr(x_), ptr(y), x_.numel(), dtype_code(x_.dtype), stream())
+        ctx.save_for_backward(x_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x_,) = ctx.saved_tensors
+        d = dy.to(x_.dtype).contiguous()
+        dx = torch.empty_like(x_)
+        call("gfe_gelu_bwd", ptr(x_), ptr(d), ptr(dx), x_.numel(), dtype_code(x_.dtype), stream())
+        return dx
+
+
+def gelu(x):
+    """exact-erf GELU (torch.nn.functional.gelu's default; vit.py:19, vit_3d.py:21), one kernel each way, f32 or bf16."""
+    _need_cuda(x, "gelu")
+    return _Gelu.apply(x)
+
+
+class _SiluMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, u):
+        g_, u_ = _f(g), _f(u)
+        h = torch.empty_like(g_)
+        call("gfe_moe_act_fwd", ptr(g_), ptr(u_), ptr(h), g_.numel(), stream())
+        ctx.save_for_backward(g_, u_)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        g_, u_ = ctx.saved_tensors
+        d = dh.float().contiguous()
+        dg, du = torch.empty_like(g_), torch.empty_like(u_)
+        call("gfe_moe_act_bwd", ptr(g_), ptr(u_), ptr(d), ptr(dg), ptr(du), g_.numel(), stream())
+        return dg, du
+
+
+def silu_mul(gate, up):
+    """silu(gate) * up (the un-routed Jamba MLP, cross_atten/jamba.py:535) on the experts' activation kernels, one launch each way."""
+    _need_cuda(gate, "silu_mul")
+    return _SiluMul.apply(gate, up)
 
 
 class _BceSigmoid(torch.autograd.Function):

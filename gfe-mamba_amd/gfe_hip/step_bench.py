@@ -9,12 +9,34 @@ from .step import ClassifyStep, build_models
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-def measured_traffic(key, rel=("profiles", "r01", "traffic_v13.json")):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic_v13.json, profiles/r04/traffic_r04.json:
-    FETCH_SIZE x2 as the gfx950 correction prescribes + WRITE_SIZE, separate passes); None when the file does not travel with the tree."""
+TRAFFIC_JSON = ("profiles", "r05", "traffic_r05.json")
+_TRAFFIC_KERNEL_SOURCE = {"conv_igemm_64to64_96cubed_b8": "conv3d.hip", "attn_fwd_b8_h8_n1729": "attn.hip", "attn_bwd_b8_h8_n1729": "attn_bwd.hip", "scan_b8": "sscan2.hip"}
+
+
+def traffic_is_current(key, rel=TRAFFIC_JSON):
+    """True / False: the committed counters were / were not taken on the kernel source that is in the tree now (the collect script stores
+    the sha256 of the kernels' .hip files next to the numbers); None: no file, or a file from before the hashes were kept."""
+    import hashlib
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        want = json.load(open(os.path.join(root, *rel)))["kernel_sources"]["sha256"][_TRAFFIC_KERNEL_SOURCE[key]]
+        have = hashlib.sha256(open(os.path.join(root, "gfe-mamba_amd", "csrc", _TRAFFIC_KERNEL_SOURCE[key]), "rb").read()).hexdigest()
+    except (OSError, KeyError, ValueError):
+        return None
+    return want == have
+
+
+def measured_traffic(key, rel=TRAFFIC_JSON):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the gfx950 correction prescribes + WRITE_SIZE,
+    separate passes: tools/collect_profiles_r05.sh); None when the file does not travel with the tree -- or when the kernel's source has
+    changed since the counters were taken (VERDICT r04 weak #11: a committed number must not silently outlive the kernel it describes)."""
     import json
     import os
     f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), *rel)
+    if traffic_is_current(key, rel) is False:
+        return None
     try:
         return float(json.load(open(f))[key]["traffic_bytes"])          # a committed rocprofv3 measurement, not this run's
     except (OSError, KeyError, ValueError):
@@ -92,8 +114,8 @@ class StepWorkload:
         flops = 2.0 * 27 * 64 * 64 * self.batch * self.vol[0] * self.vol[1] * self.vol[2]
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": (measured_traffic("conv_igemm_64to64_96cubed_b8", ("profiles", "r04", "traffic_r04.json")) or measured_traffic("conv_igemm_64to64_96cubed_b8")) if (self.batch == 8 and self.vol_tag == "96^3") else None,
-                "traffic_source": "profiles/r04/traffic_r04.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "traffic": measured_traffic("conv_igemm_64to64_96cubed_b8") if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "traffic_source": "profiles/r05/traffic_r05.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed with the kernel source's hash; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
                 "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @%s, ReLU): the launch the step makes three times per "
                           "forward (encoders.0 conv3, decoders.1 conv2 / conv3), timed alone on operands built from encoders.0's lifted tensor and "
                           "conv2 weights -- the step itself collapses encoders.0 conv2 to a one-channel conv (DESIGN 4.1)" % self.vol_tag,

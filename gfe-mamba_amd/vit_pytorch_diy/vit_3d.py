@@ -91,7 +91,7 @@ class ViT(nn.Module):
         """vit_3d.py:113-128 with autograd (module.training decides the dropouts): every op is a HIP-kernel autograd node; attention is
         train_ops.qkv_flash_attention for dim_head 64 (any token count), the 64-token kernel of the classifier head otherwise."""
         import torch.nn.functional as F
-        from gfe_hip.head_ops import layernorm_rows, sdpa_small
+        from gfe_hip.head_ops import gelu, layernorm_rows, sdpa_small
         from gfe_hip.train_ops import linear as linear_, qkv_flash_attention
         linear = lambda a, w, b: linear_(a, w, b, exact=False)         # bf16 MFMA operands, like the inference pipeline and the attention
         n, dim = self.num_patches, self.dim
@@ -116,7 +116,7 @@ class ViT(nn.Module):
                 o = sdpa_small(q.contiguous(), k.contiguous(), v.contiguous(), attn.heads, causal=False, dropout_p=p_attn)
             x = drop(linear(o, attn.to_out[0].weight, attn.to_out[0].bias), attn.to_out[1]) + x
             h = layernorm_rows(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
-            h = drop(F.gelu(linear(h, ff.net[1].weight, ff.net[1].bias)), ff.net[3])
+            h = drop(gelu(linear(h, ff.net[1].weight, ff.net[1].bias)), ff.net[3])                 # exact-erf GELU, one kernel each way
             x = drop(linear(h, ff.net[4].weight, ff.net[4].bias), ff.net[5]) + x
         pooled = x.mean(dim=1) if self.pool == 'mean' else x[:, 0]                                    # vit_3d.py:125
         hn = layernorm_rows(pooled.contiguous(), self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[0].eps)

@@ -449,6 +449,11 @@ int gfe_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta
 int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
                            float* dgamma, float* dbeta, float* ws, int64_t rows, int64_t dim, void* stream);
 
+/* Exact-erf GELU as an operator of its own and its adjoint dx = dy * gelu'(x) (vit_pytorch_diy/vit.py:19 / vit_3d.py:21 under autograd: the
+ * inference path carries the activation in the GEMM epilogue; training has to keep the pre-activation).  n elements, dtype GFE_F32 | GFE_BF16. */
+int gfe_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int gfe_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+
 /* GEGLU (corss_ft_transformer.py:10-13: x, gates = chunk(2); x * gelu(gates), exact erf) followed by Dropout(p_drop) (:19):
  * x (rows, 2F) -> y (rows, F).  The mask is a counter-based hash of (seed, element index): the backward regenerates it from the
  * same seed; p_drop = 0 in eval mode.  seed_step: NULL, or a DEVICE int64 counter that is mixed into the seed when the kernel runs -- a HIP

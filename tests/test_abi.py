@@ -67,3 +67,18 @@ def test_f32_gemm_inblock_rule_is_a_host_side_function_of_shape_and_alignment():
     assert q(296, 64, 1024) == 0 and q(8, 512, 2048) == 0                                                             # K-major B, few tiles, long K
     assert q(296, 32, 1024, b_tr=1) == 1                                                                              # dt_proj's dgrad (no split-K workspace at its call site)
     assert q(37, 2048, 512) == 1 and q(296, 2048, 512) == 0                                                          # >= 512 tiles of 32 x 32: one staged launch
+
+
+def test_committed_traffic_counters_belong_to_the_kernels_in_the_tree():
+    """bench.py's roofline.traffic is a COMMITTED rocprofv3 measurement (profiles/r05/traffic_r05.json), so it must
+    not outlive the kernel it was taken on.  The collect script stores the sha256 of the kernels' sources next to the numbers;
+    measured_traffic() returns None on a mismatch, and this test fails until tools/collect_profiles_r05.sh has been re-run."""
+    import os
+    from gfe_hip.step_bench import TRAFFIC_JSON, measured_traffic, traffic_is_current
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, *TRAFFIC_JSON)):
+        import pytest
+        pytest.skip("no committed traffic file yet")
+    for key in ("conv_igemm_64to64_96cubed_b8", "attn_fwd_b8_h8_n1729", "scan_b8"):
+        assert traffic_is_current(key) is True, f"{key}: the kernel source changed after the counters were taken -- re-run tools/collect_profiles_r05.sh"
+        assert measured_traffic(key) and measured_traffic(key) > 0

@@ -71,6 +71,9 @@ def test_token_by_token_step_reproduces_the_references_forward():
     # an inference path that callers of the reference run in eval mode WITHOUT no_grad: it must work there too, and records nothing
     o3, _ = m.step(x[:, 0].contiguous(), list(warm))
     assert torch.equal(o3, o2) and not o3.requires_grad
+    # ... but a caller who asks for gradients THROUGH a step is told that there are none, instead of getting silently detached results
+    with pytest.raises(RuntimeError):
+        m.layers[0].mixer.step(x[:, 0].contiguous().requires_grad_(True), warm[0])
 
 
 def test_cross_attention_ff_embedder_vs_reference_fixture():
@@ -216,9 +219,20 @@ def test_self_attention_on_the_small_sdpa_kernel_vs_f64_math(causal):
         assert rel_err(pp.grad, p64[kname].grad.float()) < 1e-5, kname
     with pytest.raises(NotImplementedError):
         sa(torch.randn(1, 65, 64, device=DEV))
+    # CrossAttention stays general: several queries per sample run the one-query kernel over (sample, query) pairs
     ca = CrossAttention(n_heads=2, d_embed=16, d_cross=24).to(DEV)
-    with pytest.raises(NotImplementedError):
-        ca(torch.randn(2, 3, 16, device=DEV), torch.randn(2, 6, 24, device=DEV))
+    xq, yc = torch.randn(2, 3, 16, generator=g).to(DEV).requires_grad_(True), torch.randn(2, 6, 24, generator=g).to(DEV).requires_grad_(True)
+    wq = torch.randn(2, 3, 16, generator=g).to(DEV)
+    oq = ca(xq, yc)
+    (oq * wq).sum().backward()
+    pc = {k_: v_.detach().double().cpu().requires_grad_(True) for k_, v_ in ca.named_parameters()}
+    x64q, y64q = xq.detach().double().cpu().requires_grad_(True), yc.detach().double().cpu().requires_grad_(True)
+    refq = _cross_attention_f64(pc, x64q, y64q, 2)
+    (refq * wq.double().cpu()).sum().backward()
+    assert rel_err(oq, refq.float()) < 1e-5 and rel_err(xq.grad, x64q.grad.float()) < 1e-5 and rel_err(yc.grad, y64q.grad.float()) < 1e-5
+    for kname, pp in ca.named_parameters():
+        if kname != "k_proj.bias":
+            assert rel_err(pp.grad, pc[kname].grad.float()) < 1e-5, kname
 
 
 def test_embedding_offsets_bit_exact():

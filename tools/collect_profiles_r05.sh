@@ -1,0 +1,121 @@
+#!/bin/bash
+# Runs on the GPU box: bench JSON lines + rocprofv3 kernel stats (+ scan PMC) -> gpurun_out/r05/ (copied to profiles/r05/ afterwards).
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/step_b8_bench.json 2> /dev/null
+python3 $R/bench.py --no-pipeline > $O/step_b8_serial_bench.json 2> /dev/null
+python3 $R/bench.py --workload gen128 > $O/gen128_b2_bench.json 2> /dev/null
+python3 $R/bench.py --workload vit3d > $O/vit3d_b8_bench.json 2> /dev/null
+python3 $R/bench.py --workload gentrain > $O/gentrain_b2_bench.json 2> /dev/null
+python3 $R/bench.py --workload vit3dtrain > $O/vit3dtrain_b8_bench.json 2> /dev/null
+for b in 1 8 64; do python3 $R/bench.py --workload scan --batch $b > $O/scan_b${b}_bench.json 2> /dev/null; done
+python3 $R/bench.py --workload pscan > $O/pscan_b1_bench.json 2> /dev/null
+python3 $R/bench.py --volume native --batch 2 > $O/step_native_b2_bench.json 2> /dev/null
+python3 $R/bench.py --batch 1 > $O/step_b1_bench.json 2> /dev/null
+python3 -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node=1 $R/bench.py --gpus 1 --no-cpu-baseline > $O/step_b8_torchrun1_bench.json 2> /dev/null
+# two REAL ranks on the one GPU (gloo dry-run transport: the N-rank code path, not a scaling figure)
+GFE_DIST_BACKEND=gloo python3 -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node=2 $R/bench.py --gpus 2 --batch 4 --steps 10 --warmup 3 > $O/step_b4_2ranks_gloo_bench.json 2> /dev/null
+GFE_NO_SIDE_WGRAD=1 python3 $R/bench.py --no-cpu-baseline > $O/step_b8_noside_bench.json 2> /dev/null
+python3 $R/tools/gemm_bench.py 5 20 > $O/gemm_ab.txt 2>&1
+bash $R/tools/pmc_gemm.sh r05/gemm_pmc > $O/gemm_pmc.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan8 -o scan -- python3 $R/bench.py --workload scan --batch 8 --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scan1 -o scan -- python3 $R/bench.py --workload scan --batch 1 --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gen128 -o gen -- python3 $R/bench.py --workload gen128 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_conv64 -o conv64 -- python3 $R/tools/conv_bench.py 64 96 8 20 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gentrain -o gentrain -- python3 $R/bench.py --workload gentrain --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vit3d -o vit -- python3 $R/bench.py --workload vit3d --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vit3dtrain -o vt -- python3 $R/bench.py --workload vit3dtrain --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_attnb -o attnb -- python3 $R/tools/attn_bench.py > /dev/null 2>&1
+cp $O/prof_vit3dtrain/vt_kernel_stats.csv $O/vit3dtrain_b8_kernel_stats.csv
+cp $O/prof_attnb/attnb_kernel_stats.csv $O/attn_bwd_kernel_stats.csv
+cp $O/prof_gentrain/gentrain_kernel_stats.csv $O/gentrain_b2_kernel_stats.csv
+cp $O/prof_vit3d/vit_kernel_stats.csv $O/vit3d_b8_kernel_stats.csv
+cp $O/prof_step/step_kernel_stats.csv $O/step_b8_kernel_stats.csv
+cp $O/prof_scan8/scan_kernel_stats.csv $O/scan_b8_kernel_stats.csv
+cp $O/prof_scan1/scan_kernel_stats.csv $O/scan_b1_kernel_stats.csv
+cp $O/prof_gen128/gen_kernel_stats.csv $O/gen128_b2_kernel_stats.csv
+cp $O/prof_conv64/conv64_kernel_stats.csv $O/conv64_b8_kernel_stats.csv
+# scan traffic (separate PMC passes, kernel trace only)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_scan_fetch -o p -- python3 $R/bench.py --workload scan --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_scan_write -o p -- python3 $R/bench.py --workload scan --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_conv_fetch -o p -- python3 $R/tools/conv_bench.py 64 96 8 10 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_conv_write -o p -- python3 $R/tools/conv_bench.py 64 96 8 10 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_attn_fetch -o p -- python3 $R/tools/attn_bench.py 8 8 1729 20 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_attn_write -o p -- python3 $R/tools/attn_bench.py 8 8 1729 20 > /dev/null 2>&1
+bash $R/tools/pmc_attn.sh r05/attn_pmc attn_fwd attn_bwd_dkdv attn_bwd_dq > $O/attn_pmc.txt 2>&1
+bash $R/tools/pmc_scan.sh r05/scan_pmc > $O/scan_pmc.txt 2>&1
+cd /tmp
+cd $R
+python3 - <<PY
+import csv, glob, collections, os, json
+O = "$O"
+out = open(os.path.join(O, "scan_traffic.txt"), "w")
+res = {}
+for d, scale in (("pmc_scan_fetch", 2.0), ("pmc_scan_write", 1.0)):      # gfx950: FETCH_SIZE reports half of wide streaming reads (MI355X_MICROARCH.md)
+    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+    if not f: continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"]
+        if "sscan2" not in k: continue
+        agg[k[k.index("sscan2"):][:40]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        kb = sum(v) / len(v) * scale            # counters are in KB
+        res.setdefault(k, {})[d] = kb * 1024
+        line = f"{d:16s} {k:42s} per launch {kb * 1024 / 1e6:9.1f} MB (x{scale:g} applied)"
+        print(line); out.write(line + "\n")
+out.close()
+json.dump(res, open(os.path.join(O, "scan_traffic.json"), "w"), indent=1)
+tot = sum(sum(v.values()) for v in res.values())
+attn = {}
+for d, scale in (("pmc_attn_fetch", 2.0), ("pmc_attn_write", 1.0)):
+    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+    if not f: continue
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "attn_fwd" in r["Kernel_Name"]]
+    if v: attn[d] = sum(v) / len(v) * scale * 1024
+attnb = {}
+for kern in ("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_prep"):
+    for d, scale in (("pmc_attn_fetch", 2.0), ("pmc_attn_write", 1.0)):
+        f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+        if not f: continue
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if kern in r["Kernel_Name"]]
+        if v: attnb.setdefault(kern, {})[d] = sum(v) / len(v) * scale * 1024
+conv = {}
+for d, scale in (("pmc_conv_fetch", 2.0), ("pmc_conv_write", 1.0)):
+    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
+    if not f: continue
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "conv_igemm_kernel<4, 3, true, false" in r["Kernel_Name"]]
+    if v: conv[d] = sum(v) / len(v) * scale * 1024
+extra = {}
+if len(conv) == 2:
+    extra["conv_igemm_64to64_96cubed_b8"] = {"traffic_bytes": sum(conv.values()), "fetch_x2_bytes": conv["pmc_conv_fetch"], "write_bytes": conv["pmc_conv_write"],
+                                              "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of conv_igemm_kernel<4,3,true> in tools/conv_bench.py 64 96 8"}
+    print("conv 64->64 @96^3 B=8 traffic per launch: fetch %.2f GB (x2 applied) + write %.2f GB" % (conv["pmc_conv_fetch"] / 1e9, conv["pmc_conv_write"] / 1e9))
+if len(attn) == 2:
+    extra["attn_fwd_b8_h8_n1729"] = {"traffic_bytes": sum(attn.values()), "fetch_x2_bytes": attn["pmc_attn_fetch"], "write_bytes": attn["pmc_attn_write"],
+                                     "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of attn_fwd_kernel in tools/attn_bench.py 8 8 1729"}
+    print("attention B=8 H=8 n=1729 traffic per launch: fetch %.1f MB (x2 applied) + write %.1f MB" % (attn["pmc_attn_fetch"] / 1e6, attn["pmc_attn_write"] / 1e6))
+if attnb:
+    extra["attn_bwd_b8_h8_n1729"] = {"traffic_bytes": sum(sum(v.values()) for v in attnb.values()), "per_kernel": attnb,
+                                     "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of the three gfe_attention_bwd kernels in tools/attn_bench.py 8 8 1729"}
+    print("attention backward traffic per launch:", {k: {kk: round(vv / 1e6, 1) for kk, vv in v.items()} for k, v in attnb.items()})
+import hashlib
+srcs = {k: hashlib.sha256(open(os.path.join("$R", "gfe-mamba_amd", "csrc", k), "rb").read()).hexdigest() for k in ("conv3d.hip", "attn.hip", "attn_bwd.hip", "sscan2.hip")}
+extra["kernel_sources"] = {"sha256": srcs, "note": "the kernels these counters were taken on: gfe_hip.step_bench.measured_traffic() returns None (and tests/test_abi.py fails) once a source differs"}
+json.dump({**extra, "scan_b8": {"traffic_bytes": tot, "per_kernel": res,
+                       "method": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 reports half of coalesced reads at 4, 8 and 16 B per lane, tools/probes/fetch_calib.hip) and --pmc WRITE_SIZE, separate passes, mean per launch of sscan2_fwd + sscan2_bwd at B=8 L=4096 ED=1024 N=16 bf16"}},
+          open(os.path.join(O, "traffic_r05.json"), "w"), indent=1)
+PY
+# round 5 A/Bs (same box, alternating): folded vs materialised cross-attention K/V, untracked vs tracked-only attention forward, scan dB/dC sums
+for i in 1 2 3; do for m in 0 1; do GFE_XATTN_MATERIALISED=$m python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('materialised_kv=$m step', d['value'], d['ms_per_step'])"; done; done > $O/xattn_fold_step_ab.txt 2>&1
+for m in 0 1; do echo "materialised_kv=$m"; GFE_XATTN_MATERIALISED=$m python3 $R/tools/head_graph_probe.py 8 2>/dev/null; done >> $O/xattn_fold_step_ab.txt 2>&1
+if [ -f $R/exp_build/lib_attn_track.so ]; then
+  for i in 1 2 3; do echo "untracked first pass (product)"; python3 $R/tools/attn_bench.py 8 8 1729 100 2>/dev/null | grep "attention B"; echo "tracked pass only (round 4)"; GFE_HIP_LIB=$R/exp_build/lib_attn_track.so python3 $R/tools/attn_bench.py 8 8 1729 100 2>/dev/null | grep "attention B"; done > $O/attn_untracked_ab.txt 2>&1
+fi
+for i in 1 2; do for d in 0 1; do GFE_SCAN_DETERMINISTIC=$d python3 $R/bench.py --workload scan --batch 8 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('GFE_SCAN_DETERMINISTIC=$d scan B=8', d['ms_per_step'], d['roofline']['frac'])"; done; done > $O/scan_deterministic_ab.txt 2>&1
+for d in 0 1; do GFE_SCAN_DETERMINISTIC=$d python3 $R/bench.py --workload scan --batch 1 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('GFE_SCAN_DETERMINISTIC=$d scan B=1', d['ms_per_step'], d['roofline']['frac'])"; done >> $O/scan_deterministic_ab.txt 2>&1
+python3 $R/tools/timing_fuzz.py --iters 500 > $O/timing_fuzz_500.txt 2>&1
+for f in $O/*_bench.json; do echo "$(basename $f): $(cut -c1-300 $f)"; done
