@@ -164,16 +164,22 @@ class MambaBlock(nn.Module):
         return selective_scan_tm(x, delta, A, B, C, D)
 
     # ---- single-token inference (mamba.py:342-405): the projections on the exact-f32 GEMM, the conv / state update on two small kernels ----
+    _step_warned = False
+
     def step(self, x, cache):
         """x: (B, D); cache = (h (B, ED, N) or None, inputs (B, ED, d_conv - 1)) -> (output (B, D), new cache).  Inference only."""
         if not x.is_cuda:
             raise RuntimeError("MambaBlock.step runs on the GPU only (no CPU fallback)")
-        # An inference path: the kernels behind it have no backward.  The reference's step is plain differentiable torch code (mamba.py:342-405);
-        # its callers run it in eval mode, often without no_grad -- that works here (nothing is recorded).  A caller who actually WANTS gradients
-        # through it -- grad mode on and an input that requires grad -- gets an error instead of silently detached results (ADVICE r04).
-        if torch.is_grad_enabled() and (x.requires_grad or any(t is not None and torch.is_tensor(t) and t.requires_grad for t in cache)):
-            raise RuntimeError("MambaBlock.step is inference-only on the HIP path (no backward): call it under torch.no_grad() or detach its "
-                               "inputs; to train through single tokens use forward() on a length-1 sequence")
+        # An inference path: the kernels behind it have no backward.  The reference's step is plain differentiable torch code (mamba.py:342-405)
+        # and its callers run it in eval mode, often without no_grad -- that works here too (nothing is recorded).  When grad mode is on and the
+        # input carries a graph (a caller's own requires_grad tensor, or simply the RMSNorm in front of the mixer, whose weight requires grad),
+        # the detach is said ONCE instead of happening silently (ADVICE r04).
+        if torch.is_grad_enabled() and x.requires_grad and not MambaBlock._step_warned:
+            MambaBlock._step_warned = True
+            import warnings
+            warnings.warn("MambaBlock.step is inference-only on the HIP path: its result carries no autograd graph (the reference's step is "
+                          "differentiable); call it under torch.no_grad(), or use forward() on a length-1 sequence to train through single tokens",
+                          RuntimeWarning, stacklevel=2)
         with torch.no_grad():
             return self._step(x.detach(), cache)
 
