@@ -19,6 +19,8 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef __attribute__((address_space(3))) void* lds_void_t;
@@ -123,7 +125,14 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
     // largest probabilities kept full precision and nothing overflowed); a block in which any row ends outside it -- scores beyond ~ +-60 in
     // log2 units, which a softmax of LayerNorm'ed tokens does not produce -- is redone by the tracked pass (block-uniform decision through LDS).
     f32x16 negm;
-    float lsum;                                // this lane's share of the row sum
+    // This lane's share of the row sum.  Without dropout it is summed ON THE MATRIX CORE from the bf16 probabilities the PV product actually
+    // multiplies (v_mfma_f32_4x4x4_16b_bf16 with A = ones: D[i][j] = sum_k B[k][j], i.e. every lane gets the exact f32 sum of the four bf16
+    // values it holds in a B operand; four such 8-cycle MFMAs per 32-key block instead of sixteen v_add_f32): numerator and denominator of
+    // the softmax then carry the SAME rounding -- a row dominated by one key comes out exact (a single-token sequence returns v itself and
+    // an exactly-zero score gradient), where summing the unrounded f32 values left the 2^-9 rounding of P in the output.  With dropout the
+    // sum is the UNdropped softmax's and stays on the vector unit.
+    float lsum;
+    f32x4_t lacc;
     constexpr float THR = 6.0f;
     const int ntile = (p.n + KT - 1) / KT;
     // K/V tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, no staging registers): lane L of a piece fills
@@ -263,15 +272,21 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
     #pragma unroll
                     for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
                     lsum *= alpha;
+                    if constexpr (!DROP) lacc *= alpha;
                 }
             }
-            float ps0 = 0.f, ps1 = 0.f;
+            if constexpr (DROP) {
+                float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                s[r] = fast_exp2(s[r]); s[r + 1] = fast_exp2(s[r + 1]);
-                ps0 += s[r]; ps1 += s[r + 1];
+                for (int r = 0; r < 16; r += 2) {
+                    s[r] = fast_exp2(s[r]); s[r + 1] = fast_exp2(s[r + 1]);
+                    ps0 += s[r]; ps1 += s[r + 1];
+                }
+                lsum += ps0 + ps1;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]);
             }
-            lsum += ps0 + ps1;
             if constexpr (DROP) {                                        // attn = dropout(softmax): the mask is a hash of (seed, head, row, key)
                 const uint32_t sb = attn_drop_seed(p.seed_lo, p.seed_hi, (uint32_t)bh);
                 const uint32_t e0 = (uint32_t)(q0 + ql) * (uint32_t)p.npad + 32u * (uint32_t)kidx + 4u * (uint32_t)hi;
@@ -290,6 +305,11 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
                 const auto x1 = __builtin_amdgcn_permlane32_swap(w1, w3, false, false);
                 const uint4 u = make_uint4(x0[0], x1[0], x0[1], x1[1]);
                 pb[tt] = __builtin_bit_cast(bf16x8, u);
+                if constexpr (!DROP) {
+                    const s16x4 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
+                    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, u32x2_t{x0[0], x1[0]}), lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(s16x4, u32x2_t{x0[1], x1[1]}), lacc, 0, 0, 0);
+                }
             }
 #endif
             // ---- O^T += V^T P^T: two 32-wide d blocks x the block's two 16-key slots; A fragments by transposing reads of [key][d]
@@ -332,6 +352,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[r] = 0.f;
         lsum = 0.f;
+        lacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
         dma(0, 0);
         if constexpr (RING > 2) { if (ntile > 1) dma(1, 1); }
         // vmcnt retires in order: leaving the newest tile's pieces outstanding is a COUNTED wait (a vmcnt(0) here would drain the prefetch)
@@ -351,6 +372,7 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #endif
     for (;;) {                           // ONE instance of the tile loop in the code (two inlined copies cost 12-19 spilled registers at the 128 limit)
         pass(track);
+        if constexpr (!DROP) lsum = lacc[0];
         l = lsum + __shfl_xor(lsum, 32, 64);
         if (track) break;
         // every wave has left the last tile's barrier, so nobody reads the ring any more: its first word carries the block's verdict

@@ -427,7 +427,9 @@ def test_flash_attention_untracked_pass_and_its_fallback(shift):
     e_l = (nlse.view(B, H, -1)[:, :, :n].double().cpu() + lse2).abs().max().item()
     print("untracked / fallback pass, scores shifted by %+.0f (log2): rel err %.2e, row statistic abs err %.2e" % (shift, e, e_l))
     assert e < 6e-3, e
-    assert e_l < 2e-3 * max(1.0, abs(shift) / 16), e_l
+    # the statistic is -(log2 of the sum of the bf16 probabilities the PV product multiplies): up to 2^-9 relative in the sum = 3e-3 in log2,
+    # plus the planted component's bf16 rounding (|shift| * 2^-9)
+    assert e_l < 8e-3 * max(1.0, abs(shift) / 16), e_l
 
 
 @pytest.mark.parametrize("B,H,n", [(2, 8, 1729), (1, 2, 64), (1, 3, 65), (2, 1, 127), (1, 2, 300), (1, 1, 1), (1, 2, 513)])
