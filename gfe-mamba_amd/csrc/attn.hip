@@ -230,9 +230,15 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) { asm volatile("" :: "v"(kf[ds])); s[ds] += 1.0f; }
 #else
+#if defined(GFE_ATTN_EXP_MFMAPRIO)       // experiment: issue priority for the matrix phases (T5's per-cluster form)
+            __builtin_amdgcn_s_setprio(GFE_ATTN_EXP_MFMAPRIO);
+#endif
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);         // (untracked pass: negm stays 0)
 #pragma unroll
             for (int ds = 1; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
+#if defined(GFE_ATTN_EXP_MFMAPRIO)
+            if (ANW == 8 && __builtin_amdgcn_readfirstlane(wave) >= ANW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
 #if GFE_ATTN_PREFETCH
             __builtin_amdgcn_sched_barrier(0);
@@ -316,6 +322,9 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #if !GFE_ATTN_PREFETCH
             load_v(kb2);
 #endif
+#if defined(GFE_ATTN_EXP_MFMAPRIO)
+            __builtin_amdgcn_s_setprio(GFE_ATTN_EXP_MFMAPRIO);
+#endif
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
@@ -327,6 +336,9 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #endif
                 }
             }
+#if defined(GFE_ATTN_EXP_MFMAPRIO)
+            if (ANW == 8 && __builtin_amdgcn_readfirstlane(wave) >= ANW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         }
         // tile t+1 has landed (this wave's pieces; the barrier makes all of it visible) while tile t+2's pieces, issued above, stay in flight
 #if defined(GFE_ATTN_EXP_SKEW)            // timing experiment: the younger wave of every SIMD pair leaves the barrier late

@@ -49,66 +49,7 @@ bash $R/tools/pmc_attn.sh r05/attn_pmc attn_fwd attn_bwd_dkdv attn_bwd_dq > $O/a
 bash $R/tools/pmc_scan.sh r05/scan_pmc > $O/scan_pmc.txt 2>&1
 cd /tmp
 cd $R
-python3 - <<PY
-import csv, glob, collections, os, json
-O = "$O"
-out = open(os.path.join(O, "scan_traffic.txt"), "w")
-res = {}
-for d, scale in (("pmc_scan_fetch", 2.0), ("pmc_scan_write", 1.0)):      # gfx950: FETCH_SIZE reports half of wide streaming reads (MI355X_MICROARCH.md)
-    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
-    if not f: continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"]
-        if "sscan2" not in k: continue
-        agg[k[k.index("sscan2"):][:40]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        kb = sum(v) / len(v) * scale            # counters are in KB
-        res.setdefault(k, {})[d] = kb * 1024
-        line = f"{d:16s} {k:42s} per launch {kb * 1024 / 1e6:9.1f} MB (x{scale:g} applied)"
-        print(line); out.write(line + "\n")
-out.close()
-json.dump(res, open(os.path.join(O, "scan_traffic.json"), "w"), indent=1)
-tot = sum(sum(v.values()) for v in res.values())
-attn = {}
-for d, scale in (("pmc_attn_fetch", 2.0), ("pmc_attn_write", 1.0)):
-    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
-    if not f: continue
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "attn_fwd" in r["Kernel_Name"]]
-    if v: attn[d] = sum(v) / len(v) * scale * 1024
-attnb = {}
-for kern in ("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_prep"):
-    for d, scale in (("pmc_attn_fetch", 2.0), ("pmc_attn_write", 1.0)):
-        f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
-        if not f: continue
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if kern in r["Kernel_Name"]]
-        if v: attnb.setdefault(kern, {})[d] = sum(v) / len(v) * scale * 1024
-conv = {}
-for d, scale in (("pmc_conv_fetch", 2.0), ("pmc_conv_write", 1.0)):
-    f = glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True)
-    if not f: continue
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "conv_igemm_kernel<4, 3, true, false" in r["Kernel_Name"]]
-    if v: conv[d] = sum(v) / len(v) * scale * 1024
-extra = {}
-if len(conv) == 2:
-    extra["conv_igemm_64to64_96cubed_b8"] = {"traffic_bytes": sum(conv.values()), "fetch_x2_bytes": conv["pmc_conv_fetch"], "write_bytes": conv["pmc_conv_write"],
-                                              "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of conv_igemm_kernel<4,3,true> in tools/conv_bench.py 64 96 8"}
-    print("conv 64->64 @96^3 B=8 traffic per launch: fetch %.2f GB (x2 applied) + write %.2f GB" % (conv["pmc_conv_fetch"] / 1e9, conv["pmc_conv_write"] / 1e9))
-if len(attn) == 2:
-    extra["attn_fwd_b8_h8_n1729"] = {"traffic_bytes": sum(attn.values()), "fetch_x2_bytes": attn["pmc_attn_fetch"], "write_bytes": attn["pmc_attn_write"],
-                                     "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of attn_fwd_kernel in tools/attn_bench.py 8 8 1729"}
-    print("attention B=8 H=8 n=1729 traffic per launch: fetch %.1f MB (x2 applied) + write %.1f MB" % (attn["pmc_attn_fetch"] / 1e6, attn["pmc_attn_write"] / 1e6))
-if attnb:
-    extra["attn_bwd_b8_h8_n1729"] = {"traffic_bytes": sum(sum(v.values()) for v in attnb.values()), "per_kernel": attnb,
-                                     "method": "rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes, mean per launch of the three gfe_attention_bwd kernels in tools/attn_bench.py 8 8 1729"}
-    print("attention backward traffic per launch:", {k: {kk: round(vv / 1e6, 1) for kk, vv in v.items()} for k, v in attnb.items()})
-import hashlib
-srcs = {k: hashlib.sha256(open(os.path.join("$R", "gfe-mamba_amd", "csrc", k), "rb").read()).hexdigest() for k in ("conv3d.hip", "attn.hip", "attn_bwd.hip", "sscan2.hip")}
-extra["kernel_sources"] = {"sha256": srcs, "note": "the kernels these counters were taken on: gfe_hip.step_bench.measured_traffic() returns None (and tests/test_abi.py fails) once a source differs"}
-json.dump({**extra, "scan_b8": {"traffic_bytes": tot, "per_kernel": res,
-                       "method": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 reports half of coalesced reads at 4, 8 and 16 B per lane, tools/probes/fetch_calib.hip) and --pmc WRITE_SIZE, separate passes, mean per launch of sscan2_fwd + sscan2_bwd at B=8 L=4096 ED=1024 N=16 bf16"}},
-          open(os.path.join(O, "traffic_r05.json"), "w"), indent=1)
-PY
+python3 $R/tools/summarise_profiles_r05.py $O $R
 # round 5 A/Bs (same box, alternating): folded vs materialised cross-attention K/V, untracked vs tracked-only attention forward, scan dB/dC sums
 for i in 1 2 3; do for m in 0 1; do GFE_XATTN_MATERIALISED=$m python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('materialised_kv=$m step', d['value'], d['ms_per_step'])"; done; done > $O/xattn_fold_step_ab.txt 2>&1
 for m in 0 1; do echo "materialised_kv=$m"; GFE_XATTN_MATERIALISED=$m python3 $R/tools/head_graph_probe.py 8 2>/dev/null; done >> $O/xattn_fold_step_ab.txt 2>&1

@@ -92,8 +92,8 @@ def main():
     args = ap.parse_args()
     if args.role:
         sys.exit(child(args.role, args))
-    if not os.path.exists(FUZZ_LIB):
-        subprocess.check_call(["make", "-j", "8", "-C", os.path.join(ROOT, "gfe-mamba_amd", "csrc"), "fuzz"])
+    # always through make (incremental): a fuzz library older than the sources fails to load as soon as the header gains a symbol
+    subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "gfe-mamba_amd", "csrc"), "fuzz"])
     os.makedirs(os.path.dirname(args.ref), exist_ok=True)
     env = dict(os.environ)
     for kv in args.env:
