@@ -224,6 +224,9 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #endif
 #if !GFE_ATTN_PREFETCH
             load_k(kb2);
+#if defined(GFE_ATTN_EXP_KFIRST)         // experiment: all four K fragment reads in flight before the first S MFMA (hipcc otherwise issues read, wait, MFMA four times)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
 #if defined(GFE_ATTN_EXP_NOMFMA)          // timing experiment only: no matrix instructions (wrong results)
             s = negm;
