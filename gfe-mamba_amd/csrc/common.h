@@ -105,8 +105,13 @@ __device__ __forceinline__ unsigned gfe_fuzz_init() {
 __device__ __forceinline__ void gfe_fuzz_point(unsigned& s) {
     s = (unsigned)__builtin_amdgcn_readfirstlane((int)(s * 1664525u + 1013904223u));
     const unsigned r = s >> 20;                                        // 12 bits
+#if defined(GFE_TIMING_FUZZ_HEAVY)     // second level (make fuzz FUZZ_EXTRA=-DGFE_TIMING_FUZZ_HEAVY): every other visit sleeps, a long sleep at 1 of 32
+    unsigned n = (r & 1u) == 0u ? ((r >> 1) & 63u) + 1u : 0u;
+    if ((r >> 7) == 31u) n = 256u + ((r & 127u) << 2);
+#else
     unsigned n = (r & 3u) == 0u ? ((r >> 2) & 31u) + 1u : 0u;
     if ((r >> 5) == 127u) n = 256u + ((r & 31u) << 3);
+#endif
     for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 #define GFE_FUZZ_INIT() unsigned gfe_fz_ = gfe_fuzz_init()

@@ -89,11 +89,12 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="K=V for both children (bisect switches)")
     ap.add_argument("--ref", default=os.path.join(ROOT, "gpurun_out", "timing_fuzz_ref.pt"))
     ap.add_argument("--role", default=None)
+    ap.add_argument("--heavy", action="store_true", help="the heavier fuzz level (make fuzz_heavy: every other site visit sleeps, long sleeps at 1 of 32)")
     args = ap.parse_args()
     if args.role:
         sys.exit(child(args.role, args))
     # always through make (incremental): a fuzz library older than the sources fails to load as soon as the header gains a symbol
-    subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "gfe-mamba_amd", "csrc"), "fuzz"])
+    subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "gfe-mamba_amd", "csrc"), "fuzz_heavy" if args.heavy else "fuzz"])
     os.makedirs(os.path.dirname(args.ref), exist_ok=True)
     env = dict(os.environ)
     for kv in args.env:
@@ -102,7 +103,7 @@ def main():
     base = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--vol", str(args.vol), "--ref", args.ref]
     env.pop("GFE_HIP_LIB", None)
     rc_ref = subprocess.call(base + ["--role", "ref"], env=env)                  # children, never an exec of a GPU-initialised process
-    env["GFE_HIP_LIB"] = FUZZ_LIB
+    env["GFE_HIP_LIB"] = FUZZ_LIB.replace("_fuzz.so", "_fuzz_heavy.so") if args.heavy else FUZZ_LIB
     rc_fuzz = subprocess.call(base + ["--role", "fuzz"], env=env)
     print("timing_fuzz: ref rc %d (batch 8 == batch 1 on the product library), fuzz rc %d (%s)" % (
         rc_ref, rc_fuzz, "every fuzzed run bit-identical" if rc_fuzz == 0 else "MISMATCHES, see above"))
