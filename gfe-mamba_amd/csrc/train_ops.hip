@@ -89,12 +89,15 @@ __global__ __launch_bounds__(256) void mid_linear_wgrad_kernel(const bf16_t* __r
     static_assert(S == 4, "dout rows are read as float4");
     extern __shared__ __attribute__((aligned(16))) float sd[];          // [2B][C][S]
     const int nbs = 2 * B;
+    const int CP = C >> 3;                               // lanes per row (a power of two <= 64: checked by the host)
+    // LDS image [bs][j][chunk] (channel c = 8 chunk + j): for a fixed j the row's CP lanes then read CONSECUTIVE float4 -- in channel order the
+    // lanes were 8 float4 = 128 B apart and every ds_read_b128 of the inner loop was 8-way conflicted: the kernel ran at the LDS's pace (72 us
+    // for 113 MB at B = 8; round 5, found in the head's kernel trace)
     for (int i = threadIdx.x; i < nbs * C; i += 256) {
         const int bs = i / C, c = i - bs * C, b = bs >> 1, src = bs & 1;
-        reinterpret_cast<float4*>(sd)[i] = *reinterpret_cast<const float4*>(dout + ((size_t)b * 2 * C + src * C + c) * S);
+        reinterpret_cast<float4*>(sd)[bs * C + (c & 7) * CP + (c >> 3)] = *reinterpret_cast<const float4*>(dout + ((size_t)b * 2 * C + src * C + c) * S);
     }
     __syncthreads();
-    const int CP = C >> 3;                               // lanes per row (a power of two <= 64: checked by the host)
     const int RPW = 64 / CP;                             // rows per wave pass
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunk = lane % CP, rsub = lane / CP;
@@ -116,10 +119,10 @@ __global__ __launch_bounds__(256) void mid_linear_wgrad_kernel(const bf16_t* __r
                 if (bs0 + k < nbs) {
                     const float f[8] = {bf16lo_to_f32(v[k].x), bf16hi_to_f32(v[k].x), bf16lo_to_f32(v[k].y), bf16hi_to_f32(v[k].y),
                                         bf16lo_to_f32(v[k].z), bf16hi_to_f32(v[k].z), bf16lo_to_f32(v[k].w), bf16hi_to_f32(v[k].w)};
-                    const float4* dv = reinterpret_cast<const float4*>(sd) + (size_t)(bs0 + k) * C + chunk * 8;
+                    const float4* dv = reinterpret_cast<const float4*>(sd) + (size_t)(bs0 + k) * C + chunk;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float4 d = dv[j];
+                        const float4 d = dv[j * CP];
                         acc[0] = fmaf(f[j], d.x, acc[0]); acc[1] = fmaf(f[j], d.y, acc[1]);
                         acc[2] = fmaf(f[j], d.z, acc[2]); acc[3] = fmaf(f[j], d.w, acc[3]);
                     }

@@ -4,7 +4,8 @@ condition buffers, and the flat-buffer per-parameter-clip + Adam step (with the 
 Numerics: master weights, residual stream and reductions are f32.  The head's small Linears (Mamba projections, q / out projections,
 GEGLU feed-forward, logits: launch-bound sizes) run on the exact-f32 MFMA GEMM, as the reference trains the head in fp32
 (classify_mamba.py:69-74); only Linears wider than F32_LINEAR_MAX_K inputs (the cross-attention K / V projections over d_cross =
-9 216 .. 25 600 image columns, which carry 94 % of the head's FLOPs) round their operands to bf16 (f32 accumulate).
+9 216 .. 25 600 image columns) round their operands to bf16 (f32 accumulate) -- and since round 5 the classifier's one-query call never
+forms K or V at all (csrc/xattn_fold.hip), so on the classify path every trainable product is f32.
 """
 import weakref
 

@@ -495,7 +495,10 @@ def test_flash_attention_dropout_forward_and_backward(B, H, n, p):
     q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
     o, nlse = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True, dropout_p=p, seed=seed)
     o0, nlse0 = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True)
-    assert torch.equal(nlse, nlse0) and not torch.equal(o, o0)               # the row statistic is the undropped softmax's
+    # the row statistic is the UNdropped softmax's: round 5's plain kernel sums the bf16-rounded probabilities on the matrix core, the dropout
+    # instantiation the unrounded ones on the vector unit (its packed P carries the mask) -- the same statistic up to that rounding (2^-9 of the sum)
+    fin = torch.isfinite(nlse0)
+    assert torch.equal(fin, torch.isfinite(nlse)) and (nlse[fin] - nlse0[fin]).abs().max().item() < 4e-3 and not torch.equal(o, o0)
     o_b, _ = K.attention_fwd(q, k, v, B, H, n, dh, dh ** -0.5, with_lse=True, dropout_p=p, seed=seed + 1)
     assert not torch.equal(o, o_b)
     keep = _attn_drop_keep(seed, B, H, n, p)
