@@ -629,19 +629,48 @@ __global__ __launch_bounds__(256) void bce_sigmoid_fwd_kernel(const float* __res
 
 // exact-erf GELU as an operator of its own (vit_pytorch_diy/vit_3d.py:21 / vit.py:19 inside FeedForward when the module TRAINS: the inference
 // path has it in the GEMM epilogue; under autograd the pre-activation has to survive for the backward): x, y f32 or bf16, 4 values per lane
+// 16 bytes per lane and access (4 f32 / 8 bf16), a scalar tail; n4 = number of whole 16-byte groups
+template <typename T> struct GeluVec;
+template <> struct GeluVec<float> { static constexpr int N = 4; };
+template <> struct GeluVec<bf16_t> { static constexpr int N = 8; };
 template <typename T>
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (i + k < n) IO<T>::st(y + i + k, gelu_erf_(IO<T>::ld(x + i + k)));
-    }
+__device__ __forceinline__ void gelu_unpack(const uint4& v, float (&f)[GeluVec<T>::N]) {
+    if constexpr (GeluVec<T>::N == 4) { f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w); }
+    else { f[0] = bf16lo_to_f32(v.x); f[1] = bf16hi_to_f32(v.x); f[2] = bf16lo_to_f32(v.y); f[3] = bf16hi_to_f32(v.y);
+           f[4] = bf16lo_to_f32(v.z); f[5] = bf16hi_to_f32(v.z); f[6] = bf16lo_to_f32(v.w); f[7] = bf16hi_to_f32(v.w); }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n) {
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+__device__ __forceinline__ uint4 gelu_pack(const float (&f)[GeluVec<T>::N]) {
+    if constexpr (GeluVec<T>::N == 4) return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    else return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int vec) {
+    constexpr int N = GeluVec<T>::N;
+    const int64_t nv = vec ? n / N : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float f[N];
+        gelu_unpack<T>(reinterpret_cast<const uint4*>(x)[i], f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (i + k < n) IO<T>::st(dx + i + k, IO<T>::ld(dy + i + k) * gelu_erf_grad_(IO<T>::ld(x + i + k)));
+        for (int k = 0; k < N; ++k) f[k] = gelu_erf_(f[k]);
+        reinterpret_cast<uint4*>(y)[i] = gelu_pack<T>(f);
     }
+    for (int64_t i = nv * N + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) IO<T>::st(y + i, gelu_erf_(IO<T>::ld(x + i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, int vec) {
+    constexpr int N = GeluVec<T>::N;
+    const int64_t nv = vec ? n / N : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float f[N], d[N];
+        gelu_unpack<T>(reinterpret_cast<const uint4*>(x)[i], f);
+        gelu_unpack<T>(reinterpret_cast<const uint4*>(dy)[i], d);
+#pragma unroll
+        for (int k = 0; k < N; ++k) f[k] = d[k] * gelu_erf_grad_(f[k]);
+        reinterpret_cast<uint4*>(dx)[i] = gelu_pack<T>(f);
+    }
+    for (int64_t i = nv * N + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        IO<T>::st(dx + i, IO<T>::ld(dy + i) * gelu_erf_grad_(IO<T>::ld(x + i)));
 }
 
 }  // namespace
@@ -764,18 +793,20 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
 int gfe_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
     GFE_REQUIRE(x && y, GFE_ERR_NULL);
     GFE_REQUIRE(n > 0, GFE_ERR_SHAPE);
-    int64_t g = ceil_div(n, 1024); if (g > 4096) g = 4096;
-    if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n);
-    else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n);
+    const int vec = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    int64_t g = ceil_div(n, 256 * 8); if (g > 8192) g = 8192;
+    if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, vec);
+    else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n, vec);
     else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }
 int gfe_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
     GFE_REQUIRE(x && dy && dx, GFE_ERR_NULL);
     GFE_REQUIRE(n > 0, GFE_ERR_SHAPE);
-    int64_t g = ceil_div(n, 1024); if (g > 4096) g = 4096;
-    if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, n);
-    else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+    const int vec = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    int64_t g = ceil_div(n, 256 * 8); if (g > 8192) g = 8192;
+    if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, n, vec);
+    else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, vec);
     else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }

@@ -237,6 +237,34 @@ def test_self_attention_on_the_small_sdpa_kernel_vs_f64_math(causal):
             assert rel_err(pp.grad, pc[kname].grad.float()) < 1e-5, kname
 
 
+@pytest.mark.parametrize("n,dt", [(13832 * 16 + 3, torch.float32), (4096 * 7 + 5, torch.bfloat16), (3, torch.float32)])
+def test_gelu_and_silu_mul_operators_vs_torch(n, dt):
+    """gfe_gelu_fwd/bwd (exact erf; the training paths' nn.GELU) and silu_mul (the un-routed Jamba MLP, jamba.py:535) against torch's own
+    functions in f64, forward and backward, vector body + scalar tail, f32 and bf16, also on a 4-byte-aligned (not 16-byte-aligned) view."""
+    from gfe_hip.head_ops import gelu, silu_mul
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n + 1, generator=g) * 2).to(dt).to(DEV)
+    for off in (0, 1):
+        xi = x[off:off + n].detach().requires_grad_(True)
+        w = torch.randn(n, generator=g).to(dt).to(DEV)
+        y = gelu(xi)
+        (y.float() * w.float()).sum().backward()
+        x64 = xi.detach().double().cpu().requires_grad_(True)
+        r = F.gelu(x64)
+        (r * w.double().cpu()).sum().backward()
+        tol = 1e-6 if dt == torch.float32 else 8e-3
+        assert rel_err(y.float(), r.float()) < tol and rel_err(xi.grad.float(), x64.grad.float()) < tol
+    if dt == torch.float32:
+        a = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+        b = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+        h = silu_mul(a, b)
+        (h * x[:n].float()).sum().backward()
+        a64, b64 = a.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+        r = F.silu(a64) * b64
+        (r * x[:n].double().cpu()).sum().backward()
+        assert rel_err(h, r.float()) < 1e-6 and rel_err(a.grad, a64.grad.float()) < 2e-6 and rel_err(b.grad, b64.grad.float()) < 1e-6
+
+
 def test_embedding_offsets_bit_exact():
     from cross_atten.mamba_transformer import Cross_mamba_both
     fx = golden("t0_head_ops.npz")
