@@ -187,7 +187,14 @@ class AttentionSDPA(nn.Module):
         elif T == L:
             o = sdpa_small(q, k, v, self.num_heads, causal=False, dropout_p=p_drop)  # first call with an empty cache: non-causal, as the reference
         else:
-            raise NotImplementedError("multi-token calls onto a warm KV cache are outside the built kernels (one token per call, jamba.py:421-423)")
+            # several new tokens onto a warm cache (the module-level generality of jamba.py:373-392; Jamba.step itself feeds one token per call,
+            # :421-423): every new token is a one-query problem over the T cached + new keys, non-causal as the reference's is_causal=False
+            if p_drop > 0:
+                raise NotImplementedError("attention dropout while decoding from a KV cache (the reference's training-mode corner) is not built")
+            E = self.num_heads * dh
+            kx = k.unsqueeze(1).expand(B, L, T, E).reshape(B * L, T, E)
+            vx = v.unsqueeze(1).expand(B, L, T, E).reshape(B * L, T, E)
+            o = cross_attn_q1(q.reshape(B * L, 1, E), kx, vx, self.num_heads).view(B, L, E)
         return self.o_proj(o), cache
 
 

@@ -57,6 +57,9 @@ class Cross_mamba_both(nn.Module):
         x = mean_tokens(x)                                                                        # :122
         if kv is not None:
             aux.join()
+            if kv[0].is_cuda and not torch.cuda.is_current_stream_capturing():       # allocated from the side stream's pool, read on this one
+                for t_ in kv:
+                    t_.record_stream(torch.cuda.current_stream())
         x = self.final_cross(x, whole_condition, kv=kv) + x                                       # :124
         x = self.final_feed(x) + x                                                                # :125
         return self.to_logits(x.squeeze(1))                                                       # :127-131
