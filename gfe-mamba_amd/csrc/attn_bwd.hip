@@ -187,6 +187,7 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING_KV stages of STAGE_KV bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
+    GFE_FUZZ_INIT();
 #if defined(GFE_ATTNB_PRIO)
     if (wave >= BW / 2) __builtin_amdgcn_s_setprio(GFE_ATTNB_PRIO);
 #endif
@@ -255,8 +256,10 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
     for (int t = 0; t < RING_KV - 1; ++t)
         if (t < ntile) dma(t, t);
     // vmcnt retires in order: tile 0 has landed once at most the younger tiles' pieces are outstanding
+    GFE_FUZZ();
     if (ntile >= RING_KV - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((RING_KV - 2) * PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    GFE_FUZZ();
     load_frags(rs[0], smem, 0);
     load_stats(smem, 0);
 
@@ -273,10 +276,12 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dkdv_kernel(const BwdPara
             RowSet& nxt = rs[(j + 1) & 1];
             if (j == NB - 1 && more) {
                 // tile t+1 published, tile t-1 retired: (RING_KV - 3) younger tiles may stay in flight
+                GFE_FUZZ();
                 if (t + RING_KV - 2 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((RING_KV - 3) * PIECES) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                GFE_FUZZ();
 #if !defined(GFE_ATTNB_EXP_NODMA)       // timing experiment only
-                if (t + RING_KV - 1 < ntile) dma(t + RING_KV - 1, (SLOT + RING_KV - 1) % RING_KV);
+                if (t + RING_KV - 1 < ntile) { GFE_FUZZ(); dma(t + RING_KV - 1, (SLOT + RING_KV - 1) % RING_KV); }
 #endif
             }
             // next block's row fragments: in flight under this block's MFMA chains
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                    // RING stages of STAGE_Q bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
+    GFE_FUZZ_INIT();
 #if defined(GFE_ATTNB_PRIO)
     if (wave >= BW / 2) __builtin_amdgcn_s_setprio(GFE_ATTNB_PRIO);
 #endif
@@ -417,8 +423,10 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
     };
     dma(0, 0);
     if (ntile > 1) dma(1, 1);
+    GFE_FUZZ();
     if (ntile > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    GFE_FUZZ();
 
     const FragOffsets fo = frag_offsets(lane);
     auto tile = [&](auto slot_c, const int t) {
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
         const bool ragged = t == ntile - 1 && (p.n & (RT - 1));
 #pragma unroll
         for (int kb2 = 0; kb2 < RT / 32; ++kb2) {
-            if (kb2 == 0 && t + RING - 1 < ntile) dma(t + RING - 1, (SLOT + RING - 1) % RING);
+            if (kb2 == 0 && t + RING - 1 < ntile) { GFE_FUZZ(); dma(t + RING - 1, (SLOT + RING - 1) % RING); }
             bf16x8 kr[4], vr[4];
             load_rows(kr, sk, kb2, fo);
             load_rows(vr, sv, kb2, fo);
@@ -475,8 +483,10 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
 #pragma unroll
                 for (int db = 0; db < 2; ++db) dqa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[tt][db], dsb[tt], dqa[db], 0, 0, 0);
         }
+        GFE_FUZZ();
         if (t + RING - 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        GFE_FUZZ();
     };
     for (int t = 0; t < ntile; t += 3) {
         tile(std::integral_constant<int, 0>{}, t);

@@ -142,19 +142,23 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void conv_wgrad_kernel(const WgradP
         }
     };
 
+    GFE_FUZZ_INIT();
     if (t0 < t1) dma(t0, 0);
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
+        GFE_FUZZ();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        GFE_FUZZ();
         __builtin_amdgcn_s_barrier();                       // unit t has landed for every wave; nobody still reads the other buffer
         asm volatile("" ::: "memory");
+        GFE_FUZZ();
         const uint8_t* sb = smem + buf * BUF_BYTES;
 #pragma unroll
         for (int q = 0; q < TD * 4; ++q) {                  // K-chunk: plane q / 4, h rows 2 (q % 4) and + 1
             // the next unit's DMA instructions go out once the first chunk's fragment reads are in flight (their LDS round trip then runs
             // under the ~9 DMA issues instead of in front of the first MFMA): 1.025 -> 0.997 ms
-            if (q == 1 && t + 1 < t1) dma(t + 1, buf ^ 1);
+            if (q == 1 && t + 1 < t1) { GFE_FUZZ(); dma(t + 1, buf ^ 1); }
             const int dz = q >> 2, hy0 = (q & 3) * 2;
             const bf16x8 a = tr_frag(sb + dlane + ((dz * TH + hy0) * TW) * 64);
 #pragma unroll

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void interleave_rows_kernel(const float* __res
 // out[c] (+)= sum over rows [blockIdx.y*rows_per_block, ...) of x[r][c]: 4 row strips x 64 columns per block, strips folded in LDS.
 // One row block: plain store / read-modify-write; several: f32 atomics onto a zeroed (or accumulating) out.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int64_t ld, int accumulate,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), strip = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -263,14 +263,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     __syncthreads();
     if (strip == 0 && c < N) {
         const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (gridDim.y > 1) atomicAdd(out + c, t);
+        if (gridDim.y > 1 && part) part[(size_t)blockIdx.y * N + c] = t;              // one slot per row block, folded in order by colsum_fold_kernel
+        else if (gridDim.y > 1) atomicAdd(out + c, t);
         else out[c] = accumulate ? out[c] + t : t;
     }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int nblk, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nblk; k += 4) { t0 += part[(size_t)k * N + c]; t1 += part[(size_t)(k + 1) * N + c]; t2 += part[(size_t)(k + 2) * N + c]; t3 += part[(size_t)(k + 3) * N + c]; }
+    for (; k < nblk; ++k) t0 += part[(size_t)k * N + c];
+    const float t = (t0 + t1) + (t2 + t3);
+    out[c] = accumulate ? out[c] + t : t;
+}
+
+int64_t colsum_rblocks(int64_t M, int64_t N) {
+    int64_t rblocks = M <= 4096 ? 1 : ceil_div((int64_t)256, ceil_div(N, 64));
+    if (rblocks > ceil_div(M, 32)) rblocks = ceil_div(M, 32);
+    if (rblocks < 1) rblocks = 1;
+    const int64_t rpb = ceil_div(M, rblocks);
+    return ceil_div(M, rpb);
 }
 
 }  // namespace
 
 extern "C" {
+
+int gfe_colsum_rblocks(int64_t M, int64_t N) { return (M > 0 && N > 0) ? (int)colsum_rblocks(M, N) : 0; }
+
+int gfe_colsum_f32_ws(const float* x, float* out, float* ws, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream) {
+    GFE_REQUIRE(x && out && ws, GFE_ERR_NULL);
+    GFE_REQUIRE(M > 0 && N > 0 && M <= 0x7fffffff && N <= 0x7fffffff, GFE_ERR_SHAPE);
+    const int64_t rblocks = colsum_rblocks(M, N);
+    const int rpb = (int)ceil_div(M, rblocks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)rblocks), dim3(256), 0, st, x, out, (int)M, (int)N, ld, accumulate, rpb, rblocks > 1 ? ws : nullptr);
+    if (rblocks > 1) hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, ws, out, (int)N, (int)rblocks, accumulate);
+    return gfe_launch_status();
+}
 
 int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream) {
     GFE_REQUIRE(x && out, GFE_ERR_NULL);
@@ -285,7 +318,7 @@ int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld,
     rblocks = ceil_div(M, rpb);
     hipStream_t st = (hipStream_t)stream;
     if (rblocks > 1 && !accumulate) gfe_zero_async(out, (size_t)N * sizeof(float), st);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)rblocks), dim3(256), 0, st, x, out, (int)M, (int)N, ld, accumulate, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)rblocks), dim3(256), 0, st, x, out, (int)M, (int)N, ld, accumulate, rpb, (float*)nullptr);
     return gfe_launch_status();
 }
 

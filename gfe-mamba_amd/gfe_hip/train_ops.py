@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import call, nn_ops as K, ptr, stream
+from . import call, lib, nn_ops as K, ptr, stream
 from .nn_ops import BF16
 
 _SHADOW = {}        # id(parameter) -> bf16 view kept fresh by FlatAdam (avoids a cast per use)
@@ -215,7 +215,12 @@ class _LinearFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             slot = _grad_slot(ctx.bias_ref)
             db = slot if slot is not None else torch.empty(N, dtype=torch.float32, device=d32.device)
-            _leaf(lambda: call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), int(slot is not None), stream()), slot, d32)
+            nrb = int(lib().gfe_colsum_rblocks(d32.shape[0], N))            # > 1 beyond 4 096 rows: partial rows + an ordered fold (bit-reproducible)
+            cws = torch.empty(nrb * N, dtype=torch.float32, device=d32.device) if nrb > 1 else None
+            if cws is None:
+                _leaf(lambda: call("gfe_colsum_f32", ptr(d32), ptr(db), d32.shape[0], N, d32.stride(0), int(slot is not None), stream()), slot, d32)
+            else:
+                _leaf(lambda: call("gfe_colsum_f32_ws", ptr(d32), ptr(db), ptr(cws), d32.shape[0], N, d32.stride(0), int(slot is not None), stream()), slot, d32, cws)
             if slot is not None:
                 db = None
         return dx, dw, db, None, None, None

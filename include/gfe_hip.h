@@ -531,6 +531,10 @@ int gfe_mamba_step_ssm(const float* xc, const float* delta, const float* A_log, 
 
 /* out[n] (+)= sum_m x[m][n] for a row-major (M, N) f32 matrix (accumulate != 0: added to what out holds) with row stride ld: the bias gradient of every nn.Linear. */
 int gfe_colsum_f32(const float* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream);
+/* the same, bit-reproducible for any M: tall inputs write one partial row per row block into ws (gfe_colsum_rblocks(M, N) x N floats) and a
+ * second launch folds them in order -- gfe_colsum_f32 adds them with f32 atomics beyond 4 096 rows (the 3-D ViT's 13 832 token rows). */
+int gfe_colsum_rblocks(int64_t M, int64_t N);
+int gfe_colsum_f32_ws(const float* x, float* out, float* ws, int64_t M, int64_t N, int64_t ld, int accumulate, void* stream);
 
 /* Image condition (cross_atten/mamba_transformer.py:89-94): 'b c h w d -> (b c) (h w) d' then transpose(1, 2):
  * out[b][c][r] (bf16, row stride ldo, batch stride out_batch_stride) = in[b][r][c] (f32, contiguous (batch, R, Cc)). */

@@ -16,6 +16,10 @@ every launch sees another interleaving of its waves, including ones no box's clo
    reproduce the reference fingerprints bit for bit.  A mismatch prints the first diverging stage in network order and the tiles, and the
    run goes on (the count and the distinct stages are what localises a race).  --env switches (GFE_CONV_STATIC=1, GFE_CONV_BRICK=0,
    GFE_GEMM_NO_DMA=1, GFE_CONVT_STREAMED=1) apply to both children, for bisecting.
+--workload vit3d: the other hand-synchronised kernels (flash attention forward / dK-dV / dQ with their LDS-DMA rings and counted waits, the
+LDS-DMA GEMM under the 3-D ViT's projections, the fused conv weight gradient): the synthetic vit_3d.ViT forward, its training forward +
+backward (logits, dx, every parameter gradient) and one gfe_conv3d_wgrad launch, fingerprinted per 4096-word chunk -- all of them are
+deterministic kernels (no atomics), so every fuzzed run must again be bit-identical.
 Exit code 0 = every fuzzed run bit-identical to the un-fuzzed library."""
 import argparse
 import json
@@ -36,9 +40,11 @@ def child(role, args):
     import gfe_hip.det_init as det
     import gen_stages as G
     vol = (args.vol,) * 3
+    lib = os.path.basename(gfe_hip.LIB_PATH)
+    if args.workload == "vit3d":
+        return child_vit3d(role, args, lib, torch, G, det)
     gen, _, _ = build_models(vol=vol, seed=0)
     x = det.det_inputs(8, vol, seed=77)[0].cuda()
-    lib = os.path.basename(gfe_hip.LIB_PATH)
 
     def run(xb):
         st = G.staged_forward(gen, xb)
@@ -82,6 +88,60 @@ def child(role, args):
     return 1 if fails else 0
 
 
+def child_vit3d(role, args, lib, torch, G, det):
+    from vit_pytorch_diy.vit_3d import ViT
+    from gfe_hip.gen_train import conv_wgrad
+    from gfe_hip import nn_ops as K
+    B = 4
+    m = ViT(image_size=96, image_patch_size=8, frames=96, frame_patch_size=8, channels=1, dim=512, depth=4, heads=8, dim_head=64, mlp_dim=2048, num_classes=1)
+    m.load_state_dict(det.det_state_dict(m.state_dict(), seed=21, prefix="vit3d."))
+    m = m.cuda()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 1, 96, 96, 96, generator=g).clamp_(-1, 1).cuda()
+    wi = torch.randn(2, 32, 32, 32, 64, generator=g).to(torch.bfloat16).cuda()
+    wd = torch.randn(2, 32, 32, 32, 64, generator=g).to(torch.bfloat16).cuda()
+
+    def run():
+        out = {}
+        m.eval()
+        with torch.no_grad():
+            out["inference_logits"] = m(x)
+        m.train()                                               # (dropout 0: the training twin = flash attention with the row statistic + backward)
+        for p_ in m.parameters():
+            p_.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        (y * torch.linspace(0.5, 1.5, y.numel(), device=y.device).view_as(y)).sum().backward()
+        out["train_logits"], out["dx"] = y.detach(), xi.grad
+        for k_, p_ in m.named_parameters():
+            out["grad." + k_] = p_.grad
+        out["conv_wgrad"] = conv_wgrad(wi, wd, K.CONV3_TAPS)
+        return {k_: G.fingerprint(v_.detach().float().reshape(1, -1)).cpu() for k_, v_ in out.items()}
+
+    order = None
+    if role == "ref":
+        assert "fuzz" not in lib, lib
+        ref = run()
+        again = run()
+        order = tuple(ref.keys())
+        d = G.first_divergence(ref, again, order)
+        torch.save({"ref": ref}, args.ref)
+        print(json.dumps({"role": "ref", "workload": "vit3d", "lib": lib, "device": G.device_report(), "tensors": len(ref), "repeat_mismatch": d and (d[0], d[2])}), flush=True)
+        return 1 if d else 0
+    assert "fuzz" in lib, "the fuzz child must load the fuzz library (GFE_HIP_LIB): " + lib
+    ref = torch.load(args.ref)["ref"]
+    order = tuple(ref.keys())
+    fails, t0 = [], time.time()
+    for it in range(args.iters):
+        d = G.first_divergence(ref, run(), order)
+        if d:
+            fails.append({"iter": it, "tensor": d[0], "cells": d[1], "ncells": d[2]})
+            print("MISMATCH", json.dumps(fails[-1]), flush=True)
+    print(json.dumps({"role": "fuzz", "workload": "vit3d", "lib": lib, "iters": args.iters, "mismatching_runs": len(fails),
+                      "tensors": sorted({f["tensor"] for f in fails}), "seconds": round(time.time() - t0, 1)}), flush=True)
+    return 1 if fails else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
@@ -89,6 +149,7 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="K=V for both children (bisect switches)")
     ap.add_argument("--ref", default=os.path.join(ROOT, "gpurun_out", "timing_fuzz_ref.pt"))
     ap.add_argument("--role", default=None)
+    ap.add_argument("--workload", default="generator", choices=["generator", "vit3d"])
     ap.add_argument("--heavy", action="store_true", help="the heavier fuzz level (make fuzz_heavy: every other site visit sleeps, long sleeps at 1 of 32)")
     args = ap.parse_args()
     if args.role:
@@ -100,12 +161,12 @@ def main():
     for kv in args.env:
         k, v = kv.split("=", 1)
         env[k] = v
-    base = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--vol", str(args.vol), "--ref", args.ref]
+    base = [sys.executable, os.path.abspath(__file__), "--iters", str(args.iters), "--vol", str(args.vol), "--ref", args.ref, "--workload", args.workload]
     env.pop("GFE_HIP_LIB", None)
     rc_ref = subprocess.call(base + ["--role", "ref"], env=env)                  # children, never an exec of a GPU-initialised process
     env["GFE_HIP_LIB"] = FUZZ_LIB.replace("_fuzz.so", "_fuzz_heavy.so") if args.heavy else FUZZ_LIB
     rc_fuzz = subprocess.call(base + ["--role", "fuzz"], env=env)
-    print("timing_fuzz: ref rc %d (batch 8 == batch 1 on the product library), fuzz rc %d (%s)" % (
+    print("timing_fuzz [%s]: ref rc %d (the product library repeats itself / batch 8 == batch 1), fuzz rc %d (%s)" % (args.workload, 
         rc_ref, rc_fuzz, "every fuzzed run bit-identical" if rc_fuzz == 0 else "MISMATCHES, see above"))
     sys.exit(1 if (rc_ref or rc_fuzz) else 0)
 
