@@ -50,14 +50,37 @@ __global__ __launch_bounds__(256) void mask_relu_kernel(const bf16_t* __restrict
     }
 }
 
-// grid (voxel chunks, B); block 256: thread -> channel octet tid % (C/8), voxel lane tid / (C/8); partial sums -> LDS -> f32 atomics
+// The three reductions of this file (GroupNorm backward sums, the final conv's dw / db, the first lift's dw / db) share one shape: a block's
+// threads = (channel octet, row lane) hold 8 + 8 partial sums each; round 5 (the generator-training path was f32 atomics
+// throughout, so row f-1 was not run-to-run reproducible): the row lanes park their partials in LDS slots of their own and ONE thread per
+// column folds them in lane order; the block's result goes to its own slot of a caller workspace (ws != NULL) and gt_fold_kernel adds the
+// blocks in order -- no atomic anywhere.  ws == NULL keeps the old behaviour (f32 atomics onto the zeroed / accumulating target).
+__device__ __forceinline__ float gt_block_fold(const float* sm, int ncol, int vlanes, int i) {
+    float t = 0.f;
+    for (int v = 0; v < vlanes; ++v) t += sm[v * ncol + i];
+    return t;
+}
+// out[b][i] += sum over blocks of ws[(b * nblk + blk) * ncol + i]; columns >= split go to out2 (two target arrays: S1 | S2, dw | db)
+__global__ __launch_bounds__(256) void gt_fold_kernel(const float* __restrict__ ws, float* __restrict__ out1, float* __restrict__ out2, int nblk, int ncol, int split,
+                                                      int64_t ld1, int64_t ld2) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ncol) return;
+    const float* p = ws + (size_t)b * nblk * ncol + i;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nblk; k += 4) { t0 += p[(size_t)k * ncol]; t1 += p[(size_t)(k + 1) * ncol]; t2 += p[(size_t)(k + 2) * ncol]; t3 += p[(size_t)(k + 3) * ncol]; }
+    for (; k < nblk; ++k) t0 += p[(size_t)k * ncol];
+    const float t = (t0 + t1) + (t2 + t3);
+    if (i < split) { if (out1) out1[(size_t)b * ld1 + i] += t; }
+    else if (out2) out2[(size_t)b * ld2 + i - split] += t;
+}
+
+// grid (voxel chunks, B); block 256: thread -> channel octet tid % (C/8), voxel lane tid / (C/8)
 __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const bf16_t* __restrict__ dxh, const bf16_t* __restrict__ x, const float* __restrict__ mu,
                                                           const float* __restrict__ rstd, float* __restrict__ S1, float* __restrict__ S2,
-                                                          int64_t V, int C, int64_t vchunk) {
-    extern __shared__ float sm[];                 // [2][C]
+                                                          int64_t V, int C, int64_t vchunk, float* __restrict__ ws) {
+    extern __shared__ float sm[];                 // [vlanes][2 C]
     const int c8n = C / 8, b = blockIdx.y;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
-    __syncthreads();
     const int oct = threadIdx.x % c8n, vl = threadIdx.x / c8n, vlanes = 256 / c8n;
     if (vl < vlanes) {
         float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[8], r[8];
@@ -73,10 +96,14 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const bf16_t* __restri
             for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] = fmaf(g[k], (xv[k] - m[k]) * r[k], s2[k]); }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { atomicAdd(&sm[oct * 8 + k], s1[k]); atomicAdd(&sm[C + oct * 8 + k], s2[k]); }
+        for (int k = 0; k < 8; ++k) { sm[vl * 2 * C + oct * 8 + k] = s1[k]; sm[vl * 2 * C + C + oct * 8 + k] = s2[k]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(S1 + (size_t)b * C + i, sm[i]); atomicAdd(S2 + (size_t)b * C + i, sm[C + i]); }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const float t = gt_block_fold(sm, 2 * C, vlanes, i);
+        if (ws) ws[((size_t)b * gridDim.x + blockIdx.x) * 2 * C + i] = t;
+        else atomicAdd((i < C ? S1 : S2) + (size_t)b * C + (i < C ? i : i - C), t);
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ dxh, const bf16_t* __restrict__ x, const float* __restrict__ mu,
@@ -138,11 +165,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restr
 
 // final conv C -> 1: x (rows, C) bf16, dy (rows) f32, w (C): dx = dy * w (bf16); dw[c] += sum dy * x; db += sum dy
 __global__ __launch_bounds__(256) void out1_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
-                                                       bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int64_t rows, int C, int64_t rchunk) {
-    extern __shared__ float sm[];                 // [C + 1]
-    const int c8n = C / 8;
-    for (int i = threadIdx.x; i <= C; i += 256) sm[i] = 0.f;
-    __syncthreads();
+                                                       bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int64_t rows, int C, int64_t rchunk,
+                                                       float* __restrict__ ws) {
+    extern __shared__ float sm[];                 // [rlanes][C + 8]  (column C: the row lane's sum of dy)
+    const int c8n = C / 8, NC = C + 8;
     const int oct = threadIdx.x % c8n, rl = threadIdx.x / c8n, rlanes = 256 / c8n;
     if (rl < rlanes) {
         float wv[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
@@ -159,21 +185,22 @@ __global__ __launch_bounds__(256) void out1_bwd_kernel(const bf16_t* __restrict_
             if (oct == 0) sb += g;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&sm[oct * 8 + k], acc[k]);
-        if (oct == 0) atomicAdd(&sm[C], sb);
+        for (int k = 0; k < 8; ++k) sm[rl * NC + oct * 8 + k] = acc[k];
+        if (oct == 0) sm[rl * NC + C] = sb;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dw + i, sm[i]);
-    if (threadIdx.x == 0) atomicAdd(db, sm[C]);
+    for (int i = threadIdx.x; i <= C; i += 256) {
+        const float t = gt_block_fold(sm, NC, rlanes, i);
+        if (ws) ws[(size_t)blockIdx.x * (C + 1) + i] = t;
+        else atomicAdd(i < C ? dw + i : db, t);
+    }
 }
 
 // first lift 1 -> C: x (rows) f32, dr (rows, C) bf16: dw[c] += sum dr * x, db[c] += sum dr
 __global__ __launch_bounds__(256) void in1_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dr, float* __restrict__ dw, float* __restrict__ db,
-                                                        int64_t rows, int C, int64_t rchunk) {
-    extern __shared__ float sm[];                 // [2][C]
+                                                        int64_t rows, int C, int64_t rchunk, float* __restrict__ ws) {
+    extern __shared__ float sm[];                 // [rlanes][2 C]
     const int c8n = C / 8;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
-    __syncthreads();
     const int oct = threadIdx.x % c8n, rl = threadIdx.x / c8n, rlanes = 256 / c8n;
     if (rl < rlanes) {
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -186,10 +213,15 @@ __global__ __launch_bounds__(256) void in1_wgrad_kernel(const float* __restrict_
             for (int k = 0; k < 8; ++k) { a[k] = fmaf(g[k], xv, a[k]); s[k] += g[k]; }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { atomicAdd(&sm[oct * 8 + k], a[k]); atomicAdd(&sm[C + oct * 8 + k], s[k]); }
+        for (int k = 0; k < 8; ++k) { sm[rl * 2 * C + oct * 8 + k] = a[k]; sm[rl * 2 * C + C + oct * 8 + k] = s[k]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) { if (dw) atomicAdd(dw + i, sm[i]); atomicAdd(db + i, sm[C + i]); }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const float t = gt_block_fold(sm, 2 * C, rlanes, i);
+        if (ws) ws[(size_t)blockIdx.x * 2 * C + i] = t;
+        else if (i < C) { if (dw) atomicAdd(dw + i, t); }
+        else atomicAdd(db + i - C, t);
+    }
 }
 
 static unsigned grid_for(int64_t items) { int64_t g = ceil_div(items, 256); return (unsigned)(g > 8192 ? 8192 : g); }
@@ -213,14 +245,22 @@ int gfe_mask_relu_bf16(const void* dy, const void* y, void* out, int64_t n, void
     return gfe_launch_status();
 }
 
-int gfe_gn_bwd_sums(const void* dxhat, const void* x, const float* mu, const float* rstd, float* S1_zeroed, float* S2_zeroed,
+static int64_t gt_blocks(int64_t n, int64_t per, int64_t cap) {
+    int64_t chunks = ceil_div(n, per); if (chunks > cap) chunks = cap;
+    return ceil_div(n, ceil_div(n, chunks));
+}
+int gfe_gn_bwd_sums_blocks(int64_t V) { return V > 0 ? (int)gt_blocks(V, 2048, 1024) : 0; }
+int gfe_gen_rows_blocks(int64_t rows) { return rows > 0 ? (int)gt_blocks(rows, 4096, 2048) : 0; }
+
+int gfe_gn_bwd_sums(const void* dxhat, const void* x, const float* mu, const float* rstd, float* S1_zeroed, float* S2_zeroed, float* ws,
                     int64_t B, int64_t V, int64_t C, void* stream) {
     GFE_REQUIRE(dxhat && x && mu && rstd && S1_zeroed && S2_zeroed, GFE_ERR_NULL);
-    GFE_REQUIRE(B > 0 && B <= 65535 && V > 0 && C > 0 && C % 8 == 0 && C <= 2048, GFE_ERR_SHAPE);
-    int64_t chunks = ceil_div(V, 2048); if (chunks > 1024) chunks = 1024;
-    const int64_t vchunk = ceil_div(V, chunks);
-    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3((unsigned)ceil_div(V, vchunk), (unsigned)B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream,
-                       (const bf16_t*)dxhat, (const bf16_t*)x, mu, rstd, S1_zeroed, S2_zeroed, V, (int)C, vchunk);
+    GFE_REQUIRE(B > 0 && B <= 65535 && V > 0 && C > 0 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, GFE_ERR_SHAPE);
+    const int64_t nblk = gt_blocks(V, 2048, 1024), vchunk = ceil_div(V, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), (size_t)(256 / (C / 8)) * 2 * C * sizeof(float), st,
+                       (const bf16_t*)dxhat, (const bf16_t*)x, mu, rstd, S1_zeroed, S2_zeroed, V, (int)C, vchunk, ws);
+    if (ws) hipLaunchKernelGGL(gt_fold_kernel, dim3((unsigned)ceil_div(2 * C, 256), (unsigned)B), dim3(256), 0, st, ws, S1_zeroed, S2_zeroed, (int)nblk, (int)(2 * C), (int)C, C, C);
     return gfe_launch_status();
 }
 
@@ -243,23 +283,25 @@ int gfe_maxpool2_bwd(const void* x, const void* dy, void* dx_zeroed, int64_t B, 
     return gfe_launch_status();
 }
 
-int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream) {
+int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw_accum, float* db_accum, float* ws, int64_t rows, int64_t C, void* stream) {
     GFE_REQUIRE(x && dy && w && dx && dw_accum && db_accum, GFE_ERR_NULL);
-    GFE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, GFE_ERR_SHAPE);
-    int64_t chunks = ceil_div(rows, 4096); if (chunks > 2048) chunks = 2048;
-    const int64_t rchunk = ceil_div(rows, chunks);
-    hipLaunchKernelGGL(out1_bwd_kernel, dim3((unsigned)ceil_div(rows, rchunk)), dim3(256), (size_t)(C + 1) * sizeof(float), (hipStream_t)stream,
-                       (const bf16_t*)x, dy, w, (bf16_t*)dx, dw_accum, db_accum, rows, (int)C, rchunk);
+    GFE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, GFE_ERR_SHAPE);
+    const int64_t nblk = gt_blocks(rows, 4096, 2048), rchunk = ceil_div(rows, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(out1_bwd_kernel, dim3((unsigned)nblk), dim3(256), (size_t)(256 / (C / 8)) * (C + 8) * sizeof(float), st,
+                       (const bf16_t*)x, dy, w, (bf16_t*)dx, dw_accum, db_accum, rows, (int)C, rchunk, ws);
+    if (ws) hipLaunchKernelGGL(gt_fold_kernel, dim3((unsigned)ceil_div(C + 1, 256), 1), dim3(256), 0, st, ws, dw_accum, db_accum, (int)nblk, (int)(C + 1), (int)C, 0, 0);
     return gfe_launch_status();
 }
 
-int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream) {
+int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, float* ws, int64_t rows, int64_t C, void* stream) {
     GFE_REQUIRE(dr && db_accum, GFE_ERR_NULL);
-    GFE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, GFE_ERR_SHAPE);
-    int64_t chunks = ceil_div(rows, 4096); if (chunks > 2048) chunks = 2048;
-    const int64_t rchunk = ceil_div(rows, chunks);
-    hipLaunchKernelGGL(in1_wgrad_kernel, dim3((unsigned)ceil_div(rows, rchunk)), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream,
-                       x, (const bf16_t*)dr, dw_accum, db_accum, rows, (int)C, rchunk);
+    GFE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, GFE_ERR_SHAPE);
+    const int64_t nblk = gt_blocks(rows, 4096, 2048), rchunk = ceil_div(rows, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(in1_wgrad_kernel, dim3((unsigned)nblk), dim3(256), (size_t)(256 / (C / 8)) * 2 * C * sizeof(float), st,
+                       x, (const bf16_t*)dr, dw_accum, db_accum, rows, (int)C, rchunk, ws);
+    if (ws) hipLaunchKernelGGL(gt_fold_kernel, dim3((unsigned)ceil_div(2 * C, 256), 1), dim3(256), 0, st, ws, dw_accum, db_accum, (int)nblk, (int)(2 * C), (int)C, 0, 0);
     return gfe_launch_status();
 }
 

@@ -12,12 +12,11 @@ namespace {
 // is what the conv kernel applies while staging its input tile.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws,
                                                          int64_t S, int C, int vpb, int nblk) {
-    extern __shared__ float lds[];               // [2][C]
+    extern __shared__ float lds[];               // [VI][2][C]: one slot per voxel lane, merged in lane order (round 5: was LDS float atomics,
+                                                 // whose order -- and with it the last bits of the training forward -- changed from run to run)
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const int CP = C >> 3;                       // 16-B chunks per voxel
     const int c = tid % CP, vl = tid / CP, VI = 256 / CP;
-    for (int i = tid; i < 2 * C; i += 256) lds[i] = 0.f;
-    __syncthreads();
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
@@ -31,11 +30,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
     }
+    if (vl < VI) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&lds[c * 8 + j], s[j]); atomicAdd(&lds[C + c * 8 + j], q[j]); }
+        for (int j = 0; j < 8; ++j) { lds[(vl * 2) * C + c * 8 + j] = s[j]; lds[(vl * 2 + 1) * C + c * 8 + j] = q[j]; }
+    }
     __syncthreads();
     float* o = ws + ((size_t)b * nblk + blk) * 2 * C;
-    for (int i = tid; i < 2 * C; i += 256) o[i] = lds[i];
+    for (int i = tid; i < 2 * C; i += 256) {
+        float t = 0.f;
+        for (int k = 0; k < VI; ++k) t += lds[k * 2 * C + i];
+        o[i] = t;
+    }
 }
 
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
@@ -445,7 +450,7 @@ int gfe_groupnorm_scale_shift(const void* x, const float* gamma, const float* be
     int vpb, nblk;
     gfe_groupnorm_plan(S, &vpb, &nblk);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, (unsigned)B), dim3(256), 2 * C * sizeof(float), st,
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, (unsigned)B), dim3(256), (size_t)(256 / (C / 8)) * 2 * C * sizeof(float), st,
                        (const bf16_t*)x, ws, S, (int)C, vpb, nblk);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(1024), (2 * C + 2 * G + 1024) * sizeof(double), st,
                        ws, gamma, beta, scale, shift, S, (int)C, (int)G, nblk, eps);

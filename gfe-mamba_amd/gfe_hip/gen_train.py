@@ -99,7 +99,8 @@ class _GroupNormFn(torch.autograd.Function):
         G = ctx.groups
         d = dxhat.contiguous()
         S = torch.zeros((2, B, C), dtype=torch.float32, device=x.device)
-        call("gfe_gn_bwd_sums", ptr(d), ptr(x), ptr(mu), ptr(rstd), ptr(S[0]), ptr(S[1]), B, V, C, stream())
+        ws = torch.empty(B * int(lib().gfe_gn_bwd_sums_blocks(V)) * 2 * C, dtype=torch.float32, device=x.device)    # per-block partial rows, folded in order
+        call("gfe_gn_bwd_sums", ptr(d), ptr(x), ptr(mu), ptr(rstd), ptr(S[0]), ptr(S[1]), ptr(ws), B, V, C, stream())
         m = float((C // G) * V)
         ca = ((g * S[0]).view(B, G, C // G).sum(-1, keepdim=True) / m).expand(B, G, C // G).reshape(B, C).contiguous()
         cb = ((g * S[1]).view(B, G, C // G).sum(-1, keepdim=True) / m).expand(B, G, C // G).reshape(B, C).contiguous()
@@ -158,7 +159,8 @@ class _Conv1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = K.gemm_ex(d2, True, x2, True, split_k=max(1, min(256, d2.shape[0] // 4096))).view(weight.shape).to(weight.dtype)
         db = torch.zeros(cout, dtype=torch.float32, device=d.device)
-        call("gfe_conv_in1_wgrad", None, ptr(d2), None, ptr(db), d2.shape[0], cout, stream())
+        ws = torch.empty(int(lib().gfe_gen_rows_blocks(d2.shape[0])) * 2 * cout, dtype=torch.float32, device=d.device)
+        call("gfe_conv_in1_wgrad", None, ptr(d2), None, ptr(db), ptr(ws), d2.shape[0], cout, stream())
         return dx, dw, db
 
 
@@ -178,7 +180,8 @@ class _LiftIn1Fn(torch.autograd.Function):
         C = dr.shape[-1]
         d = dr.contiguous().view(-1, C)
         g = torch.zeros((2, C), dtype=torch.float32, device=d.device)
-        call("gfe_conv_in1_wgrad", ptr(x.contiguous().float()), ptr(d), ptr(g[0]), ptr(g[1]), d.shape[0], C, stream())
+        ws = torch.empty(int(lib().gfe_gen_rows_blocks(d.shape[0])) * 2 * C, dtype=torch.float32, device=d.device)
+        call("gfe_conv_in1_wgrad", ptr(x.contiguous().float()), ptr(d), ptr(g[0]), ptr(g[1]), ptr(ws), d.shape[0], C, stream())
         return None, g[0].view(ctx.wshape), g[1]
 
 
@@ -300,7 +303,8 @@ class _Out1Fn(torch.autograd.Function):
         d = dy.contiguous().float().view(-1)
         dx = torch.empty_like(x)
         g = torch.zeros(C + 1, dtype=torch.float32, device=x.device)
-        call("gfe_conv_out1_bwd", ptr(x), ptr(d), ptr(w), ptr(dx), ptr(g[:C]), ptr(g[C:]), d.numel(), C, stream())
+        ws = torch.empty(int(lib().gfe_gen_rows_blocks(d.numel())) * (C + 1), dtype=torch.float32, device=x.device)
+        call("gfe_conv_out1_bwd", ptr(x), ptr(d), ptr(w), ptr(dx), ptr(g[:C]), ptr(g[C:]), ptr(ws), d.numel(), C, stream())
         return dx, g[:C].view(ctx.wshape), g[C:].view(1)
 
 

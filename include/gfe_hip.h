@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 44
+#define GFE_ABI_VERSION 45
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -355,8 +355,13 @@ int gfe_mid_linear_wgrad(const void* mid_in, const void* mid_out, const float* d
 int gfe_gn_apply(const void* x, const float* scale, const float* shift, void* y, int64_t B, int64_t V, int64_t C, void* stream);
 /* ReLU backward from the stored output: out = dy * (y > 0); n elements, n % 8 == 0. */
 int gfe_mask_relu_bf16(const void* dy, const void* y, void* out, int64_t n, void* stream);
-/* GroupNorm backward, pass 1: S1[b,c] += sum_v dx^, S2[b,c] += sum_v dx^ * (x - mu[b,c]) * rstd[b,c]  (mu / rstd: the group's values per channel). */
-int gfe_gn_bwd_sums(const void* dxhat, const void* x, const float* mu, const float* rstd, float* S1_zeroed, float* S2_zeroed,
+/* GroupNorm backward, pass 1: S1[b,c] += sum_v dx^, S2[b,c] += sum_v dx^ * (x - mu[b,c]) * rstd[b,c]  (mu / rstd: the group's values per channel).
+ * ws (ABI 45): B * gfe_gn_bwd_sums_blocks(V) * 2C floats -- every block stores its partial row there and a second launch adds them in order
+ * (bit-reproducible); NULL: f32 atomics.  The same holds for gfe_conv_out1_bwd (ws: gfe_gen_rows_blocks(rows) * (C + 1) floats) and
+ * gfe_conv_in1_wgrad (gfe_gen_rows_blocks(rows) * 2C). */
+int gfe_gn_bwd_sums_blocks(int64_t V);
+int gfe_gen_rows_blocks(int64_t rows);
+int gfe_gn_bwd_sums(const void* dxhat, const void* x, const float* mu, const float* rstd, float* S1_zeroed, float* S2_zeroed, float* ws,
                     int64_t B, int64_t V, int64_t C, void* stream);
 /* pass 2: dx = rstd * (gamma * dx^ - coef_a[b,c] - xn * coef_b[b,c]) (+ add_in: a second gradient into the same tensor, or NULL);
  * coef_a / coef_b = the group's mean of gamma * S1 / gamma * S2 over (channels of the group x voxels), per channel. */
@@ -366,10 +371,10 @@ int gfe_gn_bwd_apply(const void* dxhat, const void* x, const float* mu, const fl
  * a window in (d, h, w) order receives the gradient. */
 int gfe_maxpool2_bwd(const void* x, const void* dy, void* dx_zeroed, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, void* stream);
 /* final 1x1x1 conv C -> 1 (model.py:123, 162) backward: x (rows, C) bf16, dy (rows) f32: dx = dy * w; dw += sum dy * x; db += sum dy. */
-int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream);
+int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw_accum, float* db_accum, float* ws, int64_t rows, int64_t C, void* stream);
 /* 1x1x1 lift gradients from dr (rows, C) bf16: db[c] += sum dr; with x (rows) f32 of a one-channel input also dw[c] += sum dr * x
  * (x == NULL and dw == NULL: bias gradient only). */
-int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, int64_t rows, int64_t C, void* stream);
+int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, float* ws, int64_t rows, int64_t C, void* stream);
 
 /* Weight gradient of a tap-list convolution (the backward of nn.Conv3d k3 p1 / the parity classes of ConvTranspose3d k3 s2 p1,
  * pytorch3dunet/unet3d/buildingblocks.py:46-52, 523-537), ALL taps in one launch (csrc/conv_wgrad.hip):

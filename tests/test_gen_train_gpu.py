@@ -215,6 +215,33 @@ def test_generator_training_gradients_vs_oracle_autograd(tag, vol, f_maps, vit, 
     assert med < 2e-2 and worst[0][0] < 6e-2 and wn < 3e-2              # measured 9.5e-3 / 3.2e-2 / 8.9e-3
 
 
+@pytest.mark.parametrize("vol,f_maps,vit", [((32, 32, 32), (8, 16, 32), dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128)),
+                                            ((64, 64, 64), (64, 128, 256), None)])
+def test_generator_training_backward_is_bit_reproducible(vol, f_maps, vit):
+    """the generator-training path summed its GroupNorm-backward moments, the final conv's and the first lift's dw / db and
+    the tall bias gradients with f32 atomics, so row f-1 was not run-to-run reproducible.  Round 5: per-lane LDS slots + per-block partial rows
+    folded in order (csrc/gen_train.hip, gfe_colsum_f32_ws).  Two forward + backward passes from the same state: the loss and EVERY
+    parameter gradient must be bit-identical."""
+    import gfe_hip.det_init as det
+    from gfe_hip.gen_train import generator_forward_train
+    from pytorch3dunet.unet3d.model import Residual_mid_UNet3D_vit
+    gen = Residual_mid_UNet3D_vit(1, 1, is_segmentation=False, f_maps=f_maps, vol_size=vol, vit_kwargs=vit)
+    gen.load_state_dict(det.det_state_dict(gen.state_dict(), seed=57, prefix="gtrain3."))
+    gen = gen.to(DEV).eval()
+    x = det.det_inputs(2, vol, seed=57)[0].to(DEV)
+    target = torch.tanh(torch.randn(2, 1, *vol, generator=torch.Generator().manual_seed(58))).to(DEV)
+    runs = []
+    for _ in range(2):
+        for p in gen.parameters():
+            p.grad = None
+        loss = F.l1_loss(generator_forward_train(gen, x), target)
+        loss.backward()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    diff = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
+    assert not diff, "gradients differ between two identical passes: %s" % diff[:8]
+
+
 def test_generator_train_steps_reduce_the_l1_loss_and_refresh_the_frozen_packs():
     """train_step (main_gan_vit.py:68-82 minus the third-party losses) with FlatAdam: the loss falls over a few steps, and the eval-mode
     forward (which caches packed / GroupNorm-folded weights) sees the updated parameters although the update kernel rewrites them
