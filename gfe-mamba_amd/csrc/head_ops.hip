@@ -9,6 +9,7 @@
 //   geglu          corss_ft_transformer.py:10-13, 19         x * gelu(gates) (exact erf GELU) followed by Dropout(p)
 //   bce_sigmoid    classify_mamba.py:104                     BCELoss(sigmoid(logit), y), mean over the batch, log clamped at -100
 #include "common.h"
+#include "attn_drop.h"
 
 namespace {
 
@@ -629,8 +630,13 @@ __global__ __launch_bounds__(256) void bce_sigmoid_fwd_kernel(const float* __res
 
 // exact-erf GELU as an operator of its own (vit_pytorch_diy/vit_3d.py:21 / vit.py:19 inside FeedForward when the module TRAINS: the inference
 // path has it in the GEMM epilogue; under autograd the pre-activation has to survive for the backward): x, y f32 or bf16, 4 values per lane
-// 16 bytes per lane and access (4 f32 / 8 bf16), a scalar tail; n4 = number of whole 16-byte groups
+// nn.Dropout(p) as an operator of its own (the residual-branch dropouts of vit.py:24-27, 62 / vit_3d.py:25-28 in training mode): y = x * keep / (1 - p),
+// keep = a counter-based hash of (seed, element) -- the attention kernels' hash (attn_drop.h) -- so the backward applies the SAME launch to dy
+// and no mask is stored; f32 or bf16, 4 / 8 values per lane
 template <typename T> struct GeluVec;
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int vec, uint32_t thr, uint32_t seed_lo, uint32_t seed_hi, float inv_keep);
+// 16 bytes per lane and access (4 f32 / 8 bf16), a scalar tail; n4 = number of whole 16-byte groups
 template <> struct GeluVec<float> { static constexpr int N = 4; };
 template <> struct GeluVec<bf16_t> { static constexpr int N = 8; };
 template <typename T>
@@ -656,6 +662,24 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, 
         reinterpret_cast<uint4*>(y)[i] = gelu_pack<T>(f);
     }
     for (int64_t i = nv * N + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) IO<T>::st(y + i, gelu_erf_(IO<T>::ld(x + i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int vec, uint32_t thr, uint32_t seed_lo, uint32_t seed_hi, float inv_keep) {
+    constexpr int N = GeluVec<T>::N;
+    const int64_t nv = vec ? n / N : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float f[N];
+        gelu_unpack<T>(reinterpret_cast<const uint4*>(x)[i], f);
+        const uint64_t e0 = (uint64_t)i * N;
+        const uint32_t sd = attn_drop_seed(seed_lo, seed_hi, (uint32_t)(e0 >> 32));
+#pragma unroll
+        for (int k = 0; k < N; ++k) f[k] = attn_drop_hash(sd, (uint32_t)e0 + (uint32_t)k) < thr ? 0.f : f[k] * inv_keep;
+        reinterpret_cast<uint4*>(y)[i] = gelu_pack<T>(f);
+    }
+    for (int64_t i = nv * N + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t sd = attn_drop_seed(seed_lo, seed_hi, (uint32_t)((uint64_t)i >> 32));
+        IO<T>::st(y + i, attn_drop_hash(sd, (uint32_t)i) < thr ? 0.f : IO<T>::ld(x + i) * inv_keep);
+    }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, int vec) {
@@ -807,6 +831,19 @@ int gfe_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, 
     int64_t g = ceil_div(n, 256 * 8); if (g > 8192) g = 8192;
     if (dtype == GFE_F32) hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, n, vec);
     else if (dtype == GFE_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, vec);
+    else return GFE_ERR_DTYPE;
+    return gfe_launch_status();
+}
+
+int gfe_dropout(const void* x, void* y, int64_t n, float p_drop, int64_t seed, int dtype, void* stream) {
+    GFE_REQUIRE(x && y, GFE_ERR_NULL);
+    GFE_REQUIRE(n > 0 && p_drop >= 0.f && p_drop < 1.f, GFE_ERR_SHAPE);
+    const int vec = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const uint32_t thr = attn_drop_threshold(p_drop), lo = (uint32_t)(uint64_t)seed, hi = (uint32_t)((uint64_t)seed >> 32);
+    const float inv_keep = 1.0f / (1.0f - p_drop);
+    int64_t g = ceil_div(n, 256 * 8); if (g > 8192) g = 8192;
+    if (dtype == GFE_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, vec, thr, lo, hi, inv_keep);
+    else if (dtype == GFE_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n, vec, thr, lo, hi, inv_keep);
     else return GFE_ERR_DTYPE;
     return gfe_launch_status();
 }

@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from . import call, lib, nn_ops as K, ptr, stream
-from .head_ops import gelu, layernorm_rows, sdpa_small
+from .head_ops import dropout, gelu, layernorm_rows, sdpa_small
 from .nn_ops import BF16
 from .train_ops import linear
 
@@ -329,7 +329,7 @@ def resnet_block(blk, x):
 
 
 def _dropout(x, module):
-    return F.dropout(x, module.p, True) if module.training and module.p > 0 else x
+    return dropout(x, module.p, module.training)
 
 
 def vit_forward_train(vit, img):

@@ -339,6 +339,39 @@ def gelu(x):
     return _Gelu.apply(x)
 
 
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x_ = x.detach().contiguous()
+        if x_.dtype not in (torch.float32, torch.bfloat16):
+            x_ = x_.float()
+        y = torch.empty_like(x_)
+        call("gfe_dropout", ptr(x_), ptr(y), x_.numel(), float(p), seed, dtype_code(x_.dtype), stream())
+        ctx.meta = (float(p), seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        d = dy.contiguous()
+        if d.dtype not in (torch.float32, torch.bfloat16):
+            d = d.float()
+        dx = torch.empty_like(d)
+        call("gfe_dropout", ptr(d), ptr(dx), d.numel(), p, seed, dtype_code(d.dtype), stream())
+        return dx, None, None
+
+
+def dropout(x, p, training=True):
+    """nn.Dropout(p)(x) in training mode on the HIP path: the mask is a counter-based hash of (seed, element) -- seed from torch's generator seed
+    (per-rank seeds give per-rank masks) and a call counter -- regenerated by the backward, never stored; identity when not training or p == 0."""
+    if not training or p <= 0.0:
+        return x
+    _need_cuda(x, "dropout")
+    _DROP_CALLS[0] += 1
+    seed = (torch.initial_seed() * 1000003 + 7919 * _DROP_CALLS[0]) & 0x7FFFFFFFFFFFFFFF
+    return _Dropout.apply(x, float(p), seed)
+
+
 class _SiluMul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, u):

@@ -90,13 +90,12 @@ class ViT(nn.Module):
     def forward_train(self, video):
         """vit_3d.py:113-128 with autograd (module.training decides the dropouts): every op is a HIP-kernel autograd node; attention is
         train_ops.qkv_flash_attention for dim_head 64 (any token count), the 64-token kernel of the classifier head otherwise."""
-        import torch.nn.functional as F
-        from gfe_hip.head_ops import gelu, layernorm_rows, sdpa_small
+        from gfe_hip.head_ops import dropout, gelu, layernorm_rows, sdpa_small
         from gfe_hip.train_ops import linear as linear_, qkv_flash_attention
         linear = lambda a, w, b: linear_(a, w, b, exact=False)         # bf16 MFMA operands, like the inference pipeline and the attention
         n, dim = self.num_patches, self.dim
         B, T = video.shape[0], n + 1
-        drop = lambda x, m: F.dropout(x, m.p, True) if (m.training and m.p > 0) else x
+        drop = lambda x, m: dropout(x, m.p, m.training)                    # nn.Dropout on the residual branches: hash mask, regenerated in the backward
         tpe = self.to_patch_embedding
         t = self.patchify(video.float()).contiguous()
         t = layernorm_rows(t, tpe[1].weight, tpe[1].bias, tpe[1].eps)

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 45
+#define GFE_ABI_VERSION 46
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -458,6 +458,9 @@ int gfe_layernorm_rows_bwd(const float* x, const float* gamma, const float* mean
  * inference path carries the activation in the GEMM epilogue; training has to keep the pre-activation).  n elements, dtype GFE_F32 | GFE_BF16. */
 int gfe_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int gfe_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+/* nn.Dropout(p) in training mode (vit.py:24-27, 62; vit_3d.py:25-28): y = x * keep / (1 - p), keep = hash(seed, element) (csrc/attn_drop.h);
+ * its backward is the same call on dy with the same (p, seed) -- no mask is stored.  n elements, dtype GFE_F32 | GFE_BF16. */
+int gfe_dropout(const void* x, void* y, int64_t n, float p_drop, int64_t seed, int dtype, void* stream);
 
 /* GEGLU (corss_ft_transformer.py:10-13: x, gates = chunk(2); x * gelu(gates), exact erf) followed by Dropout(p_drop) (:19):
  * x (rows, 2F) -> y (rows, F).  The mask is a counter-based hash of (seed, element index): the backward regenerates it from the

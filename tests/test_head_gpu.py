@@ -265,6 +265,32 @@ def test_gelu_and_silu_mul_operators_vs_torch(n, dt):
         assert rel_err(h, r.float()) < 1e-6 and rel_err(a.grad, a64.grad.float()) < 2e-6 and rel_err(b.grad, b64.grad.float()) < 1e-6
 
 
+@pytest.mark.parametrize("n,dt", [(13832 * 16 + 3, torch.float32), (4096 * 7 + 5, torch.bfloat16), (5, torch.float32)])
+def test_dropout_operator_mask_statistics_and_backward(n, dt):
+    """gfe_dropout (nn.Dropout in the training twins, vit.py:24-27 / vit_3d.py:25-28): kept values are x / (1 - p) exactly as torch rounds them,
+    the kept fraction is 1 - p within 5 sigma, the backward regenerates the SAME mask, two calls draw different masks, eval / p = 0 are the identity,
+    vector body + scalar tail + a view that is not 16-byte aligned."""
+    from gfe_hip.head_ops import dropout
+    g = torch.Generator().manual_seed(n)
+    p = 0.25
+    x = (torch.randn(n + 1, generator=g).abs() + 0.5).to(dt).to(DEV)
+    masks = []
+    for off in (0, 1):
+        xi = x[off:off + n].detach().requires_grad_(True)
+        y = dropout(xi, p, True)
+        w = (torch.randn(n, generator=g).abs() + 0.5).to(dt).to(DEV)
+        (y.float() * w.float()).sum().backward()
+        keep = y != 0
+        assert torch.equal(y[keep], (xi.detach().float()[keep] * (1.0 / (1.0 - p))).to(dt))
+        assert torch.equal(xi.grad != 0, keep) and torch.equal(xi.grad[keep], (w.float()[keep] * (1.0 / (1.0 - p))).to(dt))
+        if n > 1000:
+            assert abs(keep.float().mean().item() - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
+        masks.append(keep)
+    if n > 1000:
+        assert (masks[0] != masks[1]).float().mean().item() > 0.2           # another call, another mask
+    assert dropout(x, p, False) is x and dropout(x, 0.0, True) is x
+
+
 def test_embedding_offsets_bit_exact():
     from cross_atten.mamba_transformer import Cross_mamba_both
     fx = golden("t0_head_ops.npz")
