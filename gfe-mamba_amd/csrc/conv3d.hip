@@ -117,6 +117,9 @@ struct ConvParams {
     // dynamic tile scheduling (single-class launches): sched[0..7] = per-XCD ticket counters, sched[8] = finished blocks; zero between
     // launches (the last block to finish resets them).  NULL: every block walks its static share.
     int* sched;
+    // work-item index -> (sample, tile, class) without integer divisions in the unit loop: n / d = umulhi(n, mg_d) with mg_d = 2^32 / d + 1, exact while
+    // n * d < 2^32 (conv_launch checks, and passes 0 = "divide" otherwise, or for d == 1)
+    unsigned mg_per, mg_nbw, mg_nbh, mg_ntw, mg_nth, mg_ntd, mg_ncls;
 };
 
 struct TilePos { int b, td, th, tw, cls; };
@@ -239,24 +242,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         wvoff[j] = (k < W_PIECES && R < WSTAGE_ROWS) ? (unsigned)((tl * p.CoutPad + r) * 64 + c * 16) : OOB;
     }
 
-    auto decode = [&](int t) {
+    // (block-uniform unsigned arithmetic: a 32-bit division by a kernel argument is ~25 scalar + 5 vector instructions, and the unit loop used to
+    // do sixteen of them per unit on every wave, with the matrix pipe idle -- round 5)
+    auto fdiv = [&](unsigned n, unsigned d, unsigned mg) -> unsigned { return mg ? __umulhi(n, mg) : n / d; };
+    auto decode = [&](int t_) {
         TilePos q;
         q.cls = 0;
-        if constexpr (MC) { q.cls = t % p.ncls; t /= p.ncls; }
+        unsigned t = (unsigned)t_;
+        if constexpr (MC) { const unsigned tq = fdiv(t, (unsigned)p.ncls, p.mg_ncls); q.cls = (int)(t - tq * (unsigned)p.ncls); t = tq; }
         if (!MC && p.brick) {
             // 32 consecutive work items = one 4 x 4 x 2 brick of tiles: what the 32 blocks of an XCD work on at one time then shares halo faces in
             // all three directions inside the XCD's L2 (in tw-fastest order the d-neighbour of a tile is 144 items = 4.5 rounds away)
-            const int per = p.ntd * p.nth * p.ntw;
-            q.b = t / per;
-            const int r = t - q.b * per, br = r >> 5, in = r & 31;
-            const int nbw = p.ntw >> 2, nbh = p.nth >> 2;
-            const int bw_ = br % nbw, bh_ = (br / nbw) % nbh, bd_ = br / (nbw * nbh);
-            q.tw = bw_ * 4 + (in & 3); q.th = bh_ * 4 + ((in >> 2) & 3); q.td = bd_ * 2 + (in >> 4);
+            const unsigned per = (unsigned)(p.ntd * p.nth * p.ntw);
+            const unsigned bb = fdiv(t, per, p.mg_per);
+            const unsigned r = t - bb * per, br = r >> 5, in = r & 31;
+            const unsigned nbw = (unsigned)p.ntw >> 2, nbh = (unsigned)p.nth >> 2;
+            const unsigned q1 = fdiv(br, nbw, p.mg_nbw), bw_ = br - q1 * nbw;
+            const unsigned bd_ = fdiv(q1, nbh, p.mg_nbh), bh_ = q1 - bd_ * nbh;
+            q.b = (int)bb;
+            q.tw = (int)(bw_ * 4 + (in & 3)); q.th = (int)(bh_ * 4 + ((in >> 2) & 3)); q.td = (int)(bd_ * 2 + (in >> 4));
             return q;
         }
-        q.tw = t % p.ntw; t /= p.ntw;
-        q.th = t % p.nth; t /= p.nth;
-        q.td = t % p.ntd; q.b = t / p.ntd;
+        const unsigned q1 = fdiv(t, (unsigned)p.ntw, p.mg_ntw), q2 = fdiv(q1, (unsigned)p.nth, p.mg_nth), q3 = fdiv(q2, (unsigned)p.ntd, p.mg_ntd);
+        q.tw = (int)(t - q1 * (unsigned)p.ntw); q.th = (int)(q1 - q2 * (unsigned)p.nth); q.td = (int)(q2 - q3 * (unsigned)p.ntd); q.b = (int)q3;
         return q;
     };
     int cur_t = dyn ? dyn_first : tile_begin, nxt_t = cur_t;  // work-item indices (block-uniform)
@@ -339,10 +347,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gstage = 0;                                   // global stage counter: weight buffer = gstage & 1
 
+    int ut = 0, group = 0, slab = 0;                  // the unit inside its tile: ut = group * nslab + slab, carried along instead of divided out of u
     for (int u = 0; u < nunits; ++u) {
-        const int ut = u % upt, group = ut / p.nslab, slab = ut - group * p.nslab;
-        const int ut1 = (ut + 1 == upt) ? 0 : ut + 1;
-        const int group1 = ut1 / p.nslab, slab1 = ut1 - group1 * p.nslab;
+        int ut1 = ut + 1, group1 = group, slab1 = slab + 1;
+        if (slab1 == p.nslab) { slab1 = 0; ++group1; }
+        if (ut1 == upt) { ut1 = 0; group1 = 0; }
         bool next_unit = u + 1 < nunits;
         if (dyn) {
             // first unit of a tile: draw the ticket of the tile after it; last unit (>= one stage barrier later): read it
@@ -824,10 +833,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
         GFE_STAMP(5);
         GFE_FUZZ();
         if (!next_unit) break;
-        if (ut + 1 == upt) {
+        if (ut1 == 0) {
             if (dyn) { cur_t = nxt_t; cur = nxt; }
             else { cur_t += tile_stride; cur = decode(min(cur_t, ntiles - 1)); }
         }
+        ut = ut1; group = group1; slab = slab1;
     }
     finish();
 #endif
@@ -989,6 +999,12 @@ int conv_launch(const ConvParams& p, hipStream_t st) {
     q.sched = MC ? nullptr : conv_sched_slot(st);
     static const bool brick_on = !(getenv("GFE_CONV_BRICK") != nullptr && getenv("GFE_CONV_BRICK")[0] == '0');     // GFE_CONV_BRICK=0: tw-fastest order
     q.brick = (!MC && brick_on && p.ntw % 4 == 0 && p.nth % 4 == 0 && p.ntd % 2 == 0) ? 1 : 0;
+    {
+        const uint64_t per = (uint64_t)p.ntd * p.nth * p.ntw;
+        auto magic = [&](uint64_t d) -> unsigned { return (d >= 2 && (uint64_t)tiles * d < (1ull << 32)) ? (unsigned)((1ull << 32) / d) + 1u : 0u; };
+        q.mg_per = magic(per); q.mg_nbw = magic((uint64_t)p.ntw >> 2); q.mg_nbh = magic((uint64_t)p.nth >> 2);
+        q.mg_ntw = magic((uint64_t)p.ntw); q.mg_nth = magic((uint64_t)p.nth); q.mg_ntd = magic((uint64_t)p.ntd); q.mg_ncls = MC ? magic((uint64_t)p.ncls) : 0u;
+    }
     // the grid need not cover every CU: gfe_conv_reserve_cus(n) leaves n CUs to the kernels of another stream (with or without the ticket
     // scheduler: on a CU-masked stream -- gfe_stream_create_cu_mask -- blocks beyond the mask's CUs would only queue up for a second round)
     const int nblk = NBLK == 256 ? NBLK - conv_reserved_cus() : NBLK;

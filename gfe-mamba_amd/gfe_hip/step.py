@@ -189,8 +189,9 @@ class ClassifyStep:
 
     def train_step_pipelined(self, x, x_cat, x_num, y, x_next=None, graph_head=False):
         """One training step on (x, x_cat, x_num, y); if `x_next` (the next batch's volumes) is given, its generator forward is
-        enqueued on the caller's stream right away and overlaps this batch's head.  Returns this batch's loss (a tensor produced on
-        the head stream: `join()` -- or any device synchronisation -- before reading it or the parameters from another stream)."""
+        enqueued on the caller's stream right away and overlaps this batch's head.  Returns this batch's loss: produced on the head
+        stream, and the caller's stream is ordered behind the kernel that writes it; the PARAMETERS are only safe to read from another
+        stream after `join()` (or a device synchronisation)."""
         G = torch.cuda.current_stream()
         if getattr(self, "_head_stream", None) is None:
             if self.head_cus > 0:
@@ -218,10 +219,16 @@ class ClassifyStep:
         _, (mid_input, mid_output, pet), ev, _ = pf
         H.wait_stream(G)                                      # inputs, and everything else the caller queued before this call
         H.wait_event(ev)
+        # Batch k+1's generator goes to the caller's stream BEFORE this batch's head is enqueued (the head waits for the caller's stream only up
+        # to the line above).  In steady state the host runs a step ahead and the order of the two enqueues does not matter; right after a
+        # synchronisation it does: the head is ~450 launches = 6-8 ms of host time, and a generator enqueued behind them starts that much late
+        # (bench.py --steps 20: 748-759 volumes/s against 770-772 at --steps 100 on one box, profiles/r05/step_kw_headfirst.txt; with this order 783-790 at both, step_kw_genfirst_box*.txt).
+        nxt_pf = self._generate_async(x_next) if x_next is not None else None
         with torch.cuda.stream(H):
             for t in (x, x_cat, x_num, y, mid_input, mid_output, pet):
                 t.record_stream(H)                            # allocated on the caller's stream, read here
             self.head.train(); self.ft.train()
+            loss_ready = None
             if graph_head:
                 loss = self._head_step_graphed(x, x_cat, x_num, y, mid_input, mid_output, pet)
             else:
@@ -229,15 +236,20 @@ class ClassifyStep:
                 mid_feature = self.head(mid_input, mid_output)
                 pred = self.ft(x_cat, x_num, mid_feature, [x, pet])
                 loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
+                loss_ready = torch.cuda.Event()
+                loss_ready.record(H)
                 with side_wgrads():
                     loss.backward()
+            if loss_ready is None:
+                loss_ready = torch.cuda.Event()
+                loss_ready.record(H)
             self.opt.step(self.world_size, self.group)
             if os.environ.get("GFE_EXP_HEAD_SPIN"):            # experiment: a spinning kernel of that many clock cycles appended to the head's chain
                 torch.cuda._sleep(int(os.environ["GFE_EXP_HEAD_SPIN"]))
             self._head_done = torch.cuda.Event()
             self._head_done.record(H)
-        if x_next is not None:
-            self._prefetched = self._generate_async(x_next)   # batch k+1's generator, under batch k's head
+        self._prefetched = nxt_pf                             # batch k+1's generator, running under batch k's head
+        G.wait_event(loss_ready)                              # the loss may be read on the caller's stream (whose next generator is already enqueued)
         return loss.detach()
 
     def forward(self, x, x_cat, x_num, _before_head=None):

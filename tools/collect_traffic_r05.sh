@@ -16,5 +16,6 @@ bash $R/tools/pmc_attn.sh r05/attn_pmc attn_fwd attn_bwd_dkdv attn_bwd_dq > $O/a
 cd $R
 cp $O/prof_step/step_kernel_stats.csv $O/step_b8_kernel_stats.csv
 python3 $R/tools/summarise_profiles_r05.py $O $R
+cp $O/traffic_r05.json $R/profiles/r05/traffic_r05.json      # (the box's copy: the bench lines below cite the counters just taken)
 python3 $R/bench.py > $O/step_b8_bench.json 2> /dev/null
 python3 $R/bench.py --workload vit3d > $O/vit3d_b8_bench.json 2> /dev/null
