@@ -84,6 +84,7 @@ class ClassifyStep:
         env = os.environ.get("GFE_HEAD_CUS")
         self.head_cus = int(env) if env not in (None, "") else (HEAD_CUS_DEFAULT if head_cus is None else int(head_cus))
         self._gen_stream = None
+        self.trace = None                          # tools/step_events.py: a list that collects (generator start, end, head start, end) timing events per pipelined call
         self.all_params = list(head.parameters()) + list(ft.parameters())          # classify_mamba.py:57-61
         self.opt = FlatAdam(self.all_params, lr=lr, max_norm=max_norm)             # Adam(lr=1e-4) + per-parameter clip
         self.opt.force_collective = bool(force_collective)                         # all_reduce even in a one-rank group
@@ -106,10 +107,15 @@ class ClassifyStep:
         behind the current stream; returns (x, outputs, event recorded behind them, (version, address) of x)."""
         GS = self._gen_stream
         if GS is None:
+            if self.trace is not None:
+                g0 = torch.cuda.Event(enable_timing=True)
+                g0.record(torch.cuda.current_stream())
             with torch.no_grad():
                 outs = self.gen(x, output_vit_mid=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.trace is not None)
             ev.record(torch.cuda.current_stream())
+            if self.trace is not None:
+                self.trace.append(("gen", g0, ev))
             return x, outs, ev, (x._version, x.data_ptr())
         GS.wait_stream(torch.cuda.current_stream())
         old = lib().gfe_conv_reserve_cus(self.head_cus)            # the persistent conv kernels launch one block per CU of THIS stream
@@ -229,6 +235,9 @@ class ClassifyStep:
                 t.record_stream(H)                            # allocated on the caller's stream, read here
             self.head.train(); self.ft.train()
             loss_ready = None
+            if self.trace is not None:
+                h0 = torch.cuda.Event(enable_timing=True)
+                h0.record(H)
             if graph_head:
                 loss = self._head_step_graphed(x, x_cat, x_num, y, mid_input, mid_output, pet)
             else:
@@ -246,8 +255,10 @@ class ClassifyStep:
             self.opt.step(self.world_size, self.group)
             if os.environ.get("GFE_EXP_HEAD_SPIN"):            # experiment: a spinning kernel of that many clock cycles appended to the head's chain
                 torch.cuda._sleep(int(os.environ["GFE_EXP_HEAD_SPIN"]))
-            self._head_done = torch.cuda.Event()
+            self._head_done = torch.cuda.Event(enable_timing=self.trace is not None)
             self._head_done.record(H)
+            if self.trace is not None:
+                self.trace.append(("head", h0, self._head_done))
         self._prefetched = nxt_pf                             # batch k+1's generator, running under batch k's head
         G.wait_event(loss_ready)                              # the loss may be read on the caller's stream (whose next generator is already enqueued)
         return loss.detach()
