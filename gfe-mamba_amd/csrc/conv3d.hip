@@ -871,8 +871,9 @@ __global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict
         o[k] = w[k] * sc;
         acc = fmaf(w[k], t, acc);
     }
-    *reinterpret_cast<uint4*>(wout + ((size_t)b * nrows + rowi) * 32 + chunk * 8) =
-        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    if (wout)                                                          // (NULL: only the bias fold is wanted -- the caller builds its weights itself)
+        *reinterpret_cast<uint4*>(wout + ((size_t)b * nrows + rowi) * 32 + chunk * 8) =
+            make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
     acc += __shfl_xor(acc, 1, 64);                                     // the 4 chunks of a row sit in adjacent lanes
     acc += __shfl_xor(acc, 2, 64);
     if (chunk == 0) T[((size_t)b * nslab + sl) * ntaps * CoutPad + tr] = acc;
@@ -1047,7 +1048,7 @@ int gfe_conv3d_cout_pad(int64_t Cout) {
 
 int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, const float* gn_shift, void* w_out, float* T_ws,
                               float* bias_tab, const int8_t* tap_offsets_dev, int64_t B, int64_t Cin, int64_t Cout, int ntaps, void* stream) {
-    GFE_REQUIRE(w_packed_f32 && gn_scale && gn_shift && w_out && T_ws && bias_tab && tap_offsets_dev, GFE_ERR_NULL);
+    GFE_REQUIRE(w_packed_f32 && gn_scale && gn_shift && T_ws && bias_tab && tap_offsets_dev, GFE_ERR_NULL);      // (w_out may be NULL: bias table only)
     GFE_REQUIRE(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
     const int cp = gfe_conv3d_cout_pad(Cout), nslab = (int)ceil_div(Cin, 32);
     const int NT = (cp < 64 ? cp : 64) / 16;

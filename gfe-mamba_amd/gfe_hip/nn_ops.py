@@ -70,12 +70,13 @@ def taps_on_device(taps, device):
     return _TAPS_DEV[key]
 
 
-def fold_groupnorm(w_packed_f32, scale, shift, taps, cin, cout):
-    """GroupNorm affine (scale, shift: (B, Cin) f32) folded into the conv: per-sample bf16 weights + boundary-class bias table."""
+def fold_groupnorm(w_packed_f32, scale, shift, taps, cin, cout, weights=True):
+    """GroupNorm affine (scale, shift: (B, Cin) f32) folded into the conv: per-sample bf16 weights + boundary-class bias table
+    (weights=False: the table alone, for a caller that builds its per-sample weights itself)."""
     B = scale.shape[0]
     cp = cout_pad(cout)
     dev = scale.device
-    wout = torch.empty((B,) + tuple(w_packed_f32.shape), dtype=BF16, device=dev)
+    wout = torch.empty((B,) + tuple(w_packed_f32.shape), dtype=BF16, device=dev) if weights else None
     T = torch.empty((B, (cin + 31) // 32, len(taps), cp), dtype=torch.float32, device=dev)      # per-slab partials of the bias fold
     tab = torch.empty((B, 64, cp), dtype=torch.float32, device=dev)
     call("gfe_conv3d_fold_groupnorm", ptr(w_packed_f32), ptr(scale), ptr(shift), ptr(wout), ptr(T), ptr(tab),
@@ -152,8 +153,8 @@ def conv_stat_slots(B, D, H, W, cout):
 
 
 def new_gn_partials(B, nblk, C, device):
-    """Zeroed workspace a producer fills with the GroupNorm partials of its output (gfe_hip.h: stats_ws): the conv kernel
-    writes only the slots where one of its persistent blocks changes sample / ends, the rest must read as zero."""
+    """Zeroed workspace a producer fills with the GroupNorm partials of its output (gfe_hip.h: stats_ws): producers that do not write every
+    slot (the transposed conv's two tile grids, callers that hand several launches one workspace) rely on the rest reading as zero."""
     return torch.zeros((B, nblk, 2, C), dtype=torch.float32, device=device)
 
 
@@ -181,7 +182,11 @@ def conv_igemm(x, w_packed, taps, cout, bias=None, bias_tab=None, res=None, relu
     if stats is True and cout >= 64 and cout % 64:
         stats = None                 # 64-channel tiles write 8-channel sums: other widths take the separate statistics pass
     if stats is True:
-        ws = new_gn_partials(B, conv_stat_slots(B, D, H, W, cout), cout, x.device)
+        # a stride-1 launch writes EVERY slot it is given -- one per tile of the sample, all channels, a plain store when the block leaves the tile
+        # (conv3d.hip, "flush") -- so the workspace needs no zero fill (a 5-10 us launch in front of six convs of a generator pass);
+        # tools/poison_probe.py screens exactly this kind of claim
+        nslot = conv_stat_slots(B, D, H, W, cout)
+        ws = torch.empty((B, nslot, 2, cout), dtype=torch.float32, device=x.device) if transposed is None else new_gn_partials(B, nslot, cout, x.device)
     elif stats is not None:
         ws, slot0 = stats
     call("gfe_conv3d_igemm", ptr(x), ptr(w_packed), wstride, ptr(bias), ptr(bias_tab), ptr(res), ptr(out),

@@ -136,7 +136,7 @@ class ResNetBlock(nn.Module):
         if cin % 32:
             weff = F.pad(weff, (0, nslab * 32 - cin))
         weff = weff.view(27, cp, B, nslab, 32).permute(2, 3, 0, 1, 4).contiguous().to(K.BF16)  # per-sample packed weights (B, nslab, 27, cp, 32)
-        _, tab = K.fold_groupnorm(w32, scale, scale * b1 + shift, K.CONV3_TAPS, c, cout)       # only the bias table is used
+        _, tab = K.fold_groupnorm(w32, scale, scale * b1 + shift, K.CONV3_TAPS, c, cout, weights=False)       # only the bias table is wanted
         return K.conv_igemm(x, weff, K.CONV3_TAPS, cout, bias_tab=tab, relu=sc.relu, stats=True)
 
     def forward(self, x, out1=None):

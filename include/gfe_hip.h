@@ -190,7 +190,7 @@ int gfe_convt3d_k3s2_fused(const void* x, const void* w_packed, const int64_t* c
 
 /* Folds GroupNorm(x) = scale[b,c]*x + shift[b,c] (from gfe_groupnorm_scale_shift) into the convolution that consumes it
  * (create_conv order 'g' before 'c', buildingblocks.py:55-67; zero padding is applied AFTER the norm):
- *   w_out[b] = bf16(w_packed_f32 * scale[b, cin])                              (B sets in the gfe_conv3d_igemm layout)
+ *   w_out[b] = bf16(w_packed_f32 * scale[b, cin])                              (B sets in the gfe_conv3d_igemm layout; NULL: the bias table alone)
  *   bias_tab[b][class][co] = sum over taps inside the volume for that boundary class of sum_ci W[t][co][ci]*shift[b,ci]
  * w_packed_f32: the packed layout in f32.  T_ws: (B, ceil(Cin / 32), ntaps, CoutPad) f32 workspace (per-slab partials, summed in a fixed
  * order: the tables are bit-reproducible).  tap_offsets_dev: DEVICE int8 ntaps x 3. */
