@@ -431,9 +431,62 @@ __global__ __launch_bounds__(256) void lift_gn_affine_kernel(const double* __res
     }
 }
 
+// conv2(GroupNorm(conv1(x))) as ONE convolution of x (ResNetBlock._conv2_through_lift, buildingblocks.py:38-67 restated): the operands of the
+// per-sample effective-weight product and its result's re-layout, one launch each where torch spent seven (they sit between two convs on the
+// generator's stream, which bounds the step).  Same f32 operations in the same order as the torch expressions they replace (no contraction).
+//   rhs[c][b * Cin + i] = scale[b][c] * w1[c][i]           shift2[b][c] = scale[b][c] * b1[c] + shift[b][c]
+__global__ __launch_bounds__(256) void lift_fold_prep_kernel(const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, float* __restrict__ rhs, float* __restrict__ shift2, int B, int C, int Cin) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)C * B * Cin;
+    if (idx < n) {
+        const int c = (int)(idx / ((int64_t)B * Cin)), r = (int)(idx - (int64_t)c * B * Cin), b = r / Cin, i = r - b * Cin;
+        rhs[idx] = __fmul_rn(scale[(size_t)b * C + c], w1[(size_t)c * Cin + i]);
+    }
+    if (idx < (int64_t)B * C) {
+        // `scale * b1 + shift` is two roundings in the expression this replaces; the library is built with -ffp-contract=fast and hipcc contracts
+        // __fmul_rn / __fadd_rn all the same, so the product is made opaque
+        float m;
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(m) : "v"(scale[idx]), "v"(b1[idx % C]));
+        shift2[idx] = m + shift[idx];
+    }
+}
+//   out[b][slab][tap][o][k] = bf16(weff[tap * cp + o][b * Cin + slab * 32 + k])   (k past Cin: 0) -- the packed per-sample weight sets of gfe_conv3d_igemm
+__global__ __launch_bounds__(256) void lift_fold_pack_kernel(const float* __restrict__ weff, bf16_t* __restrict__ out, int B, int Cin, int cp, int nslab, int ntaps) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)B * nslab * ntaps * cp * 4;
+    if (idx >= n) return;
+    const int chunk = (int)(idx & 3);
+    int64_t r = idx >> 2;
+    const int o = (int)(r % cp); r /= cp;
+    const int tap = (int)(r % ntaps); r /= ntaps;
+    const int slab = (int)(r % nslab), b = (int)(r / nslab);
+    const int i0 = slab * 32 + chunk * 8;
+    const float* src = weff + ((size_t)tap * cp + o) * ((size_t)B * Cin) + (size_t)b * Cin + i0;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = i0 + k < Cin ? src[k] : 0.f;
+    *reinterpret_cast<uint4*>(out + (idx >> 2) * 32 + chunk * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
 }  // namespace
 
 extern "C" {
+
+int gfe_lift_fold_prep(const float* scale, const float* shift, const float* w1, const float* b1, float* rhs, float* shift2,
+                       int64_t B, int64_t C, int64_t Cin, void* stream) {
+    GFE_REQUIRE(scale && shift && w1 && b1 && rhs && shift2, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && C > 0 && Cin > 0 && B * C * Cin < 0x7fffffffLL, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(lift_fold_prep_kernel, dim3((unsigned)ceil_div(C * B * Cin, 256)), dim3(256), 0, (hipStream_t)stream, scale, shift, w1, b1, rhs, shift2, (int)B, (int)C, (int)Cin);
+    return gfe_launch_status();
+}
+
+int gfe_lift_fold_pack(const float* weff, void* w_out, int64_t B, int64_t Cin, int64_t cout_pad, int ntaps, void* stream) {
+    GFE_REQUIRE(weff && w_out, GFE_ERR_NULL);
+    GFE_REQUIRE(B > 0 && Cin > 0 && cout_pad > 0 && ntaps >= 1 && ntaps <= 27, GFE_ERR_SHAPE);
+    const int64_t nslab = ceil_div(Cin, 32), n = B * nslab * ntaps * cout_pad * 4;
+    GFE_REQUIRE(n < 0x7fffffff00LL, GFE_ERR_SHAPE);
+    hipLaunchKernelGGL(lift_fold_pack_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, weff, (bf16_t*)w_out, (int)B, (int)Cin, (int)cout_pad, (int)nslab, ntaps);
+    return gfe_launch_status();
+}
 
 int gfe_groupnorm_plan(int64_t S, int* vox_per_block, int* nblk) {
     int64_t vpb = ceil_div(S, 96);

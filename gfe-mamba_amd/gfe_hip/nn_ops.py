@@ -84,6 +84,24 @@ def fold_groupnorm(w_packed_f32, scale, shift, taps, cin, cout, weights=True):
     return wout, tab
 
 
+def lift_fold_prep(scale, shift, w1, b1):
+    """Operands of ResNetBlock._conv2_through_lift in one launch: rhs (C, B*Cin) = scale_b[c] * w1[c][i], shift2 (B, C) = scale * b1 + shift."""
+    B, C = scale.shape
+    cin = w1.shape[1]
+    rhs = torch.empty((C, B * cin), dtype=torch.float32, device=scale.device)
+    shift2 = torch.empty((B, C), dtype=torch.float32, device=scale.device)
+    call("gfe_lift_fold_prep", ptr(scale), ptr(shift), ptr(w1), ptr(b1), ptr(rhs), ptr(shift2), B, C, cin, stream())
+    return rhs, shift2
+
+
+def lift_fold_pack(weff, B, cin, cp, ntaps=27):
+    """weff (ntaps*cp, B*Cin) f32 -> (B, nslab, ntaps, cp, 32) bf16: per-sample weight sets in conv_igemm's layout, one launch."""
+    assert weff.dtype == torch.float32 and weff.is_contiguous() and tuple(weff.shape) == (ntaps * cp, B * cin)
+    out = torch.empty((B, (cin + 31) // 32, ntaps, cp, 32), dtype=BF16, device=weff.device)
+    call("gfe_lift_fold_pack", ptr(weff), ptr(out), B, cin, cp, ntaps, stream())
+    return out
+
+
 def pack_conv1(weight):
     """nn.Conv3d weight (Cout, Cin, 1, 1, 1) -> packed single tap."""
     cout, cin = weight.shape[:2]

@@ -130,13 +130,11 @@ class ResNetBlock(nn.Module):
                                  _f32(c1.weight).view(c, cin), _f32(c1.bias), _f32(gn.weight), _f32(gn.bias)))(K.pack_conv3(conv.weight, torch.float32)))
         scale, shift = K.groupnorm_scale_shift(r, g, b, gn.num_groups, gn.eps)                 # (B, C) from r's partials
         B, cp, nslab = scale.shape[0], w32.shape[2], (cin + 31) // 32
-        # W_eff of all samples as ONE f32 MFMA GEMM (gfe_gemm_f32): (27*cp, C) . [s_b (.) W1]_b (C, B*Cin)
-        rhs = (scale.t().unsqueeze(2) * w1.unsqueeze(1)).reshape(c, B * cin)
-        weff = K.gemm_f32(w2m, False, rhs, True).view(27 * cp, B, cin)                           # (27*cp, B, Cin)
-        if cin % 32:
-            weff = F.pad(weff, (0, nslab * 32 - cin))
-        weff = weff.view(27, cp, B, nslab, 32).permute(2, 3, 0, 1, 4).contiguous().to(K.BF16)  # per-sample packed weights (B, nslab, 27, cp, 32)
-        _, tab = K.fold_groupnorm(w32, scale, scale * b1 + shift, K.CONV3_TAPS, c, cout, weights=False)       # only the bias table is wanted
+        # W_eff of all samples as ONE f32 MFMA GEMM (gfe_gemm_f32): (27*cp, C) . [s_b (.) W1]_b (C, B*Cin); its operands and the re-layout
+        # of its result (per-sample packed bf16 weight sets (B, nslab, 27, cp, 32)) are one launch each (gfe_lift_fold_prep / _pack)
+        rhs, shift2 = K.lift_fold_prep(scale, shift, w1, b1)
+        weff = K.lift_fold_pack(K.gemm_f32(w2m, False, rhs, True), B, cin, cp)
+        _, tab = K.fold_groupnorm(w32, scale, shift2, K.CONV3_TAPS, c, cout, weights=False)       # only the bias table is wanted
         return K.conv_igemm(x, weff, K.CONV3_TAPS, cout, bias_tab=tab, relu=sc.relu, stats=True)
 
     def forward(self, x, out1=None):

@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 46
+#define GFE_ABI_VERSION 47
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -273,6 +273,14 @@ int gfe_gemm_f32(const float* A, int64_t lda, int a_tr, const float* B, int64_t 
  * K between them and sum their tiles in a fixed tree through LDS -- split_k / splitk_ws are then ignored (no reduction launch, nothing to
  * allocate).  0: the staged kernel with the caller's split_k.  Same sums either way up to f32 summation order; both are bit-reproducible. */
 int gfe_gemm_f32_inblock(const float* A, int64_t lda, int a_tr, const float* B, int64_t ldb, int b_tr, int64_t M, int64_t N, int64_t K);
+
+/* conv2(GroupNorm(conv1(x))) of a ResNetBlock (buildingblocks.py:38-67) as one convolution of x: operands and result layout of the per-sample
+ * effective-weight product W_eff = W2 . diag(scale_b) . W1 (one gfe_gemm_f32 for all samples).
+ *   prep: rhs[c][b * Cin + i] = scale[b][c] * w1[c][i]   (C x B*Cin),   shift2[b][c] = scale[b][c] * b1[c] + shift[b][c]
+ *   pack: w_out[b][slab][tap][o][k] = bf16(weff[tap * cout_pad + o][b * Cin + slab * 32 + k])  (k past Cin: 0): B weight sets in gfe_conv3d_igemm's layout */
+int gfe_lift_fold_prep(const float* scale, const float* shift, const float* w1, const float* b1, float* rhs, float* shift2,
+                       int64_t B, int64_t C, int64_t Cin, void* stream);
+int gfe_lift_fold_pack(const float* weff, void* w_out, int64_t B, int64_t Cin, int64_t cout_pad, int ntaps, void* stream);
 
 /* out[b][c][r] = in[b][r][c], bf16 (operand re-layout for dgrad / wgrad). */
 int gfe_transpose_bf16(const void* in, void* out, int64_t batch, int64_t R, int64_t Cc, int64_t ldi, int64_t ldo, void* stream);

@@ -780,6 +780,26 @@ def test_encoder_block_conv2_through_the_lift_matches_torch(cin, shape):
     assert rel_err(out, ref) < 2e-2
 
 
+@pytest.mark.parametrize("B,C,cin,cp", [(8, 128, 64, 128), (3, 256, 128, 256), (2, 48, 24, 64)])
+def test_lift_fold_prep_and_pack_equal_the_torch_expressions_bit_for_bit(B, C, cin, cp):
+    """gfe_lift_fold_prep / gfe_lift_fold_pack (the operands and the result layout of conv2-through-lift's effective-weight product) against
+    the torch expressions they replaced: same f32 products, `scale * b1 + shift` as two roundings, the same bf16 rounding; a channel count that
+    is not a multiple of 32 pads its last slab with zeros."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(B * C)
+    scale, shift = torch.randn(B, C, generator=g).to(DEV), torch.randn(B, C, generator=g).to(DEV)
+    w1, b1 = torch.randn(C, cin, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    rhs, shift2 = K.lift_fold_prep(scale, shift, w1, b1)
+    assert torch.equal(rhs, (scale.t().unsqueeze(2) * w1.unsqueeze(1)).reshape(C, B * cin)) and torch.equal(shift2, scale * b1 + shift)
+    weff = torch.randn(27 * cp, B * cin, generator=g).to(DEV)
+    nslab = (cin + 31) // 32
+    ref = weff.view(27 * cp, B, cin)
+    if cin % 32:
+        ref = F.pad(ref, (0, nslab * 32 - cin))
+    ref = ref.view(27, cp, B, nslab, 32).permute(2, 3, 0, 1, 4).contiguous().to(BF)
+    assert torch.equal(K.lift_fold_pack(weff, B, cin, cp), ref)
+
+
 def test_final_conv_fused_into_the_last_conv_matches_the_separate_kernel():
     """Real-width generator at 32^3: `pet` from the last decoder conv with final_conv in its epilogue (default) against the path that
     stores the 64-channel tensor and runs gfe_conv_out1 on it (taken when the decoder features are requested)."""
