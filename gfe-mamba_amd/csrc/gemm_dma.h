@@ -9,6 +9,9 @@ struct GemmDmaArgs {
     int64_t lda, ldb, ldc, ldres;
     int M, N, K;
     int out_f32, res_f32, act;
+    // K cut into nsplit equal ranges (K % (64 * nsplit) == 0), range z's tile stored RAW (f32, no bias / activation / residual) to part[z][M][N];
+    // the caller's fixed-order reduction finishes the product (gemm.hip, splitk_reduce_kernel).  nsplit <= 1: part is ignored.
+    int nsplit = 1; float* part = nullptr;
 };
 
 // true: shape / alignment / size limits of the DMA kernel hold (gemm_dma_launch may be called)

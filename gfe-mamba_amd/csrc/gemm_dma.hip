@@ -57,6 +57,9 @@ struct DmaParams {
     unsigned c_bytes, res_bytes;              // M * ld * element size (num_records of the store / residual descriptors)
     int M, N, K, nk, tiles_n, ntiles;
     int res_f32, act;
+    // split-K (the generator ViT's patch embedding, vit.py:95-100: 200 x 512 x 147 456 -- a weight-streaming product): work item t = (range z, tile)
+    // with the tile innermost, nk = k-steps per RANGE; a range's tile goes raw to part + z * M * N (f32), summed in range order afterwards
+    int tiles_mn; float* part; unsigned part_bytes;
 };
 
 __device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
@@ -156,17 +159,19 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
             b_row[i] = g * Gm::G + (r >> 2) * (4 * NJ) + j * 4 + (r & 3);                    // the source row it holds (epilogue layout, see above)
         }
         unsigned pa[DA_PIECES], pb[DB_PIECES];
-        int pf_t = t_first, pf_k = 0;
+        int pf_t = t_first, pf_k = 0, pf_kbase = 0;
         auto issue_unit = [&](int slot) {                              // the cursor's unit -> ring slot, cursor advances; nothing once the block's units are out
             if (pf_t >= t_end) return;
             if (pf_k == 0) {
-                const int tm = pf_t / p.tiles_n, tn = pf_t - tm * p.tiles_n;
+                const int z = pf_t / p.tiles_mn, tmn = pf_t - z * p.tiles_mn;
+                const int tm = tmn / p.tiles_n, tn = tmn - tm * p.tiles_n;
+                pf_kbase = z * nk;
 #pragma unroll
                 for (int i = 0; i < DA_PIECES; ++i) pa[i] = (unsigned)min(tm * DBM + 8 * (lw + DLOADERS * i) + (lane >> 3), p.M - 1) * p.lda2 + chunk_b;
 #pragma unroll
                 for (int i = 0; i < DB_PIECES; ++i) pb[i] = (unsigned)min(tn * DBN + b_row[i], p.N - 1) * p.ldb2 + chunk_b;
             }
-            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)pf_k * (DBK * 2));          // ("s" operands must be provably uniform)
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(pf_kbase + pf_k) * (DBK * 2));          // ("s" operands must be provably uniform)
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * DSTAGE + (unsigned)lw * 1024);
 #if !defined(GFE_GDMA_EXP_NODMA)           // timing experiment only (wrong results): no staging traffic at all
 #pragma unroll
@@ -213,9 +218,27 @@ __global__ __launch_bounds__(DTHREADS, 3) void gemm_dma_kernel(const DmaParams p
     // columns per i; it runs inside the NEXT tile's first read interval, i.e. beside the SIMD partner's matrix interval.
     f32x4 acc[4][NJ];
     auto epilogue = [&](int t) {
-        const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+        const int z = t / p.tiles_mn, tmn = t - z * p.tiles_mn;
+        const int tm = tmn / p.tiles_n, tn = tmn - tm * p.tiles_n;
         constexpr int NV = 4 * NJ;                                   // consecutive output columns of this lane: 16 or 8
         const int nb = tn * DBN + wn * Gm::G + lq * NV;
+        if constexpr (OUT_F32) {
+            if (p.part) {
+                // a K range's raw tile: rows >= M fall outside THIS range's num_records (they would land in the next range's slab otherwise)
+                const __amdgpu_buffer_rsrc_t rsP = make_rsrc_b(p.part + (size_t)z * p.M * p.N, p.part_bytes);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned m = (unsigned)(tm * DBM + wm * 64 + i * 16 + lr);
+                    const unsigned co = m * ((unsigned)p.N * 4u) + (unsigned)nb * 4;
+#pragma unroll
+                    for (int q = 0; q < NJ; ++q) {
+                        const v4u_t d = {__float_as_uint(acc[i][q][0]), __float_as_uint(acc[i][q][1]), __float_as_uint(acc[i][q][2]), __float_as_uint(acc[i][q][3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rsP, co + 16 * q, 0, 0);
+                    }
+                }
+                return;
+            }
+        }
         float bv[NV];
         if (p.bias) {
 #pragma unroll
@@ -391,6 +414,12 @@ bool gemm_dma_usable(const GemmDmaArgs& a) {
     // wants >= 2 tiles per CU) reads its weight panel once per 256 rows here, twice per 128-row tile there: the generator ViT's un-patchify
     // projection (200 x 147 456 x 512, vit.py:91-95) 104 -> ~50 us, the generator 9.61-9.68 -> 9.56 ms (GFE_GEMM_DMA_MINM=512: the old rule).
     static const int min_m = getenv("GFE_GEMM_DMA_MINM") ? atoi(getenv("GFE_GEMM_DMA_MINM")) : 129;
+    if (a.nsplit > 1) {
+        // the split form is for callers that ask for it (a fixed cut of K whatever M is: the sum order of a row must not depend on the batch it rides in)
+        if (!a.part || !a.out_f32 || a.N % DBN != 0 || a.K % (DBK * a.nsplit) != 0 || (int64_t)a.M * a.N * 4 > 0x7fffffffLL) return false;
+        if (a.lda % 8 || a.ldb % 8 || (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.part) % 16)) return false;
+        return (int64_t)a.M * a.lda * 2 <= 0x7fffffffLL && (int64_t)a.N * a.ldb * 2 <= 0x7fffffffLL;
+    }
     if (a.M < min_m || a.N % DBN != 0 || a.K % DBK != 0 || a.K < DBK) return false;
     if (dma_shape(a) == 0) return false;
     if (a.lda % 8 || a.ldb % 8) return false;
@@ -416,7 +445,8 @@ extern "C" int gfe_gemm_dma_launches(void) { return g_dma_launches; }
 template <bool OUT_F32, int NJ>
 static int dma_launch_t(DmaParams& p, const GemmDmaArgs& a, hipStream_t st) {
     typedef Geo<NJ> Gm;
-    p.ntiles = (int)ceil_div(a.M, Gm::BM) * p.tiles_n;
+    p.tiles_mn = (int)ceil_div(a.M, Gm::BM) * p.tiles_n;
+    p.ntiles = p.tiles_mn * (p.part ? a.nsplit : 1);
     const int ncu = dma_num_cus();
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     constexpr size_t lds = (size_t)Gm::RING * Gm::STAGE;
@@ -436,10 +466,12 @@ int gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
     // the last row may be shorter than ld: num_records = bytes up to the end of row M - 1's N columns
     p.c_bytes = (unsigned)((int64_t)(a.M - 1) * a.ldc * esz + (int64_t)a.N * esz);
     p.res_bytes = a.res ? (unsigned)((int64_t)(a.M - 1) * a.ldres * rsz + (int64_t)a.N * rsz) : 0u;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.nk = a.K / DBK;
+    const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.nk = a.K / DBK / nsplit;
     p.tiles_n = a.N / DBN;
     p.res_f32 = a.res_f32; p.act = a.act;
-    const int nj = dma_shape(a);
+    p.part = nsplit > 1 ? a.part : nullptr; p.part_bytes = (unsigned)((int64_t)a.M * a.N * 4);
+    const int nj = nsplit > 1 ? 4 : dma_shape(a);
     if (nj == 4) return a.out_f32 ? dma_launch_t<true, 4>(p, a, st) : dma_launch_t<false, 4>(p, a, st);
     return a.out_f32 ? dma_launch_t<true, 2>(p, a, st) : dma_launch_t<false, 2>(p, a, st);
 }
