@@ -253,6 +253,11 @@ class ClassifyStep:
                 loss_ready = torch.cuda.Event()
                 loss_ready.record(H)
             self.opt.step(self.world_size, self.group)
+            if os.environ.get("GFE_EXP_HEAD_LAUNCHES"):        # experiment: that many extra one-element launches on the head's stream (what does a LAUNCH there cost the step?)
+                if getattr(self, "_exp_tiny", None) is None:
+                    self._exp_tiny = torch.zeros(1, device=x.device)
+                for _ in range(int(os.environ["GFE_EXP_HEAD_LAUNCHES"])):
+                    self._exp_tiny.add_(1.0)
             if os.environ.get("GFE_EXP_HEAD_SPIN"):            # experiment: a spinning kernel of that many clock cycles appended to the head's chain
                 torch.cuda._sleep(int(os.environ["GFE_EXP_HEAD_SPIN"]))
             self._head_done = torch.cuda.Event(enable_timing=self.trace is not None)
