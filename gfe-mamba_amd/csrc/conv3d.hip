@@ -884,31 +884,31 @@ __global__ __launch_bounds__(256) void fold_scale_kernel(const float* __restrict
 // four quarters together, and parked in LDS; every thread then builds 16 of the row's 64 classes from them.  (Round 2 ran one 64-thread
 // block per sample with 27 x nslab dependent loads and 64 x 27 adds per thread: 53 us a launch, nine launches per step on the critical
 // stream; same sums in the same order here, so the tables are bit-identical.)
-__global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict__ T, float* __restrict__ tab, const int8_t* __restrict__ taps,
-                                                        int ntaps, int CoutPad, int NT, int nslab) {
+__global__ __launch_bounds__(1024) void fold_bias_kernel(const float* __restrict__ T, float* __restrict__ tab, const int8_t* __restrict__ taps,
+                                                         int ntaps, int CoutPad, int NT, int nslab) {
+    // 64 packed rows x 16 thread groups (round 5: 4 groups of 256 threads took 12-13 us a launch, nine launches per generator pass on the stream that bounds
+    // the step -- each thread waited for 7 x nslab loads and then walked 16 classes x 27 taps; now <= 2 x nslab loads and 4 classes per thread)
     __shared__ float stv[27][64];
     __shared__ int sneed[27];
-    const int b = blockIdx.y, rl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int b = blockIdx.y, rl = threadIdx.x & 63, q = threadIdx.x >> 6;       // q: 0..15
     const int rho = blockIdx.x * 64 + rl;                    // packed row
     const bool live = rho < CoutPad;
-    // a quarter's <= 7 taps x nslab partials: every load in flight before the first add (as a loop nest this was 7 x nslab dependent round
-    // trips, most of the launch's 14-16 us); the slabs are still added in slab order, one tap at a time: the same sums as before
     {
         constexpr int MAXS = 8;
         const bool fits = nslab <= MAXS;
-        float v[7][MAXS];
+        float v[2][MAXS];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int t = q + 4 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int t = q + 16 * i;
 #pragma unroll
             for (int sl = 0; sl < MAXS; ++sl)
                 v[i][sl] = (fits && t < 27 && t < ntaps && live && sl < nslab) ? T[(((size_t)b * nslab + sl) * ntaps + t) * CoutPad + rho] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int t = q + 4 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int t = q + 16 * i;
             if (t >= 27) continue;
-            float a = 0.f;
+            float a = 0.f;                                   // the slabs in slab order: the same sums as before
             if (fits) {
 #pragma unroll
                 for (int sl = 0; sl < MAXS; ++sl) { if (sl < nslab) a += v[i][sl]; }
@@ -938,10 +938,12 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
     // packed row -> channel (same permutation as the weight packing)
     const int g = rho / (NT * 16), r = rho - g * (NT * 16);
     const int ch = g * NT * 16 + ((r >> 2) & 3) * 4 * NT + (r >> 4) * 4 + (r & 3);
-    for (int cls = 16 * q; cls < 16 * q + 16; ++cls) {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int cls = 4 * q + ci;
         float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
+        for (int t = 0; t < 27; ++t) {                       // the taps in tap order: the same sums as before
             if (t < ntaps && !(cls & need[t])) acc += tv[t];
         }
         tab[((size_t)b * 64 + cls) * CoutPad + ch] = acc;
@@ -1055,7 +1057,7 @@ int gfe_conv3d_fold_groupnorm(const float* w_packed_f32, const float* gn_scale, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fold_scale_kernel, dim3((unsigned)ceil_div((int64_t)nslab * ntaps * cp * 4, 256), (unsigned)B), dim3(256), 0, st,
                        w_packed_f32, gn_scale, gn_shift, (bf16_t*)w_out, T_ws, nslab, ntaps, cp, (int)Cin);
-    hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)cp, 64), (unsigned)B), dim3(256), 0, st,
+    hipLaunchKernelGGL(fold_bias_kernel, dim3((unsigned)ceil_div((int64_t)cp, 64), (unsigned)B), dim3(1024), 0, st,
                        T_ws, bias_tab, tap_offsets_dev, ntaps, cp, NT, nslab);
     return gfe_launch_status();
 }

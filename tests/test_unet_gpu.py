@@ -49,12 +49,13 @@ def test_gemm_epilogues_and_splitk():
     assert torch.equal(K.cast(f, BF), f.to(BF)) and torch.equal(K.cast(f.to(BF), torch.float32), f.to(BF).float())
 
 
-def test_gemm_weight_streaming_split_k_on_the_dma_main_loop():
-    """K >= 16 384 with an explicit split (the generator ViT's patch embedding, vit.py:95-100: 25 rows per volume x 147 456 -> 512): the K
-    ranges' tiles run on the persistent LDS-DMA main loop for ANY row count (gemm.hip), the fixed-order reduction adds bias.  Against f64; and a
-    row's result must not depend on how many other rows ride along (batch 1 = 25 rows, batch 8 = 200: bit for bit)."""
+def test_gemm_weight_streaming_split_k_on_the_dma_main_loop(monkeypatch):
+    """The opt-in path GFE_GEMM_DMA_SPLITK=1: K >= 16 384 with an explicit split (the generator ViT's patch embedding, vit.py:95-100: 25 rows per
+    volume x 147 456 -> 512): the K ranges' tiles run on the persistent LDS-DMA main loop for ANY row count (gemm.hip), the fixed-order reduction adds
+    bias.  Against f64; and a row's result must not depend on how many other rows ride along (batch 1 = 25 rows, batch 8 = 200: bit for bit)."""
     from gfe_hip import nn_ops as K
     import gfe_hip
+    monkeypatch.setenv("GFE_GEMM_DMA_SPLITK", "1")
     g = torch.Generator().manual_seed(11)
     Kd, N = 64 * 64 * 9, 512
     a = torch.randn(200, Kd, generator=g).to(BF).to(DEV)
