@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/step_b8_bench.json 2> /dev/null
+python3 $R/bench.py --steps 20 --warmup 5 > $O/step_b8_bench.json 2> /dev/null                      # (the driver's arguments)
 python3 $R/bench.py --no-pipeline > $O/step_b8_serial_bench.json 2> /dev/null
 python3 $R/bench.py --workload gen128 > $O/gen128_b2_bench.json 2> /dev/null
 python3 $R/bench.py --workload vit3d > $O/vit3d_b8_bench.json 2> /dev/null
