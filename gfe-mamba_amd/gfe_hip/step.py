@@ -241,18 +241,24 @@ class ClassifyStep:
             if graph_head:
                 loss = self._head_step_graphed(x, x_cat, x_num, y, mid_input, mid_output, pet)
             else:
-                self.opt.zero_grad()
-                mid_feature = self.head(mid_input, mid_output)
-                pred = self.ft(x_cat, x_num, mid_feature, [x, pet])
-                loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
+                part = os.environ.get("GFE_EXP_HEAD_PART", "all")        # experiment (tools/run_r05_head_parts.sh): what each part of the head costs the pipelined step
+                if part != "none":
+                    self.opt.zero_grad()
+                    mid_feature = self.head(mid_input, mid_output)
+                    pred = self.ft(x_cat, x_num, mid_feature, [x, pet])
+                    loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
+                else:
+                    loss = torch.zeros((), device=x.device)
                 loss_ready = torch.cuda.Event()
                 loss_ready.record(H)
-                with side_wgrads():
-                    loss.backward()
+                if part in ("all", "fwdbwd"):
+                    with side_wgrads():
+                        loss.backward()
             if loss_ready is None:
                 loss_ready = torch.cuda.Event()
                 loss_ready.record(H)
-            self.opt.step(self.world_size, self.group)
+            if graph_head or os.environ.get("GFE_EXP_HEAD_PART", "all") == "all":
+                self.opt.step(self.world_size, self.group)
             if os.environ.get("GFE_EXP_HEAD_LAUNCHES"):        # experiment: that many extra one-element launches on the head's stream (what does a LAUNCH there cost the step?)
                 if getattr(self, "_exp_tiny", None) is None:
                     self._exp_tiny = torch.zeros(1, device=x.device)
