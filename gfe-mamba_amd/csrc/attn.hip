@@ -217,6 +217,9 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
 #endif
 #pragma unroll
         for (int kb2 = 0; kb2 < KT / 32; ++kb2) {
+            // a 32-key block that lies wholly behind the last key (n = 1729: the second block of the last tile) contributes exact zeros -- p = exp2(-inf),
+            // nothing added to the row sums or to O -- so it is not computed at all (wave-uniform; its tile's DMA and barrier stay)
+            if (ragged && kb2 > 0 && 32 * (2 * t + kb2) >= p.n) continue;
             // ---- S^T = K Q^T for a 32-key block: four 16-wide d steps
             f32x16 s;
 #if !defined(GFE_ATTN_EXP_NODMA)     // NODMA: timing experiment only, K/V tiles are never restaged

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(BW * 64, 2) void attn_bwd_dq_kernel(const BwdParams
 #pragma unroll
         for (int kb2 = 0; kb2 < RT / 32; ++kb2) {
             if (kb2 == 0 && t + RING - 1 < ntile) { GFE_FUZZ(); dma(t + RING - 1, (SLOT + RING - 1) % RING); }
+            if (ragged && kb2 > 0 && RT * t + 32 * kb2 >= p.n) continue;      // a block wholly behind the last key adds exact zeros to dQ (attn.hip: same skip)
             bf16x8 kr[4], vr[4];
             load_rows(kr, sk, kb2, fo);
             load_rows(vr, sv, kb2, fo);
