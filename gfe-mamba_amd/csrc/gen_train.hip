@@ -226,9 +226,50 @@ __global__ __launch_bounds__(256) void in1_wgrad_kernel(const float* __restrict_
 
 static unsigned grid_for(int64_t items) { int64_t g = ceil_div(items, 256); return (unsigned)(g > 8192 ? 8192 : g); }
 
+// nn.L1Loss()(pred, target) (main_gan_vit.py:72 -- the generator's reconstruction loss) with its gradient in one pass: block i sums its 4 096-element chunk
+// (every thread its own elements in order, a fixed tree over the block) into part[i] and writes dpred = sign(pred - target) / n; l1_fold_kernel adds the
+// blocks' partials in order.  No atomics: the loss is run-to-run bit-identical.
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ part,
+                                                      float* __restrict__ dpred, int64_t n, float inv_n) {
+    __shared__ float red[32];
+    const int64_t base = (int64_t)blockIdx.x * 4096;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int64_t i = base + threadIdx.x + 256 * k;
+        if (i < n) {
+            const float d = pred[i] - target[i];
+            s += fabsf(d);
+            dpred[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void l1_fold_kernel(const float* __restrict__ part, float* __restrict__ loss, int nblk, float inv_n) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gfe_l1_loss_blocks(int64_t n) { return (int)ceil_div(n, 4096); }
+
+int gfe_l1_loss(const float* pred, const float* target, float* loss, float* dpred, float* part_ws, int64_t n, void* stream) {
+    GFE_REQUIRE(pred && target && loss && dpred && part_ws, GFE_ERR_NULL);
+    GFE_REQUIRE(n > 0 && ceil_div(n, 4096) <= 0x7fffffff, GFE_ERR_SHAPE);
+    const int nblk = gfe_l1_loss_blocks(n);
+    const float inv_n = 1.0f / (float)n;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)nblk), dim3(256), 0, st, pred, target, part_ws, dpred, n, inv_n);
+    hipLaunchKernelGGL(l1_fold_kernel, dim3(1), dim3(256), 0, st, part_ws, loss, nblk, inv_n);
+    return gfe_launch_status();
+}
 
 int gfe_gn_apply(const void* x, const float* scale, const float* shift, void* y, int64_t B, int64_t V, int64_t C, void* stream) {
     GFE_REQUIRE(x && scale && shift && y, GFE_ERR_NULL);

@@ -403,11 +403,37 @@ def generator_forward_train(gen, x):
     return pet
 
 
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        p_, t_ = pred.detach().float().contiguous().reshape(-1), target.detach().float().contiguous().reshape(-1)
+        assert p_.numel() == t_.numel() and p_.is_cuda, "l1_loss: HIP path only, equal sizes"
+        n = p_.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=p_.device)
+        dp = torch.empty_like(p_)
+        ws = torch.empty(lib().gfe_l1_loss_blocks(n), dtype=torch.float32, device=p_.device)
+        call("gfe_l1_loss", ptr(p_), ptr(t_), ptr(loss), ptr(dp), ptr(ws), n, stream())
+        ctx.save_for_backward(dp)
+        ctx.meta = (pred.shape, pred.dtype)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dp,) = ctx.saved_tensors
+        shape, dt = ctx.meta
+        return (dp * dloss).view(shape).to(dt), None
+
+
+def l1_loss(pred, target):
+    """nn.L1Loss()(pred, target) (main_gan_vit.py:72): value and gradient from one launch, per-block partial sums added in order (bit-reproducible)."""
+    return _L1Loss.apply(pred, target)
+
+
 def train_step(gen, opt, x, target):
     """One generator step of main_gan_vit.py:68-82 without the third-party losses: L1(model(condition), real) -> backward -> optimizer."""
     opt.zero_grad()
     pred = generator_forward_train(gen, x)
-    loss = F.l1_loss(pred, target)
+    loss = l1_loss(pred, target)
     loss.backward()
     opt.step()
     return loss.detach()

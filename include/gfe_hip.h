@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 47
+#define GFE_ABI_VERSION 48
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -383,6 +383,11 @@ int gfe_conv_out1_bwd(const void* x, const float* dy, const float* w, void* dx, 
 /* 1x1x1 lift gradients from dr (rows, C) bf16: db[c] += sum dr; with x (rows) f32 of a one-channel input also dw[c] += sum dr * x
  * (x == NULL and dw == NULL: bias gradient only). */
 int gfe_conv_in1_wgrad(const float* x, const void* dr, float* dw_accum, float* db_accum, float* ws, int64_t rows, int64_t C, void* stream);
+
+/* nn.L1Loss()(pred, target) -- the generator's reconstruction loss (main_gan_vit.py:72) -- value and gradient in one pass: loss[0] = mean |pred - target|,
+ * dpred = sign(pred - target) / n; part_ws holds gfe_l1_loss_blocks(n) floats (per-block partial sums, added in order: no atomics). */
+int gfe_l1_loss_blocks(int64_t n);
+int gfe_l1_loss(const float* pred, const float* target, float* loss, float* dpred, float* part_ws, int64_t n, void* stream);
 
 /* Weight gradient of a tap-list convolution (the backward of nn.Conv3d k3 p1 / the parity classes of ConvTranspose3d k3 s2 p1,
  * pytorch3dunet/unet3d/buildingblocks.py:46-52, 523-537), ALL taps in one launch (csrc/conv_wgrad.hip):

@@ -242,6 +242,27 @@ def test_generator_training_backward_is_bit_reproducible(vol, f_maps, vit):
     assert not diff, "gradients differ between two identical passes: %s" % diff[:8]
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 24, 16, 16), (1, 1, 5, 7, 3), (3, 4097)])
+def test_l1_loss_value_and_gradient_vs_torch(shape):
+    """gfe_l1_loss (nn.L1Loss of main_gan_vit.py:72): the mean against f64, the gradient sign(pred - target) / n exactly (ties give 0), both
+    run-to-run bit-identical (per-block partial sums added in order)."""
+    from gfe_hip.gen_train import l1_loss
+    g = torch.Generator().manual_seed(sum(shape))
+    pred = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+    target = torch.randn(shape, generator=g).to(DEV)
+    with torch.no_grad():
+        target.view(-1)[::7] = pred.view(-1)[::7]                       # exact ties
+    loss = l1_loss(pred, target)
+    (loss * 3.0).backward()
+    ref = (pred.detach().double() - target.double()).abs().mean()
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, ref.item())
+    sgn = torch.sign(pred.detach() - target)
+    assert torch.equal(torch.sign(pred.grad), sgn) and (sgn == 0).sum().item() >= pred.numel() // 7        # the sign pattern exactly, ties give 0
+    assert torch.allclose(pred.grad, sgn * (3.0 / pred.numel()), rtol=1e-6, atol=0.0)                     # (1 / n rounded once, then x 3)
+    again = l1_loss(pred.detach(), target)
+    assert torch.equal(again, loss.detach())
+
+
 def test_generator_train_steps_reduce_the_l1_loss_and_refresh_the_frozen_packs():
     """train_step (main_gan_vit.py:68-82 minus the third-party losses) with FlatAdam: the loss falls over a few steps, and the eval-mode
     forward (which caches packed / GroupNorm-folded weights) sees the updated parameters although the update kernel rewrites them
