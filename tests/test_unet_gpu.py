@@ -325,6 +325,33 @@ def test_fused_groupnorm_partials_match_the_statistics_pass(C, shape):
         check(up(skip, x))
 
 
+@pytest.mark.parametrize("C,shape", [(64, (2, 16, 16, 24)), (128, (2, 8, 9, 7)), (32, (1, 11, 8, 8))])
+def test_stride1_conv_writes_every_groupnorm_partial_slot(C, shape):
+    """conv_igemm(stats=True) hands the kernel an UNINITIALISED partials workspace (round 5: no zero fill in front of six convs of a generator pass):
+    out of a NaN-poisoned allocator pool the partials must come out finite and equal, bit for bit, to those written into a zeroed workspace --
+    every slot (one per tile of the sample, ragged tiles included), every channel."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(C + shape[1])
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, C, generator=g).to(BF).to(DEV)
+    wp = K.pack_conv3((torch.randn(C, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5).to(DEV), BF)
+    zeroed = K.new_gn_partials(B, K.conv_stat_slots(B, D, H, W, C), C, x.device)
+    y0 = K.conv_igemm(x, wp, K.CONV3_TAPS, C, relu=True, stats=(zeroed, 0))
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(8)] + [torch.full((1 << s_,), float("nan"), device=DEV) for s_ in (10, 12, 14, 16, 18, 20) for _ in range(16)]
+    del junk
+    torch.cuda.synchronize()                                 # the blocks go back to the caching allocator, the poison stays in them
+    probe = torch.empty_like(zeroed)
+    poisoned = bool(torch.isnan(probe).any())
+    del probe
+    if not poisoned:
+        pytest.skip("the allocator did not hand the poisoned blocks back for this size")
+    y1 = K.conv_igemm(x, wp, K.CONV3_TAPS, C, relu=True, stats=True)
+    assert torch.isfinite(y1.gn_partials).all()
+    assert torch.equal(y1.gn_partials, zeroed) and torch.equal(y1, y0)
+
+
 _CONV_CHILD = """
 import sys, torch
 sys.path.insert(0, %r)
