@@ -492,14 +492,12 @@ int gemm_dispatch(GemmParams& p, int64_t split_k, hipStream_t st) {
     }
     int rc;
     bool dma_split = false;
-    const char* dma_env = nsplit > 1 && p.K >= 16384 ? getenv("GFE_GEMM_DMA_SPLITK") : nullptr;      // (read per call: tests flip it)
-    const bool dma_splitk = dma_env != nullptr && dma_env[0] == '1';
-    if (dma_splitk && nsplit > 1 && p.part && p.a_mode == 0 && p.b_mode == 0 && p.K >= 16384 && (int64_t)ks * nsplit == p.K) {
+    if (nsplit > 1 && p.part && p.a_mode == 0 && p.b_mode == 0 && p.K >= 16384 && (int64_t)ks * nsplit == p.K) {
         // a weight-streaming product cut along K (the generator ViT's patch embedding: 200 x 512 x 147 456): the K ranges' tiles on the persistent
         // LDS-DMA main loop, one 256-row tile per (range, column tile) -- the weights cross L2 -> LDS once instead of once per 128-row tile through
-        // registers; the same fixed-order reduction below.  Taken for ANY M (a row's sum order must not depend on the batch it rides in).
-        // OPT-IN (GFE_GEMM_DMA_SPLITK=1): 105 -> 59 us for that product, but another summation order re-rolls the generator's bf16 rounding noise, and
-        // the round's end-to-end bounds (tests/test_head_gpu.py, T2) were set on the staged kernel's realisation.
+        // registers; the same fixed-order reduction below.  Taken for ANY M (a row's sum order must not depend on the batch it rides in), and
+        // BIT-IDENTICAL to the staged kernel for the same number of ranges (same k order inside a range, same MFMA shape: tools/gemm_split_equal.py,
+        // test_gemm_weight_streaming_split_k_on_the_dma_main_loop) -- what moves the generator's rounding noise is the NUMBER of ranges, which the caller keeps.
         GemmDmaArgs d;
         d.A = p.A; d.B = p.B; d.C = p.C; d.bias = nullptr; d.res = nullptr;
         d.lda = p.lda; d.ldb = p.ldb; d.ldc = p.ldc; d.ldres = 0;

@@ -112,8 +112,9 @@ class ViT(nn.Module):
         # 24 splits 119 + 9 us, 48 splits 85 + 16 us, 64 splits 90 + 19 us)
         # The cut of K is a function of the geometry alone, NOT of the batch (sized for the bench's 8 volumes = two 128-row tiles): how K is
         # partitioned decides how a row's sum is rounded, and a volume must come out bit-identical whatever batch it rides in.
-        # (GFE_GEMM_DMA_SPLITK=1 GFE_VIT_EMBED_BLOCKS=512: the ranges' tiles on the persistent LDS-DMA main loop instead, 64 ranges x 4 column tiles = one
-        # 256-row tile per CU, 105 -> 59 us; opt-in, gemm.hip says why)
+        # Round 5: with K >= 16 384 the ranges' tiles run on the persistent LDS-DMA main loop (gemm.hip), bit-identical to the staged kernel for the same
+        # number of ranges; the NUMBER of ranges (48) stays what rounds 2-4 used: it fixes the rounding of everything behind this product
+        # (profiles/r05/t2_realisations.txt: six counts, six realisations of T2's statistics).
         mblk, nblk = 2, -(-dim // 128)
         split = max(1, min(pd // 512, -(-int(os.environ.get("GFE_VIT_EMBED_BLOCKS", "384")) // (mblk * nblk))))
         emb = K.gemm_nt(tok, w["w_embed"], bias=w["b_embed"], out_dtype=torch.float32, split_k=split)

@@ -50,26 +50,33 @@ def test_gemm_epilogues_and_splitk():
 
 
 def test_gemm_weight_streaming_split_k_on_the_dma_main_loop(monkeypatch):
-    """The opt-in path GFE_GEMM_DMA_SPLITK=1: K >= 16 384 with an explicit split (the generator ViT's patch embedding, vit.py:95-100: 25 rows per
-    volume x 147 456 -> 512): the K ranges' tiles run on the persistent LDS-DMA main loop for ANY row count (gemm.hip), the fixed-order reduction adds
-    bias.  Against f64; and a row's result must not depend on how many other rows ride along (batch 1 = 25 rows, batch 8 = 200: bit for bit)."""
+    """K >= 16 384 with an explicit split (the generator ViT's patch embedding, vit.py:95-100: 25 rows per volume x 147 456 -> 512): the K ranges' tiles
+    run on the persistent LDS-DMA main loop for ANY row count (gemm.hip), the fixed-order reduction adds bias.  Against f64; a row's result must not
+    depend on how many other rows ride along (batch 1 = 25 rows, batch 8 = 200: bit for bit); and for the same number of ranges the result equals the
+    staged kernel's bit for bit (GFE_GEMM_NO_DMA=1), which is why the switch did not move the generator's outputs."""
     from gfe_hip import nn_ops as K
     import gfe_hip
-    monkeypatch.setenv("GFE_GEMM_DMA_SPLITK", "1")
     g = torch.Generator().manual_seed(11)
-    Kd, N = 64 * 64 * 9, 512
+    Kd, N = 64 * 48 * 12, 512
     a = torch.randn(200, Kd, generator=g).to(BF).to(DEV)
     b = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).to(BF).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
-    n0 = gfe_hip.lib().gfe_gemm_dma_launches()
-    y = K.gemm_nt(a, b, bias=bias, out_dtype=torch.float32, split_k=64)
-    assert gfe_hip.lib().gfe_gemm_dma_launches() == n0 + 1, "the split product did not take the LDS-DMA main loop"
-    ref = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
-    assert rel_err(y, ref.float()) < 2e-5
-    y1 = K.gemm_nt(a[:25].contiguous(), b, bias=bias, out_dtype=torch.float32, split_k=64)
-    assert torch.equal(y1, y[:25])
-    y2 = K.gemm_nt(a[100:131].contiguous(), b, bias=bias, out_dtype=torch.float32, split_k=64)       # another row count, rows at other tile positions
-    assert torch.equal(y2, y[100:131])
+    for split in (48, 64):
+        n0 = gfe_hip.lib().gfe_gemm_dma_launches()
+        y = K.gemm_nt(a, b, bias=bias, out_dtype=torch.float32, split_k=split)
+        assert gfe_hip.lib().gfe_gemm_dma_launches() == n0 + 1, "the split product did not take the LDS-DMA main loop"
+        ref = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
+        assert rel_err(y, ref.float()) < 2e-5
+        y1 = K.gemm_nt(a[:25].contiguous(), b, bias=bias, out_dtype=torch.float32, split_k=split)
+        assert torch.equal(y1, y[:25])
+        y2 = K.gemm_nt(a[100:131].contiguous(), b, bias=bias, out_dtype=torch.float32, split_k=split)       # another row count, rows at other tile positions
+        assert torch.equal(y2, y[100:131])
+        monkeypatch.setenv("GFE_GEMM_NO_DMA", "1")
+        n0 = gfe_hip.lib().gfe_gemm_dma_launches()
+        ys = K.gemm_nt(a, b, bias=bias, out_dtype=torch.float32, split_k=split)
+        assert gfe_hip.lib().gfe_gemm_dma_launches() == n0
+        monkeypatch.delenv("GFE_GEMM_NO_DMA")
+        assert torch.equal(ys, y)
 
 
 @pytest.mark.parametrize("N,K_", [(512, 512), (1536, 512), (2048, 512), (512, 2048)])
