@@ -130,16 +130,6 @@ template <> struct Vec4<bf16_t> {
     static __device__ __forceinline__ type zero() { return make_uint2(0u, 0u); }
 };
 
-// LDS image of one 32-step tile
-struct Tile {
-    float dt[CB * TT];           // [channel][step]  softplus(delta + bias), 0 past the chunk end  (dts_index)
-    float dtu[CB * TT];          // [channel][step]  dt * u
-    float epu[TT * EPS];         // [step][channel]  D * u
-    float epg[TT * EPS];         // [step][channel]  silu(z) (1 without a gate)
-    f4 bc[TT * 8];               // [step][pair]     {B[2p], B[2p+1], C[2p], C[2p+1]}
-};
-
-// One block = 32 channels x one chunk.  STATE_ONLY (K1 of the chunked plan): end state from h = 0 and sum(dt), no output.
 // A block's 32 channels are a 64-byte segment of every (b, t) row of the bf16 tensors: HALF a 128-byte line, the other half belongs to the
 // neighbouring channel group.  Workgroups go to the 8 XCDs round-robin, so with the identity mapping the two halves are fetched by two
 // different L2s -- every input line crosses the HBM interface twice (FETCH_SIZE 420 MB for 201 MB of forward inputs, profiles/r02).
@@ -181,123 +171,184 @@ __device__ __forceinline__ f2 chunk_carry(const float* __restrict__ state, const
     return H;
 }
 
-// Wave-specialised block (round 3): 8 waves = 4 SCAN waves (0-3: the recurrence, one wave per SIMD as before) + 4 STAGING waves (4-7,
-// the SIMD partners of waves 0-3): fetch the next tile's rows, do the per-(t, channel) math (softplus, silu, products) once, park it in
-// the other LDS buffer, and write the previous tile's y rows out.  The scan waves' instruction stream loses a third of its issue slots'
-// worth of work (staging 30 + stores 12 of 128 cycles per step) to a partner that fills the slots the dependent h chain leaves idle,
-// and plain VALU instructions cost 2.7 instead of 6.5 cycles with two waves on a SIMD (profiles/r02/valu_rates.txt).  One barrier per tile.
-template <typename T, bool STATE_ONLY>
-__global__ __launch_bounds__(512, 4) void sscan2_fwd_kernel(const S2Fwd p) {      // <= 128 registers: two blocks per CU when the grid has them (chunked plans, B >= 16)
-    typedef typename Vec4<T>::type V4;
-    __shared__ __attribute__((aligned(16))) Tile tiles[2];
-    __shared__ __attribute__((aligned(16))) float ytile[2][TT * EPS];           // hs.C + D*u of the tile (f32: gated and rounded once, on the way out)
+// ------------------------------------------------------------------------------------------------
+// forward (round 6 formulation)
+// ------------------------------------------------------------------------------------------------
+// Row I/O of the staging waves goes through raw buffer instructions: a row past the chunk's end is an out-of-range offset, which the
+// hardware answers with zeros (loads) or drops (stores).  That keeps the staging waves' instruction stream free of exec-masked branches, so
+// hipcc's waitcnt pass sees a straight line and emits COUNTED s_waitcnt vmcnt(N) in front of the first use of a fetched row -- with the
+// `if (row < nrows)` blocks of rounds 2-5 it had to assume the worst and emitted vmcnt(0), i.e. every tile waited for the previous
+// tile's output stores (and, in the backward, for its float atomics: 600-3000 cycles each, MI355X_MICROARCH.md).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane((int)(base ? bytes : 0u)), 0x00020000);
+}
+
+// four consecutive channels of one row: 16 B (f32) or 8 B (bf16)
+template <typename T> struct Row4;
+template <> struct Row4<float> {
+    typedef u4v raw;
+    static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+    static __device__ __forceinline__ void st(f4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b128(u4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
+    }
+    static __device__ __forceinline__ f4 unpack(raw v) { return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)}; }
+    static __device__ __forceinline__ raw zero() { return raw{0u, 0u, 0u, 0u}; }
+};
+template <> struct Row4<bf16_t> {
+    typedef u2v raw;
+    static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+    static __device__ __forceinline__ void st(f4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b64(u2v{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, r, off, 0, 0);
+    }
+    static __device__ __forceinline__ f4 unpack(raw v) { return f4{bf16lo_to_f32(v.x), bf16hi_to_f32(v.x), bf16lo_to_f32(v.y), bf16hi_to_f32(v.y)}; }
+    static __device__ __forceinline__ raw zero() { return raw{0u, 0u}; }
+};
+
+constexpr int PS = 36;           // row stride (floats) of the per-pair partial rows: 32 channels + 4, so that the 8 pair rows of a step start on
+                                 // banks 0, 4, .. 28 (scan waves: conflict-free ds_write_b32; staging waves: conflict-free ds_read_b128)
+constexpr int YP_TILE = TT * 8 * PS;
+
+// LDS image of one 32-step tile as the scan waves read it
+struct FTile {
+    f4 dd[TT / 2 * CB];          // [step / 2][slot] {dt, dt*u} of steps 2j and 2j+1: dt = softplus(delta + bias), 0 past the chunk end -- one
+                                 //                  ds_read_b128 per two steps (hipcc fuses two ds_read_b64 of a [step][channel] image into ds_read2_b64: half rate)
+    f4 bc[TT * 8];               // [step][pair]     {B[2p], B[2p+1], C[2p], C[2p+1]}                        -- one ds_read_b128 per step
+};
+// slot of a channel in FTile::dd: the staging lanes of a row write 8 bytes each for channels 4*sc + j, sc = 0..7 -- with the identity those are
+// 16 dwords apart (4-way bank conflict on every ds_write_b64); the XOR spreads the 8 lanes over the 8 bank quads
+__device__ __forceinline__ int dd_slot(int ch) { return ch ^ (ch >> 3); }
+
+// One block = 32 channels x one chunk = 8 waves: 4 SCAN waves (0-3) + 4 STAGING waves (4-7, their SIMD partners).
+//
+// Round 6: the scan waves keep ONLY what is per (step, channel, state): a = exp2(A dt) (v_pk_mul + 2 v_exp), h = a h + B dt u (v_pk_mul +
+// v_pk_fma) and the lane's share of the output, C[2p] h[2p] + C[2p+1] h[2p+1] (v_mul + v_fmac) -- which they DROP INTO LDS as it is, one
+// ds_write_b32 per step, [step][pair][channel].  Everything that is per (step, channel) belongs to the staging waves: they fetch the rows,
+// compute dt / dt*u once, and finish the outputs of the previous tile: the sum over the 8 pair rows is 7 in-lane f4 additions on
+// ds_read_b128 fragments (the LDS array does the transposition that rounds 2-5 did with a permlane / DPP butterfly in the scan wave: 76
+// of its 330 vector instructions per tile, plus 35 s_nop hazard pads), then + D u, the gate, the rounding and whole-row stores.  D u and
+// silu(z) never touch LDS: the staging lane that computed them when it parked the tile is the lane that finishes the tile two barriers
+// later (two register sets, loop unrolled by two).
+// STATE_ONLY (first pass of the chunked plan): end state from h = 0 and the chunk's sum of dt; no outputs.
+template <typename T, typename TBC, bool STATE_ONLY>
+__global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
+    typedef Row4<T> R;
+    typedef Row4<TBC> RBC;
+    __shared__ __attribute__((aligned(16))) FTile tiles[2];
+    __shared__ __attribute__((aligned(16))) float ypart[STATE_ONLY ? TT * CB : 2 * YP_TILE];   // STATE_ONLY: the staging lanes' sums of dt on their way to sdelta
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
     const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
     const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
     const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
     const int nrows = t1 - t0;
-    // staging role of a thread: row sr of the tile, channels 4*sc .. 4*sc+3 of the block
-    const int sr = tid >> 3, sc = tid & 7;
-    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;
+    const int nt = (nrows + TT - 1) / TT;
+    const size_t row0 = (size_t)b * p.L + t0;
 
     if (staging) {
-        const T* __restrict__ u = (const T*)p.u;
-        const T* __restrict__ dl = (const T*)p.delta;
-        const T* __restrict__ z = (const T*)p.z;
-        T* __restrict__ y = (T*)p.y;
-        T* __restrict__ ysc = (T*)p.yscan;
-        const bool has_z = !STATE_ONLY && z != nullptr;
+        const int sr = tid >> 3, sc = tid & 7;                       // row sr of the tile, channels 4*sc .. 4*sc+3 of the block
+        const bool has_z = !STATE_ONLY && p.z != nullptr;
+        const unsigned esz = sizeof(T);
+        const unsigned span = (unsigned)((nrows - 1) * p.ED + CB) * esz;            // this block's bytes of a (B, L, ED) tensor from its first row on
+        const __amdgpu_buffer_rsrc_t rs_u = row_rsrc((const T*)p.u + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_d = row_rsrc((const T*)p.delta + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_z = row_rsrc(has_z ? (const T*)p.z + row0 * p.ld_z + e0 : nullptr, (unsigned)((nrows - 1) * p.ld_z + CB) * esz);
+        const __amdgpu_buffer_rsrc_t rs_y = row_rsrc(STATE_ONLY ? nullptr : (T*)p.y + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_ys = row_rsrc((STATE_ONLY || !p.yscan) ? nullptr : (T*)p.yscan + row0 * p.ED + e0, span);
+        // B / C role: waves 4-5 fetch B, 6-7 fetch C: row br of the tile, floats 4*bq .. 4*bq+3
+        const int br = (tid & 127) >> 2, bq = tid & 3;
+        const bool isB = tid < 128;
+        const unsigned bsz = sizeof(TBC);
+        const __amdgpu_buffer_rsrc_t rs_bc = row_rsrc((const char*)(isB ? p.Bm : p.Cm) + row0 * p.ld_bc * bsz, (unsigned)((nrows - 1) * p.ld_bc + 16) * bsz);
+        const unsigned rowb = (unsigned)p.ED * esz, rowbz = (unsigned)p.ld_z * esz, rowbbc = (unsigned)p.ld_bc * bsz;
+        const unsigned off_e = (unsigned)(sr * p.ED + 4 * sc) * esz, off_z = (unsigned)(sr * p.ld_z + 4 * sc) * esz, off_bc = (unsigned)(br * p.ld_bc + 4 * bq) * bsz;
         float sbias[4], sD[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
             sD[k] = (!STATE_ONLY && p.D) ? p.D[e0 + 4 * sc + k] : 0.f;
         }
-        // B / C role: threads 0-127 fetch B, 128-255 fetch C: row (tid & 127) >> 2 of the tile, floats 4q .. 4q+3
-        const int br = (tid & 127) >> 2, bq = tid & 3;
-        const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
-        V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero();
-        f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
-        // 64-bit bases once; per tile only a 32-bit row offset (rows past the chunk end: clamped here, masked in park)
-        const T* __restrict__ pu = u + rowbase;
-        const T* __restrict__ pd = dl + rowbase;
-        const T* __restrict__ pz = has_z ? z + ((size_t)b * p.L + t0) * p.ld_z + e0 + 4 * sc : nullptr;
-        const size_t bcbase = ((size_t)b * p.L + t0) * p.ld_bc + 4 * bq;
-        const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
-        const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
-        auto fetch = [&](int tb) {                                    // global -> registers, tile starting at step tb
-            const int row = min(tb - t0 + sr, nrows - 1);
-            const int off = row * p.ED;
-            ru = *reinterpret_cast<const V4*>(pu + off);
-            rd = *reinterpret_cast<const V4*>(pd + off);
-            if (has_z) rz = *reinterpret_cast<const V4*>(pz + row * p.ld_z);
-            if (!STATE_ONLY || tid < 128) {
-                const int boff = min(tb - t0 + br, nrows - 1) * p.ld_bc;
-                if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
-                else rbc = *reinterpret_cast<const f4*>(pbc + boff);
-            }
+        typename R::raw ru = R::zero(), rd = R::zero(), rz = R::zero();
+        typename RBC::raw rbc = RBC::zero();
+        f4 sdt = f4{0.f, 0.f, 0.f, 0.f};
+        struct Keep { f4 du, gate; };                                 // D*u and silu(z) of a parked tile, until that tile's outputs are finished
+        auto fetch = [&](int k) {                                     // global -> registers, tile k (rows past the end: zeros)
+            const unsigned kr = (unsigned)(k * TT);
+            ru = R::ld(rs_u, off_e + kr * rowb);
+            rd = R::ld(rs_d, off_e + kr * rowb);
+            if (!STATE_ONLY) rz = R::ld(rs_z, off_z + kr * rowbz);
+            if (!STATE_ONLY || isB) rbc = RBC::ld(rs_bc, off_bc + kr * rowbbc);
         };
-        auto bc_rows = [&](int tb) -> f4 {                            // the fetched B / C quarter-row as f32 (zero past the end)
-            f4 v = rbc;
-            if (p.bc_bf16) {
-                const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
-                v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
-            }
-            return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
-        };
-        auto park = [&](Tile& tl, int tb) {                           // registers -> LDS (the per-(t, channel) math happens once, here)
-            float fu[4], fd[4], fz[4];
-            Vec4<T>::unpack(ru, fu); Vec4<T>::unpack(rd, fd);
-            if (has_z) Vec4<T>::unpack(rz, fz);
-            const bool valid = tb + sr < t1;
-            f4 vu, vg;
+        auto park = [&](int k, Keep& K) {                             // registers -> LDS; the per-(t, channel) math happens once, here
+            const f4 fu = R::unpack(ru), fd = R::unpack(rd), fz = R::unpack(rz);
+            const bool valid = k * TT + sr < nrows;
+            FTile& tl = tiles[k & 1];
+            float dt[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float raw = fd[k] + sbias[k];
-                float dt = p.softplus ? softplus_nb(raw) : raw;
-                if (!valid) dt = 0.f;                                 // a = exp2(0) = 1, dt*u = 0: steps past the end leave the state alone
-                tl.dt[dts_index(4 * sc + k, sr)] = dt;
-                tl.dtu[dts_index(4 * sc + k, sr)] = dt * fu[k];
-                vu[k] = sD[k] * fu[k];
-                vg[k] = has_z ? siluf_(fz[k]) : 1.f;
+            for (int j = 0; j < 4; ++j) {
+                const float raw = fd[j] + sbias[j];
+                float v = softplus_nb(raw);
+                asm volatile("" : "+v"(v));                           // (keeps the four softplus chains in one block: a uniform branch per element would serialise them)
+                v = p.softplus ? v : raw;
+                dt[j] = valid ? v : 0.f;                              // a = exp2(0) = 1, dt*u = 0: steps past the end leave the state alone
+                if (!STATE_ONLY) { K.du[j] = sD[j] * fu[j]; K.gate[j] = has_z ? siluf_(fz[j]) : 1.f; }
+                else sdt[j] += dt[j];
             }
-            if (!STATE_ONLY) {
-                *reinterpret_cast<f4*>(&tl.epu[sr * EPS + 4 * sc]) = vu;
-                *reinterpret_cast<f4*>(&tl.epg[sr * EPS + 4 * sc]) = vg;
-            }
-            float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
-            if (!STATE_ONLY || tid < 128) {
-                const f4 v = bc_rows(tb);
+            f2* ddp = reinterpret_cast<f2*>(&tl.dd[(sr >> 1) * CB]) + (sr & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ddp[2 * dd_slot(4 * sc + j)] = f2{dt[j], dt[j] * fu[j]};
+            if (!STATE_ONLY || isB) {
+                const f4 v = RBC::unpack(rbc);
+                float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (isB ? 0 : 2);
                 *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
                 *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
             }
         };
-
-        // a finished tile's outputs: whole row segments, 4 channels per lane; the gate silu(z) of that tile is still in its staging buffer
-        auto rows_out = [&](int buf, int r) {
-            const f4 yb = *reinterpret_cast<const f4*>(&ytile[buf][sr * EPS + 4 * sc]);
-            const f4 g = *reinterpret_cast<const f4*>(&tiles[buf].epg[sr * EPS + 4 * sc]);
-            if (r < nrows) {
-                const size_t off = rowbase + (size_t)r * p.ED;
-                *reinterpret_cast<V4*>(y + off) = Vec4<T>::pack(yb * g);
-                if (ysc) *reinterpret_cast<V4*>(ysc + off) = Vec4<T>::pack(yb);
-            }
+        auto finish = [&](int k, const Keep& K) {                     // tile k's outputs: 8 pair rows -> one value per (step, channel)
+            const float* yp = &ypart[(k & 1) * YP_TILE + sr * 8 * PS + 4 * sc];
+            f4 acc = *reinterpret_cast<const f4*>(yp);
+#pragma unroll
+            for (int q = 1; q < 8; ++q) acc += *reinterpret_cast<const f4*>(yp + q * PS);
+            const f4 yb = acc + K.du;
+            const unsigned off = off_e + (unsigned)(k * TT) * rowb;
+            R::st(yb * K.gate, rs_y, off);
+            R::st(yb, rs_ys, off);                                    // (no yscan: zero-sized resource, the store is dropped)
         };
-        fetch(t0);
-        park(tiles[0], t0);
-        if (t0 + TT < t1) fetch(t0 + TT);                             // the rows of tile k+1 are in flight while tile k-1's outputs go out
+        Keep k0, k1;
+        fetch(0);
+        park(0, k0);
+        fetch(1);
+        lds_barrier();                                                // tile 0 is ready
+        park(1, k1);                                                  // iteration 0: nothing to finish yet
+        fetch(2);
         lds_barrier();
-        int cur = 0;
-        for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
-            const bool more = tb + TT < t1;
-            if (!STATE_ONLY && tb > t0) rows_out(cur ^ 1, tb - TT - t0 + sr);   // (before park() reuses that buffer)
-            if (more) {
-                park(tiles[cur ^ 1], tb + TT);
-                if (tb + 2 * TT < t1) fetch(tb + 2 * TT);
-            }
+        for (int k = 1; k < nt; k += 2) {                             // iteration k: the scan waves are on tile k
+            if (!STATE_ONLY) finish(k - 1, k0);
+            park(k + 1, k0);
+            fetch(k + 2);
             lds_barrier();
+            if (k + 1 < nt) {
+                if (!STATE_ONLY) finish(k, k1);
+                park(k + 2, k1);
+                fetch(k + 3);
+                lds_barrier();
+            }
         }
-        if (!STATE_ONLY) rows_out(cur ^ 1, ((t1 - t0 - 1) / TT) * TT + sr);     // the last tile
+        if (!STATE_ONLY) {
+            if (nt & 1) finish(nt - 1, k0); else finish(nt - 1, k1);
+        } else {
+            *reinterpret_cast<f4*>(&ypart[sr * CB + 4 * sc]) = sdt;
+            lds_barrier();
+            if (tid < CB) {
+                float s = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < TT; ++r) s += ypart[r * CB + tid];
+                p.sdelta[((size_t)b * p.nchunks + c) * p.ED + e0 + tid] = s;
+            }
+        }
         return;
     }
 
@@ -312,73 +363,51 @@ __global__ __launch_bounds__(512, 4) void sscan2_fwd_kernel(const S2Fwd p) {    
     f2 h = f2{0.f, 0.f};
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
     if (!STATE_ONLY && p.nchunks > 1) h = chunk_carry<false>(p.hstate, p.sdelta, A2, b, c, e, pr, p.nchunks, p.ED);
-    float sd = 0.f;
+    const bool do_ck = !STATE_ONLY && p.ckpt != nullptr;         // (uniform)
+    float* ckp = p.ckpt + ((((size_t)b * p.nseg + t0 / SEG) * p.ED + e) * 16 + 2 * pr);
+    const size_t ckstride = (size_t)p.ED * 16;
     lds_barrier();
-    int cur = 0;
     S2_STAMP_DECL
-    for (int tb = t0; tb < t1; tb += TT, cur ^= 1) {
+    for (int k = 0; k < nt; ++k) {
         S2_STAMP(0)
-        if (!STATE_ONLY && p.ckpt)                                // every tile starts a segment (t0 is a multiple of SEG)
-            *reinterpret_cast<f2*>(p.ckpt + ((((size_t)b * p.nseg + tb / SEG) * p.ED + e) * 16 + 2 * pr)) = h;
-        const Tile& tl = tiles[cur];
-        // Nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream, so reads are issued half a group
-        // (4 steps) ahead of their use: a group's second-half B / C rows while its 16 decays are exponentiated, the next group's dt / dt*u
-        // quads and first-half rows between its two halves (two register sets for those, pinned with sched_barrier; <= 128 registers).
-        struct Grp { f4 dt4[2], du4[2], bc[4]; float epu; };
-        auto load_a = [&](Grp& G, int g) {
+        if (do_ck) { *reinterpret_cast<f2*>(ckp) = h; ckp += ckstride; }     // every tile starts a segment (t0 is a multiple of SEG)
+        const f4* ddp = &tiles[k & 1].dd[dd_slot(cl)];
+        const f4* bcp = &tiles[k & 1].bc[pr];
+        float* yp = &ypart[STATE_ONLY ? 0 : (k & 1) * YP_TILE + pr * PS + cl];
+        // Work unit = 4 steps; the LDS reads of the NEXT unit are issued in front of the current unit's arithmetic (two register sets, pinned
+        // with sched_barrier): nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream.
+        struct U4 { f4 dd[2]; f4 bc[4]; };
+        auto load_u = [&](U4& U, int u) {
+            U.dd[0] = ddp[(2 * u) * CB]; U.dd[1] = ddp[(2 * u + 1) * CB];
 #pragma unroll
-            for (int j4 = 0; j4 < 2; ++j4) {
-                G.dt4[j4] = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 8 * g + 4 * j4)]);
-                G.du4[j4] = *reinterpret_cast<const f4*>(&tl.dtu[dts_index(cl, 8 * g + 4 * j4)]);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) G.bc[s] = tl.bc[(8 * g + s) * 8 + pr];
-            if (!STATE_ONLY) G.epu = tl.epu[(8 * g + pr) * EPS + cl];
+            for (int s = 0; s < 4; ++s) U.bc[s] = bcp[(4 * u + s) * 8];
         };
-        f4 bcb[4];
-        auto load_b = [&](int g) {
+        auto step_u = [&](const U4& U, int u) {
+            f2 a[4], xb[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bcb[s] = tl.bc[(8 * g + 4 + s) * 8 + pr];
-        };
-        float yv[8];
-        f2 a[8];
-        auto exps = [&](const Grp& G) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {                          // the decays do not depend on h: all 16 exp first, so that none of the
-                const f2 x = A2 * G.dt4[s >> 2][s & 3];            // transcendental results is wanted right behind its instruction
+            for (int s = 0; s < 4; ++s) {                          // nothing here depends on h: decays and inputs of the unit first
+                const float dtv = U.dd[s >> 1][2 * (s & 1)], dtu = U.dd[s >> 1][2 * (s & 1) + 1];
+                const f2 x = A2 * dtv;
                 a[s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
-                if (STATE_ONLY) sd += G.dt4[s >> 2][s & 3];
+                xb[s] = f2{U.bc[s].x, U.bc[s].y} * dtu;
             }
-        };
-        auto half = [&](const Grp& G, const f4 (&bc4)[4], int hf) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const f4 bc = bc4[s];
-                h = a[4 * hf + s] * h + f2{bc.x, bc.y} * G.du4[hf][s];
-                if (!STATE_ONLY) yv[4 * hf + s] = fmaf(h.y, bc.w, h.x * bc.z);
+                h = __builtin_elementwise_fma(a[s], h, xb[s]);       // ONE dependent instruction per step (v_pk_fma_f32)
+                if (!STATE_ONLY) yp[(4 * u + s) * 8 * PS] = fmaf(h.y, U.bc[s].w, h.x * U.bc[s].z);
             }
         };
-        auto finish = [&](const Grp& G, int g) {
-            if (!STATE_ONLY) {
-                const float ys = reduce_pairs8(yv);                // this lane: step 8g + pr of channel cl
-                ytile[cur][(8 * g + pr) * EPS + cl] = ys + G.epu;
-            }
-        };
-        Grp ga, gb;
+        U4 ua, ub;
         S2_STAMP(1)
-        load_a(ga, 0);
+        load_u(ua, 0);
 #define SB __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-        for (int g = 0; g < TT / 8; g += 2) {
-            load_b(g); SB;
-            exps(ga); half(ga, ga.bc, 0); SB;
-            load_a(gb, g + 1); SB;
-            half(ga, bcb, 1); finish(ga, g); SB;
-            load_b(g + 1); SB;
-            exps(gb); half(gb, gb.bc, 0); SB;
-            if (g + 2 < TT / 8) load_a(ga, g + 2);
+        for (int u = 0; u < TT / 4; u += 2) {
+            load_u(ub, u + 1); SB;
+            step_u(ua, u); SB;
+            if (u + 2 < TT / 4) load_u(ua, u + 2);
             SB;
-            half(gb, bcb, 1); finish(gb, g + 1); SB;
+            step_u(ub, u + 1); SB;
         }
 #undef SB
         S2_STAMP(2)
@@ -388,16 +417,20 @@ __global__ __launch_bounds__(512, 4) void sscan2_fwd_kernel(const S2Fwd p) {    
     S2_STAMP_FLUSH(STATE_ONLY ? 36 : 0)
     if (STATE_ONLY) {
         *reinterpret_cast<f2*>(p.hstate + sbase) = h;
-        if (pr == 0) p.sdelta[((size_t)b * p.nchunks + c) * p.ED + e] = sd;
+        lds_barrier();                                               // (the staging waves' sum of dt)
     }
 }
 
+template <typename T, typename TBC>
+int sscan2_fwd_launch2(const S2Fwd& p, hipStream_t st) {
+    const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
+    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_fwd_kernel<T, TBC, true>), grid, blk, 0, st, p);      // local end states + sum dt of every chunk
+    hipLaunchKernelGGL((sscan2_fwd_kernel<T, TBC, false>), grid, blk, 0, st, p);
+    return gfe_launch_status();
+}
 template <typename T>
 int sscan2_fwd_launch(const S2Fwd& p, hipStream_t st) {
-    const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
-    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_fwd_kernel<T, true>), grid, blk, 0, st, p);      // local end states + sum dt of every chunk
-    hipLaunchKernelGGL((sscan2_fwd_kernel<T, false>), grid, blk, 0, st, p);
-    return gfe_launch_status();
+    return p.bc_bf16 ? sscan2_fwd_launch2<T, bf16_t>(p, st) : sscan2_fwd_launch2<T, float>(p, st);
 }
 
 
@@ -426,173 +459,207 @@ struct S2Bwd {
 };
 
 constexpr int RSL = TT * 32 + 8;   // slab stride: + 8 floats so that the four (channel & 3) slabs of one ds_write_b64 fall on disjoint banks
-struct BStage {                  // what the staging waves park for one 32-step segment (double-buffered)
-    float dt[CB * TT];           // [channel][step] (dts_index)  softplus(delta + bias), 0 past the end
-    float dtu[CB * TT];          //                              dt * u
-    float g[CB * TT];            //                              dL/dy_scan = dy * silu(z) (dy without a gate), 0 past the end
-    float eu[TT * EPS];          // [step][channel]: what the lane that owns (step, channel) after the pair butterflies needs
-    float edt[TT * EPS];
-    float esg[TT * EPS];         //   d softplus / d raw = sigmoid(raw) (1 without softplus), 0 past the end
-    float eg[TT * EPS];
-    f4 bc[TT * 8];               // [step][pair] {B[2p], B[2p+1], C[2p], C[2p+1]}
+constexpr int PB = 36;             // row stride (f2) of the {d(dt*u), d dt} partial rows: 32 channels + 4 (conflict-free ds_write_b64 from the scan waves)
+struct BTile {                   // what the staging waves park for one 32-step segment (double-buffered)
+    f4 dd[TT / 2 * CB];          // [step / 2][slot]  {dt, dt*u} of two steps, as FTile::dd
+    float g[TT * CB];            // [step][channel]   dL/dy_scan = dy * silu(z) (dy without a gate), 0 past the end
+    f4 bc[TT * 8];               // [step][pair]      {B[2p], B[2p+1], C[2p], C[2p+1]}
 };
 
 // One block = 32 channels x one chunk, segments of 32 steps walked from the chunk's end to its start:
-//   recompute the segment forward from its checkpoint, keeping a_t = exp(dt_t A) and h_t of all 32 steps in registers (a lane owns two
-//   states: 128 registers), then run the adjoint over the same steps -- no exp beyond the recompute's.
-//   Sums over states (d(dt*u), d dt) go through the pair butterflies (dz needs the forward's pre-gate output, which the forward saved:
-//   it is finished by the staging waves, element-wise, on the way in), sums over channels (dB, dC) through
-//   v_permlane32_swap + quad DPP adds into an LDS slab that the block folds over its waves and adds to memory two steps per atomic.
-// Wave-specialised like the forward (round 3): waves 0-3 run the recurrence and its adjoint, waves 4-7 (their SIMD partners) fetch and
-// stage the next segment into the other LDS buffer, write the previous segment's du / ddelta / dz rows out and fold + publish its dB / dC
-// rows.  Two barriers per segment: A (segment start: staging buffer ready, previous segment's outputs complete) and B (between recompute
-// and adjoint: the previous outputs have been drained, the adjoint may overwrite `red` / `otile`).
-// STATE_ONLY (K1' of the chunked plan): only the local adjoint carry q of the chunk from q = 0 (one barrier per segment).
-template <typename T, bool STATE_ONLY>
+//   phase 1: recompute the segment forward from its checkpoint, keeping a_t = exp(dt_t A) and h_t of all 32 steps in registers (a lane owns
+//            two states: 128 registers); phase 2: the adjoint over the same steps, last first -- no exp beyond the recompute's.
+// Round 6, same principle as the forward: the scan waves (0-3) keep what is per (step, channel, state) and hand every sum over lanes to
+// the LDS array:
+//   * d(dt*u) and d dt (sums over the 16 states of a channel): the lane's two-state share of both, folded ONCE over lane bit 4 with the
+//     step parity (v_permlane16_swap + add: the lanes of even rows keep step 2j, odd rows step 2j+1), goes out as one ds_write_b64 per two
+//     steps; the staging lane that owns (step, 4 channels) adds the four partial rows with f4 additions and finishes du / ddelta from the
+//     u, dt, sigmoid and g it has kept in registers since it parked that segment (rounds 2-5: two 19-instruction butterflies per 8 steps in the
+//     scan wave, four more LDS arrays for the owner lanes, and the finishing arithmetic on the dependent wave);
+//   * dB, dC (sums over the block's 32 channels): v_permlane32_swap pairs dB with dC, the 16 partial slabs are folded by the staging waves.
+// Staging waves (4-7): fetch + park the next segment, finish + write the previous segment's du / ddelta rows, fold + publish its dB / dC rows.
+// Their row I/O is branch-free (raw buffer instructions, see the forward), and the atomics of a row past the end add 0 to a clamped
+// address: hipcc counts the queue exactly, so the wait in front of a parked row is vmcnt(N younger operations), not vmcnt(0) behind the
+// previous segment's float atomics (which stay counted for 600-3000 cycles).
+// Two barriers per segment: A (segment start: staging buffer ready, previous segment's outputs complete) and B (between recompute and adjoint:
+// the previous outputs have been drained, the adjoint may overwrite `red` / `part`).
+// STATE_ONLY (first pass of the chunked plan): only the local adjoint carry q of the chunk from q = 0 (one barrier per segment).
+template <typename T, typename TBC, bool STATE_ONLY, bool DET>
 __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
-    typedef typename Vec4<T>::type V4;
-    __shared__ __attribute__((aligned(16))) BStage stg[2];
+    typedef Row4<T> R;
+    typedef Row4<TBC> RBC;
+    __shared__ __attribute__((aligned(16))) BTile stg[2];
     __shared__ __attribute__((aligned(16))) float red[STATE_ONLY ? 4 : 16 * RSL];   // [wave][channel & 3] slabs of [step][16 dB | 16 dC]
-    __shared__ __attribute__((aligned(16))) T otile[2][TT * EPS];       // du, ddelta rows on their way out
+    __shared__ __attribute__((aligned(16))) f2 part[STATE_ONLY ? 2 : TT * 4 * PB];  // [step][pair & 3][channel] {d(dt*u), d dt} summed over lane bit 4
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
     const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
     const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
     const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
     const int nrows = t1 - t0;
-    const int nsegc = (t1 - t0 + TT - 1) / TT;
-    const bool has_z = p.z != nullptr;
-    const int sr = tid >> 3, sc = tid & 7;
-    const size_t rowbase = ((size_t)b * p.L + t0) * p.ED + e0 + 4 * sc;      // 64-bit bases once; per segment only a 32-bit row offset
+    const int K = (nrows + TT - 1) / TT;                                // segments of this chunk
+    const size_t row0 = (size_t)b * p.L + t0;
 
     if (staging) {
-        const T* __restrict__ u = (const T*)p.u;
-        const T* __restrict__ dl = (const T*)p.delta;
-        const T* __restrict__ z = (const T*)p.z;
-        const T* __restrict__ dy = (const T*)p.dy;
-        const T* __restrict__ ysc = (const T*)p.yscan;
-        float sbias[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
+        const int sr = tid >> 3, sc = tid & 7;
+        const bool has_z = p.z != nullptr;
+        const unsigned esz = sizeof(T);
+        const unsigned span = (unsigned)((nrows - 1) * p.ED + CB) * esz, spanz = (unsigned)((nrows - 1) * p.ld_z + CB) * esz;
+        const __amdgpu_buffer_rsrc_t rs_u = row_rsrc(STATE_ONLY ? nullptr : (const T*)p.u + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_d = row_rsrc((const T*)p.delta + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_g = row_rsrc((const T*)p.dy + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_z = row_rsrc(has_z ? (const T*)p.z + row0 * p.ld_z + e0 : nullptr, spanz);
+        const __amdgpu_buffer_rsrc_t rs_ys = row_rsrc((has_z && !STATE_ONLY) ? (const T*)p.yscan + row0 * p.ED + e0 : nullptr, span);
+        const __amdgpu_buffer_rsrc_t rs_du = row_rsrc(STATE_ONLY ? nullptr : (T*)p.du + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_dd = row_rsrc(STATE_ONLY ? nullptr : (T*)p.ddelta + row0 * p.ED + e0, span);
+        const __amdgpu_buffer_rsrc_t rs_dz = row_rsrc((has_z && !STATE_ONLY) ? (T*)p.dz + row0 * p.ld_z + e0 : nullptr, spanz);
         const int br = (tid & 127) >> 2, bq = tid & 3;
-        const void* bcsrc = (tid < 128) ? p.Bm : p.Cm;
-        V4 ru = Vec4<T>::zero(), rd = Vec4<T>::zero(), rz = Vec4<T>::zero(), rg = Vec4<T>::zero(), ry = Vec4<T>::zero();
-        f4 rbc = f4{0.f, 0.f, 0.f, 0.f};
-        const T* __restrict__ pu = u + rowbase;
-        const T* __restrict__ pd = dl + rowbase;
-        const T* __restrict__ pg = dy + rowbase;
-        const size_t zbase = ((size_t)b * p.L + t0) * p.ld_z + e0 + 4 * sc;
-        const T* __restrict__ pz = has_z ? z + zbase : nullptr;
-        const T* __restrict__ py = (has_z && !STATE_ONLY) ? ysc + rowbase : nullptr;
-        const size_t bcbase = ((size_t)b * p.L + t0) * p.ld_bc + 4 * bq;
-        const float* __restrict__ pbc = (const float*)bcsrc + bcbase;
-        const bf16_t* __restrict__ pbc16 = (const bf16_t*)bcsrc + bcbase;
-        auto fetch = [&](int tb) {                                    // rows past the end: clamped here, masked in park
-            const int row = min(tb - t0 + sr, nrows - 1);
-            const int off = row * p.ED;
-            if (!STATE_ONLY) ru = *reinterpret_cast<const V4*>(pu + off);
-            rd = *reinterpret_cast<const V4*>(pd + off);
-            rg = *reinterpret_cast<const V4*>(pg + off);
-            if (has_z) rz = *reinterpret_cast<const V4*>(pz + row * p.ld_z);
-            if (has_z && !STATE_ONLY) ry = *reinterpret_cast<const V4*>(py + off);
-            if (!STATE_ONLY || tid >= 128) {
-                const int boff = min(tb - t0 + br, nrows - 1) * p.ld_bc;
-                if (p.bc_bf16) { const uint2 r = *reinterpret_cast<const uint2*>(pbc16 + boff); rbc = f4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f}; }
-                else rbc = *reinterpret_cast<const f4*>(pbc + boff);
-            }
-        };
-        auto bc_rows = [&](int tb) -> f4 {
-            f4 v = rbc;
-            if (p.bc_bf16) {
-                const uint32_t lo = __float_as_uint(rbc.x), hi = __float_as_uint(rbc.y);
-                v = f4{bf16lo_to_f32(lo), bf16hi_to_f32(lo), bf16lo_to_f32(hi), bf16hi_to_f32(hi)};
-            }
-            return (tb + br < t1) ? v : f4{0.f, 0.f, 0.f, 0.f};
-        };
-        auto park = [&](BStage& tl, int tb) {
-            float fu[4] = {0.f, 0.f, 0.f, 0.f}, fd[4], fz[4], fg[4], fy[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!STATE_ONLY) Vec4<T>::unpack(ru, fu);
-            Vec4<T>::unpack(rd, fd); Vec4<T>::unpack(rg, fg);
-            if (has_z) Vec4<T>::unpack(rz, fz);
-            if (has_z && !STATE_ONLY) Vec4<T>::unpack(ry, fy);
-            const bool valid = tb + sr < t1;
-            f4 vu, vdt, vsg, vg, vgz;
+        const bool isB = tid < 128;
+        const unsigned bsz = sizeof(TBC);
+        const __amdgpu_buffer_rsrc_t rs_bc = row_rsrc((const char*)(isB ? p.Bm : p.Cm) + row0 * p.ld_bc * bsz, (unsigned)((nrows - 1) * p.ld_bc + 16) * bsz);
+        const __amdgpu_buffer_rsrc_t rs_pbc = row_rsrc((DET && !STATE_ONLY) ? p.part_bc + (((size_t)b * gridDim.x + blockIdx.x) * p.L + t0) * 32 : nullptr, (unsigned)nrows * 128u);
+        const unsigned rowb = (unsigned)p.ED * esz, rowbz = (unsigned)p.ld_z * esz, rowbbc = (unsigned)p.ld_bc * bsz;
+        const unsigned off_e = (unsigned)(sr * p.ED + 4 * sc) * esz, off_z = (unsigned)(sr * p.ld_z + 4 * sc) * esz, off_bc = (unsigned)(br * p.ld_bc + 4 * bq) * bsz;
+        float sbias[4], sD[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float raw = fd[k] + sbias[k];
-                float sg = 1.f;
+        for (int k = 0; k < 4; ++k) {
+            sbias[k] = p.dbias ? p.dbias[e0 + 4 * sc + k] : 0.f;
+            sD[k] = (!STATE_ONLY && p.D) ? p.D[e0 + 4 * sc + k] : 0.f;
+        }
+        typename R::raw ru = R::zero(), rd = R::zero(), rz = R::zero(), rg = R::zero(), ry = R::zero();
+        typename RBC::raw rbc = RBC::zero();
+        f4 dDacc = f4{0.f, 0.f, 0.f, 0.f}, dbacc = f4{0.f, 0.f, 0.f, 0.f};
+        struct Keep { f4 u, dt, sg, g; };                             // a parked segment's per-(t, channel) values, until its du / ddelta rows are finished
+        auto fetch = [&](int k) {                                     // segment k (k < 0 / rows past the end: zeros)
+            const unsigned kr = (unsigned)(k * TT);
+            if (!STATE_ONLY) ru = R::ld(rs_u, off_e + kr * rowb);
+            rd = R::ld(rs_d, off_e + kr * rowb);
+            rg = R::ld(rs_g, off_e + kr * rowb);
+            rz = R::ld(rs_z, off_z + kr * rowbz);
+            if (!STATE_ONLY) ry = R::ld(rs_ys, off_e + kr * rowb);
+            if (!STATE_ONLY || !isB) rbc = RBC::ld(rs_bc, off_bc + kr * rowbbc);
+        };
+        auto park = [&](int k, BTile& tl, Keep& S) {
+            const f4 fu = R::unpack(ru), fd = R::unpack(rd), fg = R::unpack(rg), fz = R::unpack(rz), fy = R::unpack(ry);
+            const bool valid = (unsigned)(k * TT + sr) < (unsigned)nrows;
+            f4 gz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float raw = fd[j] + sbias[j];
+                float sg;
                 float dt = softplus_nb(raw, &sg);
+                asm volatile("" : "+v"(dt), "+v"(sg));
                 if (!p.softplus) { dt = raw; sg = 1.f; }
-                float gg = fg[k], gz = 0.f;
+                float gg = fg[j], z_ = 0.f;
                 if (has_z) {
-                    const float sz = sigmoidf_(fz[k]);
-                    gz = fg[k] * sz * (1.f + fz[k] * (1.f - sz)) * fy[k];  // dz = dy * d/dz [z sigmoid(z)] * (hs.C + D*u)
-                    gg = fg[k] * fz[k] * sz;
+                    const float sz = sigmoidf_(fz[j]);
+                    z_ = fg[j] * sz * (1.f + fz[j] * (1.f - sz)) * fy[j];      // dz = dy * d/dz [z sigmoid(z)] * (hs.C + D*u)
+                    gg = fg[j] * fz[j] * sz;
                 }
-                if (!valid) { dt = 0.f; sg = 0.f; gg = 0.f; gz = 0.f; }
-                const int ix = dts_index(4 * sc + k, sr);
-                tl.dt[ix] = dt;
-                if (!STATE_ONLY) tl.dtu[ix] = dt * fu[k];
-                tl.g[ix] = gg;
-                vu[k] = fu[k]; vdt[k] = dt; vsg[k] = sg; vg[k] = gg; vgz[k] = gz;
+                S.u[j] = fu[j]; S.dt[j] = valid ? dt : 0.f; S.sg[j] = valid ? sg : 0.f; S.g[j] = valid ? gg : 0.f; gz[j] = z_;
             }
-            if (!STATE_ONLY) {
-                *reinterpret_cast<f4*>(&tl.eu[sr * EPS + 4 * sc]) = vu;
-                *reinterpret_cast<f4*>(&tl.edt[sr * EPS + 4 * sc]) = vdt;
-                *reinterpret_cast<f4*>(&tl.esg[sr * EPS + 4 * sc]) = vsg;
-                *reinterpret_cast<f4*>(&tl.eg[sr * EPS + 4 * sc]) = vg;
-                if (has_z && valid) *reinterpret_cast<V4*>((T*)p.dz + zbase + (size_t)(tb - t0 + sr) * p.ld_z) = Vec4<T>::pack(vgz);   // finished here
-            }
-            float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (tid < 128 ? 0 : 2);
-            if (!STATE_ONLY || tid >= 128) {
-                const f4 v = bc_rows(tb);
+            f2* ddp = reinterpret_cast<f2*>(&tl.dd[(sr >> 1) * CB]) + (sr & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ddp[2 * dd_slot(4 * sc + j)] = f2{S.dt[j], S.dt[j] * fu[j]};
+            *reinterpret_cast<f4*>(&tl.g[sr * CB + 4 * sc]) = S.g;
+            if (!STATE_ONLY) R::st(gz, rs_dz, off_z + (unsigned)(k * TT) * rowbz);        // finished here (no gate / row past the end: dropped)
+            if (!STATE_ONLY || !isB) {
+                const f4 v = RBC::unpack(rbc);
+                float* bcp = reinterpret_cast<float*>(&tl.bc[br * 8 + 2 * bq]) + (isB ? 0 : 2);
                 *reinterpret_cast<f2*>(bcp) = f2{v.x, v.y};
                 *reinterpret_cast<f2*>(bcp + 4) = f2{v.z, v.w};
             }
         };
-        // ---- rows out, and the block's dB / dC rows, of the segment that starts at step tb.  Wave w folds the 16 partial slabs for steps
-        // 8w .. 8w+7 with ds_read_b128, writes the sums back as rows of 32 (its own rows: no barrier, only its own lgkmcnt) and adds them to
-        // memory as contiguous 64-lane atomics -- two steps x (16 dB | 16 dC) per instruction, the access shape float atomics run at full rate on.
-        auto drain = [&](int tb) {
-            const int r = tb - t0 + sr;
-            if (r < nrows) {
-                const size_t off = rowbase + (size_t)r * p.ED;
-                *reinterpret_cast<V4*>((T*)p.du + off) = *reinterpret_cast<const V4*>(&otile[0][sr * EPS + 4 * sc]);
-                *reinterpret_cast<V4*>((T*)p.ddelta + off) = *reinterpret_cast<const V4*>(&otile[1][sr * EPS + 4 * sc]);
+        // ---- the outputs of segment k: du / ddelta rows from the four partial rows, and the block's dB / dC rows: wave w folds the 16 slabs
+        // for steps 8w .. 8w+7 with ds_read_b128, writes the sums back as rows of 32 (its own rows: no barrier, only its own lgkmcnt) and adds
+        // them to memory as contiguous 64-lane atomics -- two steps x (16 dB | 16 dC) per instruction, the access shape float atomics run at
+        // full rate on (DET: plain stores of the block's partial rows instead).
+        auto drain = [&](int k, const Keep& S) {
+            const f4* pp = reinterpret_cast<const f4*>(&part[sr * 4 * PB + 4 * sc]);
+            f4 s0 = pp[0], s1 = pp[1];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) { s0 += pp[q * (PB / 2)]; s1 += pp[q * (PB / 2) + 1]; }
+            const f4 ddtu = f4{s0.x, s0.z, s1.x, s1.z}, ddtA = f4{s0.y, s0.w, s1.y, s1.w};
+            f4 du, dd;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                du[j] = fmaf(ddtu[j], S.dt[j], sD[j] * S.g[j]);
+                dd[j] = fmaf(ddtu[j], S.u[j], ddtA[j]) * S.sg[j];
+                dDacc[j] = fmaf(S.g[j], S.u[j], dDacc[j]);
+                dbacc[j] += dd[j];
             }
+            const unsigned off = off_e + (unsigned)(k * TT) * rowb;
+            R::st(du, rs_du, off);
+            R::st(dd, rs_dd, off);
             const int ts = 8 * w + (lane >> 3), jq = (lane & 7) * 4;
             f4 acc = *reinterpret_cast<const f4*>(&red[ts * 32 + jq]);
 #pragma unroll
-            for (int k = 1; k < 16; ++k) acc += *reinterpret_cast<const f4*>(&red[k * RSL + ts * 32 + jq]);
+            for (int q = 1; q < 16; ++q) acc += *reinterpret_cast<const f4*>(&red[q * RSL + ts * 32 + jq]);
             *reinterpret_cast<f4*>(&red[ts * 32 + jq]) = acc;          // slab 0, this wave's rows only
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int v = lane + 64 * i, t2 = 8 * w + (v >> 5), j = v & 31;
                 const float sum = red[t2 * 32 + j];
-                if (tb + t2 < t1) {
-                    if (p.part_bc) p.part_bc[(((size_t)b * gridDim.x + blockIdx.x) * p.L + tb + t2) * 32 + j] = sum;
-                    else atomicAdd((j < 16 ? p.dBws : p.dCws) + ((size_t)b * p.L + tb + t2) * p.ld_dbc + (j & 15), sum);
-                }
+                const int row = k * TT + t2;
+                if (DET) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), rs_pbc, (unsigned)(row * 32 + j) * 4u, 0, 0);
+                else atomicAdd((j < 16 ? p.dBws : p.dCws) + (row0 + min(row, nrows - 1)) * p.ld_dbc + (j & 15), row < nrows ? sum : 0.f);
             }
         };
 
-        fetch(t0 + (nsegc - 1) * TT);
-        park(stg[0], t0 + (nsegc - 1) * TT);
-        if (nsegc > 1) fetch(t0 + (nsegc - 2) * TT);
-        lds_barrier();                                                   // A_0
-        for (int k = nsegc - 1, i = 0; k >= 0; --k, ++i) {
-            const int tb = t0 + k * TT;
-            if (!STATE_ONLY) {
-                if (i > 0) drain(tb + TT);
-                lds_barrier();                                           // B_i
+        if (STATE_ONLY) {
+            Keep S;
+            fetch(K - 1);
+            park(K - 1, stg[0], S);
+            fetch(K - 2);
+            lds_barrier();
+            for (int k = K - 1, i = 0; k >= 0; --k, ++i) {
+                park(k - 1, stg[(i + 1) & 1], S);
+                fetch(k - 2);
+                lds_barrier();
             }
-            if (k > 0) {
-                park(stg[(i + 1) & 1], tb - TT);
-                if (k > 1) fetch(tb - 2 * TT);
-            }
-            lds_barrier();                                               // A_{i+1}
+            return;
         }
-        if (!STATE_ONLY) drain(t0);
+        Keep s0, s1;
+        fetch(K - 1);
+        park(K - 1, stg[0], s1);
+        fetch(K - 2);
+        lds_barrier();                                                   // A_0
+        lds_barrier();                                                   // B_0 (iteration 0: nothing to drain)
+        park(K - 2, stg[1], s0);
+        fetch(K - 3);
+        lds_barrier();                                                   // A_1
+        for (int i = 1; i < K; i += 2) {                                 // iteration i: the scan waves are on segment K-1-i
+            drain(K - i, s1);
+            lds_barrier();                                               // B_i
+            park(K - 2 - i, stg[(i + 1) & 1], s1);
+            fetch(K - 3 - i);
+            lds_barrier();                                               // A_{i+1}
+            if (i + 1 < K) {
+                drain(K - 1 - i, s0);
+                lds_barrier();
+                park(K - 3 - i, stg[i & 1], s0);
+                fetch(K - 4 - i);
+                lds_barrier();
+            }
+        }
+        if (K & 1) drain(0, s1); else drain(0, s0);
+        // dD / dbias: this lane's sums over its rows of every segment; the 32 row lanes of a channel quad meet in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_barrier();                                                   // (every wave's last fold is done with `red`)
+        *reinterpret_cast<f4*>(&red[sr * CB + 4 * sc]) = dDacc;
+        *reinterpret_cast<f4*>(&red[TT * CB + sr * CB + 4 * sc]) = dbacc;
+        lds_barrier();
+        if (tid < 2 * CB) {
+            const int ch = tid & (CB - 1), which = tid >> 5;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TT; ++r) s += red[which * TT * CB + r * CB + ch];
+            if (DET) p.part_vec[((size_t)b * p.nchunks + c) * ((size_t)p.ED * 18) + (size_t)p.ED * (16 + which) + e0 + ch] = s;
+            else {
+                float* dst = which ? p.dbiasws : p.dDws;
+                if (dst) atomicAdd(dst + e0 + ch, s);
+            }
+        }
         return;
     }
 
@@ -604,136 +671,142 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     f2 An = f2{p.A[(size_t)e * 16 + 2 * pr], p.A[(size_t)e * 16 + 2 * pr + 1]};
     if (p.a_log) An = f2{-fast_exp2(An.x * GFE_LOG2E), -fast_exp2(An.y * GFE_LOG2E)};       // A = -exp(A_log)
     const f2 A2 = An * GFE_LOG2E;
-    const float Dv = p.D ? p.D[e] : 0.f;
     const size_t sbase = (((size_t)b * p.nchunks + c) * p.ED + e) * 16 + 2 * pr;
     f2 q = f2{0.f, 0.f};
     if (!STATE_ONLY && p.nchunks > 1) q = chunk_carry<true>(p.qstate, p.sdelta, A2, b, c, e, pr, p.nchunks, p.ED);
     f2 dAacc = f2{0.f, 0.f};
-    float dDacc = 0.f, dbacc = 0.f;
     // the segment's start state: fetched one segment ahead (wanted by the very first instruction of phase 1: an HBM round trip there
     // cost 1 300 cycles per segment)
     const float* __restrict__ pck = STATE_ONLY ? nullptr : p.ckpt + (((size_t)b * p.nseg + t0 / SEG) * p.ED + e) * 16 + 2 * pr;
     const size_t ckstride = (size_t)p.ED * 16;
     f2 hck_next = f2{0.f, 0.f};
-    if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(nsegc - 1) * ckstride);
+    if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(K - 1) * ckstride);
+    float* redp = &red[STATE_ONLY ? 0 : (w * 4 + (lane & 3)) * RSL + (lane >> 5) * 16 + 2 * pr];
+    f2* partp = &part[STATE_ONLY ? 0 : (((lane >> 4) & 1) * 4 + ((lane >> 2) & 3)) * PB + cl];
     lds_barrier();                                                       // A_0
     S2_STAMP_DECL
-    for (int k = nsegc - 1, i = 0; k >= 0; --k, ++i) {
-        const BStage& tl = stg[i & 1];
+    for (int k = K - 1, i = 0; k >= 0; --k, ++i) {
+        const BTile& tl = stg[i & 1];
+        const f4* ddp = &tl.dd[dd_slot(cl)];
+        const float* gp = &tl.g[cl];
+        const f4* bcp = &tl.bc[pr];
         S2_STAMP(2)
         const f2 hck = hck_next;
         if (k > 0 && !STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(k - 1) * ckstride);
         S2_STAMP(7)
 
+        // Work unit = 4 steps; as in the forward, the LDS reads of the NEXT unit are issued in front of the current unit's arithmetic
+        // (two register sets X / Y by unit parity, pinned with sched_barrier).
+        struct H4 { f4 dd[2]; f4 bc[4]; float g[4]; };
+        auto load_u = [&](H4& H, int u, bool with_g) {
+            H.dd[0] = ddp[(2 * u) * CB]; H.dd[1] = ddp[(2 * u + 1) * CB];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) H.bc[s] = bcp[(4 * u + s) * 8];
+            if (with_g) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) H.g[s] = gp[(4 * u + s) * CB];
+            }
+        };
+#define SB __builtin_amdgcn_sched_barrier(0)
         if (STATE_ONLY) {
+            H4 X, Y;
+            auto adj_u = [&](const H4& H) {
+                f2 a[4];
 #pragma unroll
-            for (int j4 = TT / 4 - 1; j4 >= 0; --j4) {
-                const f4 dt4 = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 4 * j4)]);
-                const f4 g4 = *reinterpret_cast<const f4*>(&tl.g[dts_index(cl, 4 * j4)]);
-#pragma unroll
-                for (int s = 3; s >= 0; --s) {
-                    const f4 bc = tl.bc[(4 * j4 + s) * 8 + pr];
-                    const f2 x = A2 * dt4[s];
-                    const f2 a = f2{fast_exp2(x.x), fast_exp2(x.y)};
-                    q = a * (f2{bc.z, bc.w} * g4[s] + q);
+                for (int s = 0; s < 4; ++s) {
+                    const f2 x = A2 * H.dd[s >> 1][2 * (s & 1)];
+                    a[s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
                 }
+#pragma unroll
+                for (int s = 3; s >= 0; --s) q = a[s] * __builtin_elementwise_fma(f2{H.bc[s].z, H.bc[s].w}, f2{H.g[s], H.g[s]}, q);
+            };
+            load_u(X, TT / 4 - 1, true);
+#pragma unroll
+            for (int u = TT / 4 - 1; u >= 0; u -= 2) {
+                load_u(Y, u - 1, true); SB;
+                adj_u(X); SB;
+                if (u - 2 >= 0) load_u(X, u - 2, true);
+                SB;
+                adj_u(Y); SB;
             }
             lds_barrier();                                               // A_{i+1}
             continue;
         }
 
-        // ---- phase 1: the segment's states, forward from the checkpoint; phase 2: the adjoint, last step first.
-        // Work unit = 4 steps.  As in the forward, the LDS reads of the NEXT unit are issued ahead of the current unit's arithmetic:
-        // two register sets X / Y by unit parity, pinned with sched_barrier.
         f2 av[TT], hs[TT];
-        struct H4 { f4 dt4, du4, g4, bc[4]; };
-        auto load_u = [&](H4& H, int qd) {
-            H.dt4 = *reinterpret_cast<const f4*>(&tl.dt[dts_index(cl, 4 * qd)]);
-            H.du4 = *reinterpret_cast<const f4*>(&tl.dtu[dts_index(cl, 4 * qd)]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) H.bc[s] = tl.bc[(4 * qd + s) * 8 + pr];
-        };
-        auto load_g = [&](H4& H, int qd) { H.g4 = *reinterpret_cast<const f4*>(&tl.g[dts_index(cl, 4 * qd)]); };
         f2 h = hck;
-        auto fwd_u = [&](const H4& H, int qd) {
+        auto fwd_u = [&](const H4& H, int u) {
+            f2 xb[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int t = 4 * qd + s;
-                const f4 bc = H.bc[s];
-                const f2 x = A2 * H.dt4[s];
-                av[t] = f2{fast_exp2(x.x), fast_exp2(x.y)};
-                h = av[t] * h + f2{bc.x, bc.y} * H.du4[s];
-                hs[t] = h;
+                const float dtv = H.dd[s >> 1][2 * (s & 1)], dtu = H.dd[s >> 1][2 * (s & 1) + 1];
+                const f2 x = A2 * dtv;
+                av[4 * u + s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
+                xb[s] = f2{H.bc[s].x, H.bc[s].y} * dtu;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                h = __builtin_elementwise_fma(av[4 * u + s], h, xb[s]);
+                hs[4 * u + s] = h;
             }
         };
-        struct Own { float u, dt, sg, g; };
-        auto load_own = [&](Own& O, int g8) {
-            const int r = 8 * g8 + pr;
-            O.u = tl.eu[r * EPS + cl]; O.dt = tl.edt[r * EPS + cl]; O.sg = tl.esg[r * EPS + cl]; O.g = tl.eg[r * EPS + cl];
-        };
-        float ddtu_p[8], ddt_p[8];
-        auto bwd_u = [&](const H4& H, const Own& O, int qd) {
+        auto bwd_u = [&](const H4& H, int u) {
+            f2 pu[4];                                                      // this lane's {d(dt*u), d dt} share of the unit's steps
 #pragma unroll
             for (int s = 3; s >= 0; --s) {
-                const int t = 4 * qd + s;
+                const int t = 4 * u + s;
                 const f4 bc = H.bc[s];
                 const f2 Bv = f2{bc.x, bc.y}, Cv = f2{bc.z, bc.w};
-                const float gt = H.g4[s], dtv = H.dt4[s], dtu = H.du4[s];
-                const f2 dh = Cv * gt + q;
+                const float gt = H.g[s], dtv = H.dd[s >> 1][2 * (s & 1)], dtu = H.dd[s >> 1][2 * (s & 1) + 1];
+                const f2 dh = __builtin_elementwise_fma(Cv, f2{gt, gt}, q);
                 const f2 dC = hs[t] * gt;
                 const f2 dB = dh * dtu;
-                ddtu_p[4 * (qd & 1) + s] = fmaf(dh.y, Bv.y, dh.x * Bv.x);
+                const float ddtu_p = fmaf(dh.y, Bv.y, dh.x * Bv.x);
                 const f2 hp = (t == 0) ? hck : hs[t == 0 ? 0 : t - 1];
                 q = av[t] * dh;
                 const f2 da = q * hp;                                      // dL/d(dt*A) of this (t, pair) = dh * a * h_{t-1}
-                dAacc += da * dtv;
-                ddt_p[4 * (qd & 1) + s] = fmaf(da.y, An.y, da.x * An.x);
+                dAacc = __builtin_elementwise_fma(da, f2{dtv, dtv}, dAacc);
+                pu[s] = f2{ddtu_p, fmaf(da.y, An.y, da.x * An.x)};
                 // dB / dC sum over channels.  In the wave: v_permlane32_swap pairs dB with dC (lanes < 32 end up with the dB sum over lane
                 // bit 5, lanes >= 32 with the dC sum).  The remaining 4 (channel & 3) x 4 (wave) partials are folded by the staging waves from
                 // LDS: every lane stores, so there is no exec masking and no basic-block break inside the unrolled steps.
-                // (ds_add_f32 into one shared row instead was 15x slower: ~900 cycles per instruction with 4 lanes per address.)
                 const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.x), __float_as_uint(dC.x), false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.y), __float_as_uint(dC.y), false, false);
-                *reinterpret_cast<f2*>(&red[(w * 4 + (lane & 3)) * RSL + t * 32 + (lane >> 5) * 16 + 2 * pr]) =
-                    f2{__uint_as_float(sx[0]) + __uint_as_float(sx[1]), __uint_as_float(sy[0]) + __uint_as_float(sy[1])};
+                *reinterpret_cast<f2*>(redp + t * 32) = f2{__uint_as_float(sx[0]) + __uint_as_float(sx[1]), __uint_as_float(sy[0]) + __uint_as_float(sy[1])};
             }
-            if ((qd & 1) == 0) {                                           // group complete: the lane that owns (step r, channel cl) finishes it
-                const float ddtu = reduce_pairs8(ddtu_p);
-                const float ddtA = reduce_pairs8(ddt_p);
-                const int r = 4 * qd + pr;
-                const float dd = fmaf(ddtu, O.u, ddtA) * O.sg;
-                IO<T>::st(&otile[0][r * EPS + cl], fmaf(ddtu, O.dt, Dv * O.g));
-                IO<T>::st(&otile[1][r * EPS + cl], dd);
-                dDacc = fmaf(O.g, O.u, dDacc);
-                dbacc += dd;
+#pragma unroll
+            for (int s2 = 1; s2 >= 0; --s2) {                              // steps 4u + 2*s2 (even rows of lanes keep it) and + 1 (odd rows)
+                const auto ux = __builtin_amdgcn_permlane16_swap(__float_as_uint(pu[2 * s2].x), __float_as_uint(pu[2 * s2 + 1].x), false, false);
+                const auto uy = __builtin_amdgcn_permlane16_swap(__float_as_uint(pu[2 * s2].y), __float_as_uint(pu[2 * s2 + 1].y), false, false);
+                partp[(4 * u + 2 * s2) * 4 * PB] = f2{__uint_as_float(ux[0]) + __uint_as_float(ux[1]), __uint_as_float(uy[0]) + __uint_as_float(uy[1])};
             }
         };
-#define SB __builtin_amdgcn_sched_barrier(0)
         {
             H4 X, Y;
-            Own oa, ob;
-            load_u(X, 0); SB;
-            load_u(Y, 1); SB; fwd_u(X, 0); SB;
-            load_u(X, 2); SB; fwd_u(Y, 1); SB;
-            load_u(Y, 3); SB; fwd_u(X, 2); SB;
-            load_u(X, 4); SB; fwd_u(Y, 3); SB;
-            S2_STAMP(8)
-            load_u(Y, 5); SB; fwd_u(X, 4); SB;
-            load_u(X, 6); SB; fwd_u(Y, 5); SB;
-            load_u(Y, 7); load_g(Y, 7); SB; fwd_u(X, 6); SB;
-            load_g(X, 6); load_own(oa, 3); SB; fwd_u(Y, 7); SB;
+            load_u(X, 0, false); SB;
+#pragma unroll
+            for (int u = 0; u < TT / 4; u += 2) {
+                load_u(Y, u + 1, u + 1 == TT / 4 - 1); SB;
+                fwd_u(X, u); SB;
+                if (u + 2 < TT / 4) load_u(X, u + 2, false);
+                SB;
+                if (u + 1 < TT / 4 - 1) { fwd_u(Y, u + 1); SB; }
+            }
+            // (the last unit's arithmetic follows the load of the adjoint's second unit: keep reads in flight across the phase change)
+            load_u(X, TT / 4 - 2, true); SB;
+            fwd_u(Y, TT / 4 - 1); SB;
             S2_STAMP(3)
-            lds_barrier();                                               // B_i: the previous segment's red / otile have been drained
+            lds_barrier();                                               // B_i: the previous segment's red / part have been drained
             SB;
-            bwd_u(Y, oa, 7); SB;
-            load_u(Y, 5); load_g(Y, 5); SB; bwd_u(X, oa, 6); SB;
-            load_u(X, 4); load_g(X, 4); load_own(ob, 2); SB; bwd_u(Y, ob, 5); SB;
-            load_u(Y, 3); load_g(Y, 3); SB; bwd_u(X, ob, 4); SB;
-            S2_STAMP(9)
-            load_u(X, 2); load_g(X, 2); load_own(oa, 1); SB; bwd_u(Y, oa, 3); SB;
-            load_u(Y, 1); load_g(Y, 1); SB; bwd_u(X, oa, 2); SB;
-            load_u(X, 0); load_g(X, 0); load_own(ob, 0); SB; bwd_u(Y, ob, 1); SB;
-            bwd_u(X, ob, 0);
+#pragma unroll
+            for (int u = TT / 4 - 1; u >= 0; u -= 2) {
+                bwd_u(Y, u); SB;
+                if (u - 2 >= 0) load_u(Y, u - 2, true);
+                SB;
+                bwd_u(X, u - 1); SB;
+                if (u - 3 >= 0) load_u(X, u - 3, true);
+                SB;
+            }
         }
 #undef SB
         S2_STAMP(4)
@@ -745,23 +818,15 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         *reinterpret_cast<f2*>(p.qstate + sbase) = q;
         return;
     }
+    lds_barrier(); lds_barrier();                                        // (the staging waves' dD / dbias sums)
     if (p.a_log) dAacc *= An;                                            // d/dA_log = dA * dA/dA_log = dA * A
-    // dD / dbias: the 8 owner lanes of a channel (pair bits 2, 3, 4) hold partial sums over their steps
-    dDacc += __shfl_xor(dDacc, 4, 64); dbacc += __shfl_xor(dbacc, 4, 64);
-    dDacc += __shfl_xor(dDacc, 8, 64); dbacc += __shfl_xor(dbacc, 8, 64);
-    dDacc += __shfl_xor(dDacc, 16, 64); dbacc += __shfl_xor(dbacc, 16, 64);
-    if (p.part_vec) {                                                    // this (sample, chunk)'s row of partials: plain stores, summed in order later
+    if (DET) {                                                           // this (sample, chunk)'s row of partials: plain stores, summed in order later
         float* pv = p.part_vec + ((size_t)b * p.nchunks + c) * ((size_t)p.ED * 18);
         *reinterpret_cast<f2*>(pv + (size_t)e * 16 + 2 * pr) = dAacc;
-        if (pr == 0) { pv[(size_t)p.ED * 16 + e] = dDacc; pv[(size_t)p.ED * 17 + e] = dbacc; }
         return;
     }
     atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr, dAacc.x);
     atomicAdd(p.dAws + (size_t)e * 16 + 2 * pr + 1, dAacc.y);
-    if (pr == 0) {
-        if (p.dDws) atomicAdd(p.dDws + e, dDacc);
-        if (p.dbiasws) atomicAdd(p.dbiasws + e, dbacc);
-    }
 }
 
 // Fixed-order sums of the backward's partials (S2Bwd::part_vec / part_bc).  Blocks [0, nb_vec): dA / dD / dbias += sum over the (sample,
@@ -794,17 +859,22 @@ __global__ __launch_bounds__(256) void sscan2_fold_kernel(const S2Bwd p, int nb_
     (j < 16 ? p.dBws : p.dCws)[(size_t)bt * p.ld_dbc + (j & 15)] = (s0 + s1) + (s2 + s3);
 }
 
-template <typename T>
-int sscan2_bwd_launch(const S2Bwd& p, hipStream_t st) {
+template <typename T, typename TBC, bool DET>
+int sscan2_bwd_launch3(const S2Bwd& p, hipStream_t st) {
     const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
-    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_bwd_kernel<T, true>), grid, blk, 0, st, p);      // local adjoint carries of every chunk
-    hipLaunchKernelGGL((sscan2_bwd_kernel<T, false>), grid, blk, 0, st, p);
-    if (p.part_vec) {
+    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_bwd_kernel<T, TBC, true, false>), grid, blk, 0, st, p);      // local adjoint carries of every chunk
+    hipLaunchKernelGGL((sscan2_bwd_kernel<T, TBC, false, DET>), grid, blk, 0, st, p);
+    if (DET) {
         const int nb_vec = (int)ceil_div((int64_t)p.ED * 18, 256);
         const int64_t nb_bc = ceil_div((int64_t)p.B * p.L * 32, 256);
         hipLaunchKernelGGL(sscan2_fold_kernel, dim3((unsigned)(nb_vec + nb_bc)), dim3(256), 0, st, p, nb_vec, p.ED / CB);
     }
     return gfe_launch_status();
+}
+template <typename T>
+int sscan2_bwd_launch(const S2Bwd& p, hipStream_t st) {
+    if (p.part_vec) return p.bc_bf16 ? sscan2_bwd_launch3<T, bf16_t, true>(p, st) : sscan2_bwd_launch3<T, float, true>(p, st);
+    return p.bc_bf16 ? sscan2_bwd_launch3<T, bf16_t, false>(p, st) : sscan2_bwd_launch3<T, float, false>(p, st);
 }
 
 }  // namespace
@@ -841,6 +911,7 @@ int gfe_sscan2_fwd(const void* u, const void* delta, const float* A, const void*
     if (ld_bc <= 0) ld_bc = 16;
     GFE_REQUIRE(ld_z >= ED && ld_z % 4 == 0 && ld_bc >= 16 && ld_bc % 4 == 0 && ld_z <= 0x7fffffff && ld_bc <= 0x7fffffff, GFE_ERR_SHAPE);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
+    GFE_REQUIRE((L + 4 * TT) * (ld_z > ED ? ld_z : ED) * 4 < ((int64_t)1 << 32) && (L + 4 * TT) * ld_bc * 4 < ((int64_t)1 << 32), GFE_ERR_SHAPE);   // 32-bit row offsets inside a chunk (buffer addressing)
     S2Fwd p;
     p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.A = A; p.D = D; p.dbias = delta_bias; p.y = y; p.yscan = yscan;
     p.hstate = hstate; p.sdelta = sdelta; p.ckpt = ckpt;
@@ -872,6 +943,7 @@ int gfe_sscan2_bwd(const void* u, const void* delta, const float* A, const void*
     GFE_REQUIRE((part_vec == nullptr) == (part_bc == nullptr), GFE_ERR_NULL);
     GFE_REQUIRE(B > 0 && L > 0 && ED > 0 && T > 0 && ED % CB == 0 && B <= 65535, GFE_ERR_SHAPE);
     GFE_REQUIRE(!part_vec || (B * L * 32 <= 0x7fffffff * (int64_t)256 && ED * 18 <= 0x7fffffff), GFE_ERR_SHAPE);
+    GFE_REQUIRE((L + 4 * TT) * (ld_z > ED ? ld_z : ED) * 4 < ((int64_t)1 << 32) && (L + 4 * TT) * ld_bc * 4 < ((int64_t)1 << 32), GFE_ERR_SHAPE);   // 32-bit row offsets inside a chunk (buffer addressing)
     S2Bwd p;
     p.part_vec = part_vec; p.part_bc = part_bc;
     p.u = u; p.delta = delta; p.z = z; p.Bm = Bm; p.Cm = Cm; p.dy = dy; p.yscan = yscan; p.A = A; p.D = D; p.dbias = delta_bias;
