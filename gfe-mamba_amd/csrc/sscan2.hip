@@ -209,8 +209,17 @@ template <> struct Row4<bf16_t> {
     static __device__ __forceinline__ raw zero() { return raw{0u, 0u}; }
 };
 
-constexpr int PS = 36;           // row stride (floats) of the per-pair partial rows: 32 channels + 4, so that the 8 pair rows of a step start on
-                                 // banks 0, 4, .. 28 (scan waves: conflict-free ds_write_b32; staging waves: conflict-free ds_read_b128)
+// a * b.y for a register pair b: hipcc selects the op_sel form for element 1 of a pair it loaded as such, but moves element 3 of a 16-byte
+// LDS fragment into a fresh register first (one v_mov per odd step)
+__device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+constexpr int PS = 40;           // row stride (floats) of the per-pair partial rows: 32 channels + 8: a step's 8 rows are 1280 B = 5 x 256 B, so the partials
+                                 // of two steps leave as ONE ds_write2st64_b32 (pair rows p and p+4 share banks: 2-way, free on a 4-byte store; the staging
+                                 // waves' ds_read_b128 of two steps' rows collide 2-way too: 8 reads per lane and tile)
 constexpr int YP_TILE = TT * 8 * PS;
 
 // LDS image of one 32-step tile as the scan waves read it
@@ -238,7 +247,7 @@ template <typename T, typename TBC, bool STATE_ONLY>
 __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     typedef Row4<T> R;
     typedef Row4<TBC> RBC;
-    __shared__ __attribute__((aligned(16))) FTile tiles[2];
+    __shared__ __attribute__((aligned(16))) FTile tiles[3];     // a ring of three: tile k+1 is complete one barrier BEFORE the scan waves finish tile k, so they read its first steps ahead of the barrier
     __shared__ __attribute__((aligned(16))) float ypart[STATE_ONLY ? TT * CB : 2 * YP_TILE];   // STATE_ONLY: the staging lanes' sums of dt on their way to sdelta
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
     const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
@@ -282,10 +291,10 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
             if (!STATE_ONLY) rz = R::ld(rs_z, off_z + kr * rowbz);
             if (!STATE_ONLY || isB) rbc = RBC::ld(rs_bc, off_bc + kr * rowbbc);
         };
-        auto park = [&](int k, Keep& K) {                             // registers -> LDS; the per-(t, channel) math happens once, here
+        auto park = [&](int k, int buf, Keep& K) {                    // registers -> LDS (tiles[buf], buf = k mod 3); the per-(t, channel) math happens once, here
             const f4 fu = R::unpack(ru), fd = R::unpack(rd), fz = R::unpack(rz);
             const bool valid = k * TT + sr < nrows;
-            FTile& tl = tiles[k & 1];
+            FTile& tl = tiles[buf];
             float dt[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -317,28 +326,37 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
             R::st(yb * K.gate, rs_y, off);
             R::st(yb, rs_ys, off);                                    // (no yscan: zero-sized resource, the store is dropped)
         };
-        Keep k0, k1;
+        Keep k0, k1, k2;                                              // tile j <-> set j mod 3 <-> tiles[j mod 3]
         fetch(0);
-        park(0, k0);
+        park(0, 0, k0);
         fetch(1);
-        lds_barrier();                                                // tile 0 is ready
-        park(1, k1);                                                  // iteration 0: nothing to finish yet
+        park(1, 1, k1);
         fetch(2);
+        lds_barrier();                                                // tiles 0 and 1 are ready
+        park(2, 2, k2);                                               // iteration 0: nothing to finish yet
+        fetch(3);
         lds_barrier();
-        for (int k = 1; k < nt; k += 2) {                             // iteration k: the scan waves are on tile k
+        for (int k = 1; k < nt; k += 3) {                             // iteration k: the scan waves are on tile k; finish k-1, park k+2, fetch k+3
             if (!STATE_ONLY) finish(k - 1, k0);
-            park(k + 1, k0);
-            fetch(k + 2);
+            park(k + 2, 0, k0);
+            fetch(k + 3);
             lds_barrier();
             if (k + 1 < nt) {
                 if (!STATE_ONLY) finish(k, k1);
-                park(k + 2, k1);
-                fetch(k + 3);
+                park(k + 3, 1, k1);
+                fetch(k + 4);
+                lds_barrier();
+            }
+            if (k + 2 < nt) {
+                if (!STATE_ONLY) finish(k + 1, k2);
+                park(k + 4, 2, k2);
+                fetch(k + 5);
                 lds_barrier();
             }
         }
         if (!STATE_ONLY) {
-            if (nt & 1) finish(nt - 1, k0); else finish(nt - 1, k1);
+            const int r3 = (nt - 1) % 3;
+            if (r3 == 0) finish(nt - 1, k0); else if (r3 == 1) finish(nt - 1, k1); else finish(nt - 1, k2);
         } else {
             *reinterpret_cast<f4*>(&ypart[sr * CB + 4 * sc]) = sdt;
             lds_barrier();
@@ -367,49 +385,67 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     float* ckp = p.ckpt + ((((size_t)b * p.nseg + t0 / SEG) * p.ED + e) * 16 + 2 * pr);
     const size_t ckstride = (size_t)p.ED * 16;
     lds_barrier();
+    constexpr int LD = 6;
+    f4 ddr[TT / 2], bcr[TT];
+    int kb = 0;                                                      // k mod 3
+    auto head_reads = [&](int buf) {                                 // LDS reads of a tile's first LD + 2 steps
+        const f4* ddp = &tiles[buf].dd[dd_slot(cl)];
+        const f4* bcp = &tiles[buf].bc[pr];
+#pragma unroll
+        for (int t = 0; t < LD + 2; ++t) {
+            if ((t & 1) == 0) ddr[t >> 1] = ddp[(t >> 1) * CB];
+            bcr[t] = bcp[t * 8];
+        }
+    };
+    head_reads(0);
     S2_STAMP_DECL
     for (int k = 0; k < nt; ++k) {
         S2_STAMP(0)
         if (do_ck) { *reinterpret_cast<f2*>(ckp) = h; ckp += ckstride; }     // every tile starts a segment (t0 is a multiple of SEG)
-        const f4* ddp = &tiles[k & 1].dd[dd_slot(cl)];
-        const f4* bcp = &tiles[k & 1].bc[pr];
+        const f4* ddp = &tiles[kb].dd[dd_slot(cl)];
+        const f4* bcp = &tiles[kb].bc[pr];
         float* yp = &ypart[STATE_ONLY ? 0 : (k & 1) * YP_TILE + pr * PS + cl];
-        // Work unit = 4 steps; the LDS reads of the NEXT unit are issued in front of the current unit's arithmetic (two register sets, pinned
-        // with sched_barrier): nothing hides an LDS round trip of the dependent chain but the wave's own instruction stream.
-        struct U4 { f4 dd[2]; f4 bc[4]; };
-        auto load_u = [&](U4& U, int u) {
-            U.dd[0] = ddp[(2 * u) * CB]; U.dd[1] = ddp[(2 * u + 1) * CB];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) U.bc[s] = bcp[(4 * u + s) * 8];
-        };
-        auto step_u = [&](const U4& U, int u) {
-            f2 a[4], xb[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                          // nothing here depends on h: decays and inputs of the unit first
-                const float dtv = U.dd[s >> 1][2 * (s & 1)], dtu = U.dd[s >> 1][2 * (s & 1) + 1];
-                const f2 x = A2 * dtv;
-                a[s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
-                xb[s] = f2{U.bc[s].x, U.bc[s].y} * dtu;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                h = __builtin_elementwise_fma(a[s], h, xb[s]);       // ONE dependent instruction per step (v_pk_fma_f32)
-                if (!STATE_ONLY) yp[(4 * u + s) * 8 * PS] = fmaf(h.y, U.bc[s].w, h.x * U.bc[s].z);
-            }
-        };
-        U4 ua, ub;
-        S2_STAMP(1)
-        load_u(ua, 0);
+        kb = kb == 2 ? 0 : kb + 1;
+        // The wave is ALONE with this stream for most of its life (its partner finishes a tile's staging in a third of the time), and a lone
+        // in-order wave pays the full result latency of every instruction whose operand is younger than ~4 instructions: compiled as a
+        // unit of arithmetic the tile ran at 87 cycles per step for 7 vector instructions (profiles/r06/scan_ablation.txt).  So the tile is
+        // written as a software pipeline over steps, one instruction per statement, the order pinned with sched_barrier:
+        //   step t+LD: LDS reads   t+2: x = A dt, xb = B dt u   t+1: a = exp2(x)   t: h = a h + xb   t-1: p = C . h   t-2: p -> LDS
+        // so that every operand was produced at least four instructions earlier (h alternates between two register pairs).
+        f2 xr[2], ar[2], xbr[3], hr[2];
+        float pp[4];
+        hr[1] = h;                                                   // h[-1]
 #define SB __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-        for (int u = 0; u < TT / 4; u += 2) {
-            load_u(ub, u + 1); SB;
-            step_u(ua, u); SB;
-            if (u + 2 < TT / 4) load_u(ua, u + 2);
+        for (int t = -2; t < TT + 2; ++t) {
+            if (!STATE_ONLY && t - 1 >= 0 && t - 1 < TT) { pp[(t + 3) & 3] = hr[(t + 1) & 1].x * bcr[t - 1].z; SB; }
+            if (t + 2 < TT) { const f4 d = ddr[(t + 2) >> 1]; xr[t & 1] = A2 * (((t + 2) & 1) ? d.z : d.x); SB; }
+            if (t + 1 >= 0 && t + 1 < TT) { ar[(t + 1) & 1].x = fast_exp2(xr[(t + 1) & 1].x); SB; }
+            if (t >= 0 && t < TT) { hr[t & 1] = __builtin_elementwise_fma(ar[t & 1], hr[(t + 1) & 1], xbr[(t + 3) % 3]); SB; }
+            if (!STATE_ONLY && t - 1 >= 0 && t - 1 < TT) { pp[(t + 3) & 3] = fmaf(hr[(t + 1) & 1].y, bcr[t - 1].w, pp[(t + 3) & 3]); SB; }
+            if (t + 1 >= 0 && t + 1 < TT) { ar[(t + 1) & 1].y = fast_exp2(xr[(t + 1) & 1].y); SB; }
+            if (t + 2 < TT) {
+                const f4 d = ddr[(t + 2) >> 1];
+                const f2 Bv = f2{bcr[t + 2].x, bcr[t + 2].y};
+                if ((t + 2) & 1) xbr[(t + 5) % 3] = pk_mul_hi(Bv, __builtin_shufflevector(d, d, 2, 3)); else xbr[(t + 5) % 3] = Bv * d.y;
+                SB;
+            }
+            if (!STATE_ONLY && t - 2 >= 0 && ((t - 2) & 1)) { yp[(t - 3) * 8 * PS] = pp[(t + 1) & 3]; yp[(t - 2) * 8 * PS] = pp[(t + 2) & 3]; }   // steps t-3, t-2: one ds_write2st64_b32
+            if (t + LD + 2 < TT && t + LD + 2 >= LD + 2) {
+                if (((t + LD + 2) & 1) == 0) ddr[(t + LD + 2) >> 1] = ddp[((t + LD + 2) >> 1) * CB];
+                bcr[t + LD + 2] = bcp[(t + LD + 2) * 8];
+            }
             SB;
-            step_u(ub, u + 1); SB;
         }
 #undef SB
+        h = hr[(TT - 1) & 1];
+        head_reads(kb);                                              // the next tile's first steps: in flight across the barrier (that tile was complete one barrier ago)
+        if (!STATE_ONLY) {
+            // the barrier publishes this tile's partial rows: LDS operations complete in order, so "at most the head reads outstanding" means every write has landed
+            asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(LD + 2 + (LD + 2 + 1) / 2) : "memory");
+            S2_STAMP(4)
+            continue;
+        }
         S2_STAMP(2)
         lds_barrier();
         S2_STAMP(4)
@@ -733,78 +769,88 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
             continue;
         }
 
+        // Both phases are software pipelines over steps, one instruction per statement, pinned with sched_barrier (see the forward): a lone
+        // in-order wave pays the result latency of every operand younger than ~4 instructions, and nothing else runs on its SIMD for two
+        // thirds of its life.  LDS fragments live in rotating windows (8 steps of B / C / g, 4 step pairs of {dt, dt*u}), read LDB steps ahead.
         f2 av[TT], hs[TT];
-        f2 h = hck;
-        auto fwd_u = [&](const H4& H, int u) {
-            f2 xb[4];
+        constexpr int LDB = 4;
+        f4 bcw[8], ddw[4];
+        float gw[8];
+        {   // ---- phase 1: a_t, h_t of the segment.  step t+LDB+2: reads   t+2: x = A dt, xb = B dt u   t+1: a = exp2(x)   t: h = a h + xb
+            f2 xr[2], xbr[3];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float dtv = H.dd[s >> 1][2 * (s & 1)], dtu = H.dd[s >> 1][2 * (s & 1) + 1];
-                const f2 x = A2 * dtv;
-                av[4 * u + s] = f2{fast_exp2(x.x), fast_exp2(x.y)};
-                xb[s] = f2{H.bc[s].x, H.bc[s].y} * dtu;
+            for (int t = 0; t < LDB + 2; ++t) {
+                if ((t & 1) == 0) ddw[(t >> 1) & 3] = ddp[(t >> 1) * CB];
+                bcw[t & 7] = bcp[t * 8];
             }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                h = __builtin_elementwise_fma(av[4 * u + s], h, xb[s]);
-                hs[4 * u + s] = h;
-            }
-        };
-        auto bwd_u = [&](const H4& H, int u) {
-            f2 pu[4];                                                      // this lane's {d(dt*u), d dt} share of the unit's steps
-#pragma unroll
-            for (int s = 3; s >= 0; --s) {
-                const int t = 4 * u + s;
-                const f4 bc = H.bc[s];
-                const f2 Bv = f2{bc.x, bc.y}, Cv = f2{bc.z, bc.w};
-                const float gt = H.g[s], dtv = H.dd[s >> 1][2 * (s & 1)], dtu = H.dd[s >> 1][2 * (s & 1) + 1];
-                const f2 dh = __builtin_elementwise_fma(Cv, f2{gt, gt}, q);
-                const f2 dC = hs[t] * gt;
-                const f2 dB = dh * dtu;
-                const float ddtu_p = fmaf(dh.y, Bv.y, dh.x * Bv.x);
-                const f2 hp = (t == 0) ? hck : hs[t == 0 ? 0 : t - 1];
-                q = av[t] * dh;
-                const f2 da = q * hp;                                      // dL/d(dt*A) of this (t, pair) = dh * a * h_{t-1}
-                dAacc = __builtin_elementwise_fma(da, f2{dtv, dtv}, dAacc);
-                pu[s] = f2{ddtu_p, fmaf(da.y, An.y, da.x * An.x)};
-                // dB / dC sum over channels.  In the wave: v_permlane32_swap pairs dB with dC (lanes < 32 end up with the dB sum over lane
-                // bit 5, lanes >= 32 with the dC sum).  The remaining 4 (channel & 3) x 4 (wave) partials are folded by the staging waves from
-                // LDS: every lane stores, so there is no exec masking and no basic-block break inside the unrolled steps.
-                const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.x), __float_as_uint(dC.x), false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB.y), __float_as_uint(dC.y), false, false);
-                *reinterpret_cast<f2*>(redp + t * 32) = f2{__uint_as_float(sx[0]) + __uint_as_float(sx[1]), __uint_as_float(sy[0]) + __uint_as_float(sy[1])};
-            }
-#pragma unroll
-            for (int s2 = 1; s2 >= 0; --s2) {                              // steps 4u + 2*s2 (even rows of lanes keep it) and + 1 (odd rows)
-                const auto ux = __builtin_amdgcn_permlane16_swap(__float_as_uint(pu[2 * s2].x), __float_as_uint(pu[2 * s2 + 1].x), false, false);
-                const auto uy = __builtin_amdgcn_permlane16_swap(__float_as_uint(pu[2 * s2].y), __float_as_uint(pu[2 * s2 + 1].y), false, false);
-                partp[(4 * u + 2 * s2) * 4 * PB] = f2{__uint_as_float(ux[0]) + __uint_as_float(ux[1]), __uint_as_float(uy[0]) + __uint_as_float(uy[1])};
-            }
-        };
-        {
-            H4 X, Y;
-            load_u(X, 0, false); SB;
-#pragma unroll
-            for (int u = 0; u < TT / 4; u += 2) {
-                load_u(Y, u + 1, u + 1 == TT / 4 - 1); SB;
-                fwd_u(X, u); SB;
-                if (u + 2 < TT / 4) load_u(X, u + 2, false);
-                SB;
-                if (u + 1 < TT / 4 - 1) { fwd_u(Y, u + 1); SB; }
-            }
-            // (the last unit's arithmetic follows the load of the adjoint's second unit: keep reads in flight across the phase change)
-            load_u(X, TT / 4 - 2, true); SB;
-            fwd_u(Y, TT / 4 - 1); SB;
-            S2_STAMP(3)
-            lds_barrier();                                               // B_i: the previous segment's red / part have been drained
             SB;
 #pragma unroll
-            for (int u = TT / 4 - 1; u >= 0; u -= 2) {
-                bwd_u(Y, u); SB;
-                if (u - 2 >= 0) load_u(Y, u - 2, true);
+            for (int t = -2; t < TT; ++t) {
+                if (t + 2 < TT) { const f4 d = ddw[((t + 2) >> 1) & 3]; xr[t & 1] = A2 * (((t + 2) & 1) ? d.z : d.x); SB; }
+                if (t + 1 >= 0 && t + 1 < TT) { av[t + 1].x = fast_exp2(xr[(t + 1) & 1].x); SB; }
+                if (t >= 0) { hs[t] = __builtin_elementwise_fma(av[t], t == 0 ? hck : hs[t == 0 ? 0 : t - 1], xbr[(t + 3) % 3]); SB; }
+                if (t + 1 >= 0 && t + 1 < TT) { av[t + 1].y = fast_exp2(xr[(t + 1) & 1].y); SB; }
+                if (t + 2 < TT) {
+                    const f4 d = ddw[((t + 2) >> 1) & 3], bc = bcw[(t + 2) & 7];
+                    const f2 Bv = f2{bc.x, bc.y};
+                    if ((t + 2) & 1) xbr[(t + 5) % 3] = pk_mul_hi(Bv, __builtin_shufflevector(d, d, 2, 3)); else xbr[(t + 5) % 3] = Bv * d.y;
+                    SB;
+                }
+                if (t + LDB + 2 < TT && t + LDB + 2 >= LDB + 2) {
+                    const int s = t + LDB + 2;
+                    if ((s & 1) == 0) ddw[(s >> 1) & 3] = ddp[(s >> 1) * CB];
+                    bcw[s & 7] = bcp[s * 8];
+                }
                 SB;
-                bwd_u(X, u - 1); SB;
-                if (u - 3 >= 0) load_u(X, u - 3, true);
+            }
+        }
+        // the adjoint's first LDB steps: their reads are in flight across barrier B (they are inputs: nothing the staging waves still write)
+#pragma unroll
+        for (int s = TT - 1; s >= TT - LDB; --s) {
+            if (s & 1) ddw[(s >> 1) & 3] = ddp[(s >> 1) * CB];
+            bcw[s & 7] = bcp[s * 8];
+            gw[s & 7] = gp[s * CB];
+        }
+        SB;
+        S2_STAMP(3)
+        lds_barrier();                                                   // B_i: the previous segment's red / part have been drained
+        SB;
+        {   // ---- phase 2: the adjoint, last step first.  Stage A (step t): dh, dC, q, dB, da;  stage B (step t+1): the lane's shares of d(dt*u)
+            // and d dt, dB | dC over lane bit 5 -> red, dA;  stage C (steps t+2, t+3 when t is even): fold over lane bit 4 -> part.
+            f2 dh[2], dC[2], dB[2], da[2], pu[4];
+            f2 sxy0, sxy1, uxy0, uxy1;
+#pragma unroll
+            for (int t = TT - 1; t >= -2; --t) {
+                const int s = t + 1;                                       // stage B's step
+                const bool A_ = t >= 0, B_ = s >= 0 && s < TT, C_ = (t + 2) < TT && ((t + 2) & 1) == 0 && t + 2 >= 0;
+                const f4 bcA = bcw[t & 7], bcB = bcw[s & 7];
+                const f4 dA_ = ddw[(t >> 1) & 3], dB_ = ddw[(s >> 1) & 3];
+                const float dtvB = (s & 1) ? dB_.z : dB_.x;
+                if (A_) { const float gt = gw[t & 7]; dh[t & 1] = __builtin_elementwise_fma(f2{bcA.z, bcA.w}, f2{gt, gt}, q); SB; }
+                if (B_) { pu[s & 3].x = dh[s & 1].x * bcB.x; SB; }
+                if (C_) { const auto ux = __builtin_amdgcn_permlane16_swap(__float_as_uint(pu[(t + 2) & 3].x), __float_as_uint(pu[(t + 3) & 3].x), false, false); uxy0.x = __uint_as_float(ux[0]); uxy1.x = __uint_as_float(ux[1]); SB; }
+                if (A_) { dC[t & 1] = hs[t] * gw[t & 7]; SB; }
+                if (B_) { const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB[s & 1].x), __float_as_uint(dC[s & 1].x), false, false); sxy0.x = __uint_as_float(sx[0]); sxy1.x = __uint_as_float(sx[1]); SB; }
+                if (C_) { const auto uy = __builtin_amdgcn_permlane16_swap(__float_as_uint(pu[(t + 2) & 3].y), __float_as_uint(pu[(t + 3) & 3].y), false, false); uxy0.y = __uint_as_float(uy[0]); uxy1.y = __uint_as_float(uy[1]); SB; }
+                if (A_) { q = av[t] * dh[t & 1]; SB; }
+                if (B_) { pu[s & 3].x = fmaf(dh[s & 1].y, bcB.y, pu[s & 3].x); SB; }
+                if (A_) {
+                    if (t & 1) dB[t & 1] = pk_mul_hi(dh[t & 1], __builtin_shufflevector(dA_, dA_, 2, 3)); else dB[t & 1] = dh[t & 1] * dA_.y;
+                    SB;
+                }
+                if (B_) { const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(dB[s & 1].y), __float_as_uint(dC[s & 1].y), false, false); sxy0.y = __uint_as_float(sy[0]); sxy1.y = __uint_as_float(sy[1]); SB; }
+                if (A_) { da[t & 1] = q * (t == 0 ? hck : hs[t == 0 ? 0 : t - 1]); SB; }     // dL/d(dt*A) of this (t, pair) = dh * a * h_{t-1}
+                if (B_) { pu[s & 3].y = da[s & 1].x * An.x; SB; }
+                if (B_) { dAacc = __builtin_elementwise_fma(da[s & 1], f2{dtvB, dtvB}, dAacc); SB; }
+                if (C_) { partp[(t + 2) * 4 * PB] = uxy0 + uxy1; SB; }
+                if (B_) { *reinterpret_cast<f2*>(redp + s * 32) = sxy0 + sxy1; SB; }
+                if (B_) { pu[s & 3].y = fmaf(da[s & 1].y, An.y, pu[s & 3].y); SB; }
+                if (t - LDB >= 0) {
+                    const int r = t - LDB;
+                    if (r & 1) ddw[(r >> 1) & 3] = ddp[(r >> 1) * CB];
+                    bcw[r & 7] = bcp[r * 8];
+                    gw[r & 7] = gp[r * CB];
+                }
                 SB;
             }
         }
@@ -887,9 +933,9 @@ int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out,
     if (chunk_req > 0) {
         T = ceil_div(chunk_req, SEG) * SEG;                       // chunk starts must be checkpoint positions
     } else {
-        const int64_t waves = B * (ED / 8);                       // one wave = 8 channels x 8 state pairs
+        const int64_t waves = B * (ED / 8);                       // one scan wave = 8 channels x 8 state pairs
         if (waves < 768) {                                        // cannot fill 1024 SIMDs: cut L (two passes + carry)
-            const int64_t want = ceil_div(2048, waves);           // two waves per SIMD: measured -8 % (B = 1) / -7 % (B = 4) kernel time vs one
+            const int64_t want = ceil_div(1024, waves);           // one block per CU (round 6: a block's LDS image is 116-133 KB; two rounds of blocks cost more than they hide)
             T = ceil_div(ceil_div(L, want), SEG) * SEG;
             if (T < 64) T = 64;
         }
