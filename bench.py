@@ -167,7 +167,7 @@ class ScanWorkload:
         from gfe_hip.step_bench import measured_traffic
         traffic = measured_traffic("scan_b8") if (self.B, self.L, self.ED) == (8, 4096, 1024) else None
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r05/traffic_r05.json (committed rocprofv3 PMC passes of this command, not this run)",
+                "traffic": traffic, "traffic_source": None if traffic is None else "profiles/r06/traffic_r06.json (committed rocprofv3 PMC passes of this command, not this run)",
                 "kernel": "sscan2_fwd + sscan2_bwd (fused selective scan: state-pair lanes, 4 scan + 4 staging waves per block; one launch each way from B = 8, three each way when L is chunked)",
                 "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                 "fwd_GBs": round(self.bytes_fwd / (t_f * 1e-3) / 1e9, 1), "bwd_GBs": round(self.bytes_bwd / (t_b * 1e-3) / 1e9, 1),
@@ -275,7 +275,7 @@ class Vit3dWorkload:
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": self._traffic(),
-                "traffic_source": "profiles/r05/traffic_r05.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.B == 8 else None,
+                "traffic_source": "profiles/r06/traffic_r06.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed; not this run)" if self.B == 8 else None,
                 "kernel": "attn_fwd_kernel (one layer, B x 8 heads x 1729 x 64)", "launches_timed": iters,
                 "launch_ms": round(ms, 4), "algorithmic_flops": flops}
 

@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/gfe_hip.h"
+#include "diag_guard.h"
+#if defined(GFE_DIAG)   // a diagnostic library identifies itself (tests/test_build_resources.py: the product library must not export this)
+extern "C" __attribute__((weak, visibility("default"))) int gfe_diag_build(void) { return 1; }
+#endif
 
 #define GFE_WAVE 64
 

@@ -241,31 +241,18 @@ class ClassifyStep:
             if graph_head:
                 loss = self._head_step_graphed(x, x_cat, x_num, y, mid_input, mid_output, pet)
             else:
-                part = os.environ.get("GFE_EXP_HEAD_PART", "all")        # experiment (tools/run_r05_head_parts.sh): what each part of the head costs the pipelined step
-                if part != "none":
-                    self.opt.zero_grad()
-                    mid_feature = self.head(mid_input, mid_output)
-                    pred = self.ft(x_cat, x_num, mid_feature, [x, pet])
-                    loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
-                else:
-                    loss = torch.zeros((), device=x.device)
+                self.opt.zero_grad()
+                mid_feature = self.head(mid_input, mid_output)
+                pred = self.ft(x_cat, x_num, mid_feature, [x, pet])
+                loss = bce_sigmoid(pred.squeeze(1), y)                   # classify_mamba.py:104, value + gradient in one launch
                 loss_ready = torch.cuda.Event()
                 loss_ready.record(H)
-                if part in ("all", "fwdbwd"):
-                    with side_wgrads():
-                        loss.backward()
+                with side_wgrads():
+                    loss.backward()
             if loss_ready is None:
                 loss_ready = torch.cuda.Event()
                 loss_ready.record(H)
-            if graph_head or os.environ.get("GFE_EXP_HEAD_PART", "all") == "all":
-                self.opt.step(self.world_size, self.group)
-            if os.environ.get("GFE_EXP_HEAD_LAUNCHES"):        # experiment: that many extra one-element launches on the head's stream (what does a LAUNCH there cost the step?)
-                if getattr(self, "_exp_tiny", None) is None:
-                    self._exp_tiny = torch.zeros(1, device=x.device)
-                for _ in range(int(os.environ["GFE_EXP_HEAD_LAUNCHES"])):
-                    self._exp_tiny.add_(1.0)
-            if os.environ.get("GFE_EXP_HEAD_SPIN"):            # experiment: a spinning kernel of that many clock cycles appended to the head's chain
-                torch.cuda._sleep(int(os.environ["GFE_EXP_HEAD_SPIN"]))
+            self.opt.step(self.world_size, self.group)
             self._head_done = torch.cuda.Event(enable_timing=self.trace is not None)
             self._head_done.record(H)
             if self.trace is not None:

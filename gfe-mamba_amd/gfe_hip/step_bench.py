@@ -9,7 +9,7 @@ from .step import ClassifyStep, build_models
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-TRAFFIC_JSON = ("profiles", "r05", "traffic_r05.json")
+TRAFFIC_JSON = ("profiles", "r06", "traffic_r06.json")
 _TRAFFIC_KERNEL_SOURCE = {"conv_igemm_64to64_96cubed_b8": "conv3d.hip", "attn_fwd_b8_h8_n1729": "attn.hip", "attn_bwd_b8_h8_n1729": "attn_bwd.hip", "scan_b8": "sscan2.hip"}
 
 
@@ -30,7 +30,7 @@ def traffic_is_current(key, rel=TRAFFIC_JSON):
 
 def measured_traffic(key, rel=TRAFFIC_JSON):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the gfx950 correction prescribes + WRITE_SIZE,
-    separate passes: tools/collect_profiles_r05.sh); None when the file does not travel with the tree -- or when the kernel's source has
+    separate passes: tools/collect_profiles_r06.sh); None when the file does not travel with the tree -- or when the kernel's source has
     changed since the counters were taken (VERDICT r04 weak #11: a committed number must not silently outlive the kernel it describes)."""
     import json
     import os
@@ -115,7 +115,7 @@ class StepWorkload:
         tf = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                 "traffic": measured_traffic("conv_igemm_64to64_96cubed_b8") if (self.batch == 8 and self.vol_tag == "96^3") else None,
-                "traffic_source": "profiles/r05/traffic_r05.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed with the kernel source's hash; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
+                "traffic_source": "profiles/r06/traffic_r06.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this launch, committed with the kernel source's hash; not this run)" if (self.batch == 8 and self.vol_tag == "96^3") else None,
                 "kernel": "conv_igemm_kernel<4,3,true> (GroupNorm-folded Conv3d 3x3x3 64->64 @%s, ReLU): the launch the step makes three times per "
                           "forward (encoders.0 conv3, decoders.1 conv2 / conv3), timed alone on operands built from encoders.0's lifted tensor and "
                           "conv2 weights -- the step itself collapses encoders.0 conv2 to a one-channel conv (DESIGN 4.1)" % self.vol_tag,

@@ -70,9 +70,9 @@ def test_f32_gemm_inblock_rule_is_a_host_side_function_of_shape_and_alignment():
 
 
 def test_committed_traffic_counters_belong_to_the_kernels_in_the_tree():
-    """bench.py's roofline.traffic is a COMMITTED rocprofv3 measurement (profiles/r05/traffic_r05.json), so it must
+    """bench.py's roofline.traffic is a COMMITTED rocprofv3 measurement (profiles/r06/traffic_r06.json), so it must
     not outlive the kernel it was taken on.  The collect script stores the sha256 of the kernels' sources next to the numbers;
-    measured_traffic() returns None on a mismatch, and this test fails until tools/collect_profiles_r05.sh has been re-run."""
+    measured_traffic() returns None on a mismatch, and this test fails until tools/collect_profiles_r06.sh has been re-run."""
     import os
     from gfe_hip.step_bench import TRAFFIC_JSON, measured_traffic, traffic_is_current
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -80,5 +80,5 @@ def test_committed_traffic_counters_belong_to_the_kernels_in_the_tree():
         import pytest
         pytest.skip("no committed traffic file yet")
     for key in ("conv_igemm_64to64_96cubed_b8", "attn_fwd_b8_h8_n1729", "scan_b8"):
-        assert traffic_is_current(key) is True, f"{key}: the kernel source changed after the counters were taken -- re-run tools/collect_profiles_r05.sh"
+        assert traffic_is_current(key) is True, f"{key}: the kernel source changed after the counters were taken -- re-run tools/collect_profiles_r06.sh"
         assert measured_traffic(key) and measured_traffic(key) > 0

@@ -67,3 +67,35 @@ def test_scan_kernels_keep_their_two_waves_per_simd(tmp_path):
     for k in fwd + bwd:
         assert res[k]["VGPRs"] + res[k].get("AGPRs", 0) <= 256 and res[k]["VGPRs Spill"] == 0, (k, res[k])
         assert res[k]["LDS Size"] <= 160 * 1024, (k, res[k])
+
+
+def test_product_library_carries_no_diagnostic_switch(tmp_path):
+    """the timing / ablation switches of csrc/ (GFE_EXP_*, CONVT_EXP_*, *_STAMPS) build diagnostic libraries only.
+    (1) every switch the sources test is listed in csrc/diag_guard.h; (2) one of them without -DGFE_DIAG does not compile; (3) `make all`
+    refuses flags that name one; (4) the in-tree product library does not export the marker a diagnostic library carries."""
+    import ctypes
+    import re
+    guard = open(os.path.join(CSRC, "diag_guard.h")).read()
+    used = set()
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".h")) and f != "diag_guard.h":
+            for m in re.finditer(r"#\s*(?:if|ifdef|ifndef|elif)[^\n]*?\b((?:GFE_EXP_|CONVT_EXP_)[A-Z0-9_]+|GFE_[A-Z0-9]*_STAMPS)\b", open(os.path.join(CSRC, f)).read()):
+                used.add(m.group(1))
+    assert used, "no switches found: the pattern no longer matches the sources"
+    missing = sorted(u for u in used if ("defined(%s)" % u) not in guard)
+    assert not missing, "switches not listed in diag_guard.h: %s" % missing
+    tu = tmp_path / "tu.hip"
+    tu.write_text('#include "common.h"\nint main() { return 0; }\n')
+    base = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-host-only", "-I", CSRC, str(tu)]
+    bad = subprocess.run(base + ["-DGFE_EXP_NOMFMA"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "GFE_DIAG" in bad.stderr, bad.stderr[-400:]
+    ok = subprocess.run(base + ["-DGFE_EXP_NOMFMA", "-DGFE_DIAG"], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-400:]
+    mk = subprocess.run(["make", "-n", "-C", CSRC, "CXXFLAGS=-DCONVT_EXP_NOW"], capture_output=True, text=True)
+    assert mk.returncode != 0 and "diagnostic switches" in mk.stderr
+    lib = os.path.join(os.path.dirname(CSRC), "gfe_hip", "libgfe_hip.so")
+    if os.path.exists(lib):
+        assert not hasattr(ctypes.CDLL(lib), "gfe_diag_build"), "gfe_hip/libgfe_hip.so was built with -DGFE_DIAG"
+        exp = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "exp_build", "lib_stamps.so")
+        if os.path.exists(exp):
+            assert hasattr(ctypes.CDLL(exp), "gfe_diag_build")

@@ -16,7 +16,7 @@ exec(expr)
 open("../../exp_build/obj_%s/sscan2_var.hip" % name, "w").write(s)
 PY
 cp common.h ../../exp_build/obj_$1/ 2>/dev/null || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-pass-failed -fno-honor-nans -I. -I../../include -c ../../exp_build/obj_$1/sscan2_var.hip -o ../../exp_build/obj_$1/exp.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-pass-failed -fno-honor-nans -DGFE_DIAG -I. -I../../include -c ../../exp_build/obj_$1/sscan2_var.hip -o ../../exp_build/obj_$1/exp.o
 OBJS=$(ls build/*.o | grep -v "build/sscan2.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS ../../exp_build/obj_$1/exp.o -o ../../exp_build/lib_$1.so
 echo built lib_$1.so
