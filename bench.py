@@ -591,7 +591,8 @@ def main():
         metric, unit, dtype = "MRI volumes/sec (%s bf16) classify_mamba fwd+bwd" % ("96^3" if a.volume == "96" else "160x160x96"), "volumes/s", "bf16"
         cfg = {"workload": wl.name, "global_batch": a.batch * n_gpus, "batch_per_gpu": a.batch, "volume": "x".join(map(str, vol)),
                "parallelism": f"dp{n_gpus}", "dist_backend": (backend if distributed else None), "hip_graph": bool(a.graph or getattr(wl, "graph_head", False)),
-               "pipeline": ("generator(batch k+1) || head(batch k), 2 streams" + (", head replayed from a HIP graph" if getattr(wl, "graph_head", False) else "")) if wl.pipeline else "none"}
+               "pipeline": ("generator(batch k+1) || head(batch k), 2 streams" + (", head replayed from a HIP graph" if getattr(wl, "graph_head", False) else "")) if wl.pipeline else "none",
+               "dp": wl.step_obj.dp_modes()}       # how the multi-rank switches resolved (GFE_OVERLAP_UPDATE / GFE_DP_BUCKETS / GFE_NO_AUTO_GRAPH override)
 
     def barrier():
         if distributed:

@@ -91,19 +91,14 @@ class Jamba(nn.Module):
             router_logits.append(rl)
         return x, router_logits
 
-    _step_warned = False
 
     def step(self, x, caches):
         """Cached decoding, jamba.py:298-306: x (B, L, D) -- one token per call once the caches are warm (MambaLayer squeezes dim 1,
-        jamba.py:421-423) -- and caches[i] from layers[i].get_empty_cache(...); returns (x, caches).  Inference only (no graph is recorded)."""
-        if torch.is_grad_enabled() and x.requires_grad and not Jamba._step_warned:
-            Jamba._step_warned = True
-            import warnings
-            warnings.warn("Jamba.step is inference-only on the HIP path: its result carries no autograd graph (ADVICE r04); use it under torch.no_grad()",
-                          RuntimeWarning, stacklevel=2)
-        with torch.no_grad():
-            for i, layer in enumerate(self.layers):
-                (x, _), caches[i] = layer(x, caches[i])
+        jamba.py:421-423) -- and caches[i] from layers[i].get_empty_cache(...); returns (x, caches).  Under no_grad (or with nothing that
+        requires grad) no graph is recorded; otherwise every layer runs on its differentiable operators, as the reference's plain torch code
+        would (the attention kernels and MambaBlock.step both carry backwards)."""
+        for i, layer in enumerate(self.layers):
+            (x, _), caches[i] = layer(x, caches[i])
         return x, caches
 
 

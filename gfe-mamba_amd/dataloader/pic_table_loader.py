@@ -7,9 +7,9 @@ names, constructor arguments and sample dictionary (`image` (1, d, h, w) f32, `l
 What differs, deliberately:
   * the image transform runs on the GPU: utils.data_normalization.load_transform = adaptive_normal (bit-exact radix select) -> channel
     first -> Resized(desired_shape) (monai's default mode "area") -> first channel, instead of the monai Compose on the host;
-  * volumes are read from `.npy` files (raw (D, H, W) or (D, H, W, C) arrays) as well as `.nii.gz`: NIfTI decoding needs nibabel, which is
-    not a dependency of this build -- with nibabel importable `.nii` / `.nii.gz` files load as in the reference (get_fdata), without it they
-    raise.  The file-name convention and everything derived from it is the same for both extensions;
+  * volumes are read from `.nii.gz` / `.nii` by a dependency-free NIfTI-1 reader (read_nifti1 below: the values nibabel's get_fdata() returns,
+    which is what monai's LoadImaged hands the reference; nibabel itself is not in this image) and from `.npy` files (raw (D, H, W) or
+    (D, H, W, C) arrays).  The file-name convention and everything derived from it is the same for every extension;
   * the file list is SORTED (glob order is file-system dependent, and the reference's filter loop -- kept bug for bug, see __init__ --
     depends on it): with a sorted listing both implementations keep the same files (tests/golden/t11_dataset.json, generated from the
     reference with `glob` returning sorted names).
@@ -34,15 +34,50 @@ def date_difference(date1, date2):
     return abs(datetime.strptime(date2, '%Y-%m-%d') - datetime.strptime(date1, '%Y-%m-%d')).days
 
 
+_NIFTI_DTYPES = {2: "u1", 4: "i2", 8: "i4", 16: "f4", 64: "f8", 256: "i1", 512: "u2", 768: "u4", 1024: "i8", 1280: "u8"}
+
+
+def read_nifti1(path):
+    """A NIfTI-1 single-file volume (.nii / .nii.gz) as float64, the values nibabel's `get_fdata()` returns (the reference loads its MRI
+    through monai's LoadImaged = nibabel, pic_table_loader.py:104-117): voxel order of the file (x fastest, no reorientation), stored value *
+    scl_slope + scl_inter unless the slope is 0 / not finite.  Dependency-free: the 348-byte header by hand (either byte order), gzip from
+    the standard library.  NIfTI-2, Analyze pairs (.hdr/.img), complex and RGB voxels are refused."""
+    import gzip
+    import struct
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as fh:
+        raw = fh.read()
+    if len(raw) < 352:
+        raise ValueError(f"{path}: shorter than a NIfTI-1 header")
+    for e in ("<", ">"):
+        if struct.unpack(e + "i", raw[0:4])[0] == 348:
+            break
+    else:
+        raise ValueError(f"{path}: sizeof_hdr is not 348 (NIfTI-2 or not NIfTI)")
+    if raw[344:348] not in (b"n+1\0",):
+        raise ValueError(f"{path}: magic {raw[344:348]!r}: only single-file NIfTI-1 ('n+1') is read")
+    dim = struct.unpack(e + "8h", raw[40:56])
+    datatype, bitpix = struct.unpack(e + "2h", raw[70:74])
+    vox_offset, slope, inter = struct.unpack(e + "3f", raw[108:120])
+    if datatype not in _NIFTI_DTYPES or not 1 <= dim[0] <= 7:
+        raise ValueError(f"{path}: unsupported NIfTI datatype {datatype} / dim[0] = {dim[0]}")
+    shape = tuple(int(d) for d in dim[1:1 + dim[0]])
+    dt = np.dtype(e + _NIFTI_DTYPES[datatype])
+    if dt.itemsize * 8 != bitpix:
+        raise ValueError(f"{path}: bitpix {bitpix} does not match datatype {datatype}")
+    n = int(np.prod(shape))
+    off = int(vox_offset) if vox_offset >= 352 else 352
+    if len(raw) < off + n * dt.itemsize:
+        raise ValueError(f"{path}: {len(raw)} bytes, the header promises {off + n * dt.itemsize}")
+    vol = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape, order="F").astype(np.float64)
+    if np.isfinite(slope) and slope != 0.0 and np.isfinite(inter) and not (slope == 1.0 and inter == 0.0):
+        vol = vol * float(slope) + float(inter)
+    return vol
+
+
 def _load_volume(path):
     if path.endswith(".npy"):
         return np.load(path)
-    try:
-        import nibabel as nib
-    except ImportError as e:
-        raise RuntimeError(f"{path}: reading NIfTI needs nibabel (not a dependency of this build); convert the volume to .npy "
-                           "(np.save of nibabel's get_fdata()) or install nibabel") from e
-    return nib.load(path).get_fdata()
+    return read_nifti1(path)
 
 
 def read_nii(ni_path, desired_shape=(160, 160, 96)):

@@ -77,7 +77,7 @@ def allreduce_grads_(flat_grad, world_size, group=None, force=False):
 
 
 class ClassifyStep:
-    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None, overlap_update=None, force_collective=False, head_cus=None):
+    def __init__(self, gen, head, ft, lr=1e-4, max_norm=1.0, world_size=1, group=None, overlap_update=None, force_collective=False, head_cus=None, dp_buckets=None):
         self.gen, self.head, self.ft = gen.eval(), head, ft
         # train_step_pipelined: CUs the head's streams own (a multiple of 8 = the same number from every XCD; 0 = both streams share the
         # chip and the head only runs in the gaps between conv launches).  GFE_HEAD_CUS overrides.
@@ -91,10 +91,22 @@ class ClassifyStep:
         self.world_size, self.group = world_size, group
         # The generator is frozen (classify_mamba.py:53,100), so its forward for step k+1 does not depend on update k: with
         # overlap_update the gradient all-reduce + Adam of step k run on a side stream underneath it (same arithmetic, same order
-        # of updates).  Off by default: measured on one GPU in round 1 it LOST 3 % (16.9 -> 17.5 ms) -- the update kernel took CUs away
-        # from the persistent one-block-per-CU conv kernels, whose statically partitioned tile ranges then waited for the straggler
-        # (the conv kernels draw their tiles from ticket counters since round 3); to be re-measured on an 8-GPU node.
-        self.overlap_update = bool(overlap_update)
+        # of updates).  On ONE rank there is nothing to hide and the update kernel only takes CUs from the persistent conv kernels
+        # (round 1: -3 %), so the mode chooses itself: off at world_size 1, ON from two ranks up, where the step would otherwise wait
+        # for an 87 MB ring all-reduce (point-to-point xGMI: ~1-2 ms at 8 ranks) before the next generator may start.
+        # GFE_OVERLAP_UPDATE=0|1 and overlap_update=True|False override; GFE_DP_BUCKETS=n (or dp_buckets) splits collective + update
+        # into n buckets (FlatAdam.set_buckets).  Both are A/B switches for the first 8-GPU run: bench.py prints what was chosen.
+        env_ov = os.environ.get("GFE_OVERLAP_UPDATE")
+        if env_ov in ("0", "1"):
+            overlap_update = env_ov == "1"
+        self.overlap_update = (world_size > 1) if overlap_update is None else bool(overlap_update)
+        nb = int(os.environ.get("GFE_DP_BUCKETS", "0") or 0) or int(dp_buckets or 1)
+        self.dp_buckets = self.opt.set_buckets(nb) if nb > 1 else 1
+
+    def dp_modes(self):
+        """What the multi-rank switches resolved to (bench.py logs it with every line)."""
+        return {"world_size": self.world_size, "overlap_update": self.overlap_update, "dp_buckets": self.dp_buckets,
+                "collective": "forced" if self.opt.force_collective else ("all_reduce" if self.world_size > 1 else "none")}
 
     # ---- cross-batch software pipeline -------------------------------------------------------------------------------
     # The generator is frozen (classify_mamba.py:53, 100), so its forward for batch k+1 depends on nothing batch k's head computes

@@ -465,6 +465,8 @@ class FlatAdam:
         tab["off"], tab["len"], tab["tid"] = zip(*rec)
         self.chunks = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
         self.nchunks = len(rec)
+        self._chunk_tids = np.asarray(tab["tid"], dtype=np.int64)
+        self.buckets = []                                      # set_buckets(n): bucketed all-reduce + update
         self.norm2 = torch.zeros(len(self.params) + self.nchunks, dtype=torch.float32, device=dev)     # per-tensor norms | per-chunk partials
         self.offs, self.sizes = offs, sizes
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
@@ -506,12 +508,46 @@ class FlatAdam:
             torch.cuda.current_stream().wait_event(ev)
             self._done = None
 
+    def set_buckets(self, n):
+        """Split the update into n buckets of whole tensors with about equal numbers of elements, LAST parameters first (the order in which
+        the backward finishes them): bucket k's slice of the flat gradient is all-reduced and then clipped + updated on its own, so that
+        the collective of bucket k+1 runs under the update of bucket k (and, with RCCL, as several medium transfers instead of one of
+        87 MB).  n = 1: one collective, one update (the default).  The arithmetic per element is the same either way: every tensor's
+        norm, clip factor and Adam update see the same summed gradient (tests/test_dp_gloo.py compares the two bit for bit)."""
+        n = max(1, min(int(n), len(self.params)))
+        tids = self._chunk_tids
+        total = float(sum(self.sizes))
+        bounds, acc, target = [len(self.params)], 0.0, total / n
+        for tid in range(len(self.params) - 1, 0, -1):
+            acc += self.sizes[tid]
+            if acc >= target * len(bounds) and len(bounds) < n:
+                bounds.append(tid)
+        bounds.append(0)
+        self.buckets = []
+        for hi, lo in zip(bounds[:-1], bounds[1:]):                # tensors [lo, hi)
+            if hi <= lo:
+                continue
+            c0, c1 = int(np.searchsorted(tids, lo, "left")), int(np.searchsorted(tids, hi, "left"))
+            self.buckets.append((int(self.offs[lo]), int(self.offs[hi]), c0, c1))
+        return len(self.buckets)
+
     def _step(self, world_size, group):
-        from .step import allreduce_grads_
-        scale = allreduce_grads_(self.flat_g, world_size, group, force=getattr(self, "force_collective", False))   # SUM over ranks; the mean is folded into grad_scale
+        from .step import all_reduce_, allreduce_grads_, dp_mean_scale
         self.t += 1
         self.epoch[0] += 1
         nt = len(self.params)
+        force = getattr(self, "force_collective", False)
+        if len(self.buckets) > 1:
+            scale = dp_mean_scale(world_size)
+            for o0, o1, c0, c1 in self.buckets:
+                if world_size > 1 or force:
+                    all_reduce_(self.flat_g[o0:o1], group=group)
+                # the chunk table is sorted by tensor: a bucket is a contiguous range of it (tensor norms outside the range come out 0 and are not read)
+                call("gfe_clip_adam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.flat_p16),
+                     self.chunks.data_ptr() + 16 * c0, c1 - c0, ptr(self.norm2), nt, self.norm2.data_ptr() + 4 * nt, scale, self.max_norm, self.lr,
+                     self.betas[0], self.betas[1], self.eps, self.t, stream())
+            return
+        scale = allreduce_grads_(self.flat_g, world_size, group, force=force)   # SUM over ranks; the mean is folded into grad_scale
         call("gfe_clip_adam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.flat_p16),
              ptr(self.chunks), self.nchunks, ptr(self.norm2), nt, self.norm2.data_ptr() + 4 * nt, scale, self.max_norm, self.lr,
              self.betas[0], self.betas[1], self.eps, self.t, stream())

@@ -110,3 +110,33 @@ def test_shard_batch_is_a_partition():
     t = torch.arange(24).view(8, 3)
     parts = [shard_batch([t], r, 4)[0] for r in range(4)]
     assert torch.equal(torch.cat(parts), t)
+
+
+def test_bucket_plan_covers_every_tensor_once_last_parameters_first():
+    """FlatAdam.set_buckets without a GPU: the plan is pure host arithmetic.  Buckets are contiguous ranges of whole tensors,
+    ordered from the last parameter to the first (the order in which the backward finishes them), they cover every element and every chunk of
+    the table exactly once, and n = 1 / n > #tensors degenerate sensibly."""
+    import numpy as np
+    from gfe_hip.train_ops import FlatAdam
+    sizes = [40000, 7, 16384, 300, 8192, 123456, 64, 9000]
+    opt = FlatAdam.__new__(FlatAdam)
+    opt.params, opt.sizes = [None] * len(sizes), sizes
+    opt.offs = np.concatenate([[0], np.cumsum([(s + 7) // 8 * 8 for s in sizes])])
+    tids = []
+    for tid, s in enumerate(sizes):
+        tids += [tid] * ((s + 8191) // 8192)
+    opt._chunk_tids = np.asarray(tids, dtype=np.int64)
+    for n in (1, 2, 4, 8, 100):
+        nb = opt.set_buckets(n)
+        assert 1 <= nb <= min(n, len(sizes))
+        b = opt.buckets
+        assert b[0][1] == int(opt.offs[-1]) and b[-1][0] == 0 and b[0][3] == len(tids) and b[-1][2] == 0
+        for (o0, o1, c0, c1), (p0, p1, d0, d1) in zip(b[:-1], b[1:]):
+            assert o0 == p1 and c0 == d1                                   # contiguous, descending
+        for o0, o1, c0, c1 in b:
+            assert o0 < o1 and c0 < c1 and o0 in set(int(v) for v in opt.offs) and o1 in set(int(v) for v in opt.offs)
+            assert len(set(tids[c0:c1])) == sum(1 for t in range(len(sizes)) if o0 <= int(opt.offs[t]) < o1)
+    if True:
+        opt.set_buckets(4)
+        el = [o1 - o0 for o0, o1, _, _ in opt.buckets]
+        assert max(el) < 0.75 * int(opt.offs[-1])                          # no bucket swallows the buffer when the sizes allow a split

@@ -68,14 +68,36 @@ def test_token_by_token_step_reproduces_the_references_forward():
         y2, h2 = m.layers[0].mixer.ssm_step(torch.ones(B, cfg.d_inner, device=DEV), h1)
     assert not torch.allclose(o2, outs[0]) and caches2[0][0].shape == (B, cfg.d_inner, cfg.d_state)
     assert torch.isfinite(y2).all() and not torch.allclose(y1, y2)
-    # an inference path that callers of the reference run in eval mode WITHOUT no_grad: it must work there too, and records nothing
+    # Grad mode on and parameters that require grad: the reference's step is plain differentiable torch code, so is ours (VERDICT r05 missing #4):
+    # same values as the kernel path, and a graph behind them
     o3, _ = m.step(x[:, 0].contiguous(), list(warm))
-    assert torch.equal(o3, o2) and not o3.requires_grad
-    # ... but a caller whose input carries a graph is TOLD (once) that the result does not, instead of getting silently detached results
-    type(m.layers[0].mixer)._step_warned = False
-    with pytest.warns(RuntimeWarning, match="inference-only"):
-        o4, _ = m.layers[0].mixer.step(x[:, 0].contiguous().requires_grad_(True), warm[0])
-    assert not o4.requires_grad
+    assert rel_err(o3, o2) < 1e-5 and o3.requires_grad
+    # ... through which the token-by-token pass trains: the gradients of sum(y * w) w.r.t. the input and every parameter equal the ones the
+    # REFERENCE's full-sequence forward produced (fixture t0_mamba.npz: back-propagation through the caches == through the scan)
+    for p_ in m.parameters():
+        p_.grad = None
+    xg = x.clone().requires_grad_(True)
+    caches = [(None, torch.zeros(B, cfg.d_inner, cfg.d_conv - 1, device=DEV)) for _ in range(cfg.n_layers)]
+    outs = []
+    for t in range(L):
+        o, caches = m.step(xg[:, t], caches)
+        outs.append(o)
+    ys = torch.stack(outs, 1)
+    assert rel_err(ys, y_ref) < 1e-5
+    (ys * tt(fx["w"], device=DEV)).sum().backward()
+    e_gx = rel_err(xg.grad, tt(fx["gx"]))
+    e_g = {k: rel_err(p_.grad, tt(fx["g." + k])) for k, p_ in m.named_parameters()}
+    kw = max(e_g, key=e_g.get)
+    print("token-by-token step under autograd vs the reference's gradients: dx %.2e, worst parameter %.2e (%s)" % (e_gx, e_g[kw], kw))
+    assert e_gx < 1e-3 and e_g[kw] < 1e-3              # fp32 tolerance of BASELINE.json
+    # with no graph to record the step kernels run and the result carries none
+    frozen = [p_.requires_grad for p_ in m.parameters()]
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    o4, _ = m.step(x[:, 0].contiguous(), list(warm))
+    assert torch.equal(o4, o2) and not o4.requires_grad
+    for p_, f in zip(m.parameters(), frozen):
+        p_.requires_grad_(f)
 
 
 def test_cross_attention_ff_embedder_vs_reference_fixture():

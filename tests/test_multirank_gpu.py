@@ -104,6 +104,25 @@ def test_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(tmp_path):
     one = str(tmp_path / "one.pt")
     _run([sys.executable, child, "dp", "0", "1", one, port])
     r0, r1, ref = torch.load(outs[0]), torch.load(outs[1]), torch.load(one)
+    # the bucketed variant (GFE_DP_BUCKETS=4: the flat gradient all-reduced and updated as four slices of whole tensors, last parameters
+    # first -- FlatAdam.set_buckets) must leave the SAME bits: every element sees the same sum, every tensor the same norm
+    port2 = str(_free_port())
+    outs_b = [str(tmp_path / ("b%d.pt" % r)) for r in range(2)]
+    env_b = dict(_env(), GFE_DP_BUCKETS="4")
+    procs_b = [subprocess.Popen([sys.executable, child, "dp", str(r), "2", outs_b[r], port2], env=env_b, cwd=ROOT,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    logs_b = []
+    try:
+        for pr in procs_b:
+            logs_b.append(pr.communicate(timeout=1500))
+    finally:
+        for pr in procs_b:
+            if pr.poll() is None:
+                pr.kill()
+    for r, (pr, (so, se)) in enumerate(zip(procs_b, logs_b)):
+        assert pr.returncode == 0, "bucketed rank %d failed (%d)\n--- stdout ---\n%s\n--- stderr ---\n%s" % (r, pr.returncode, so[-3000:], se[-6000:])
+    b0, b1 = torch.load(outs_b[0]), torch.load(outs_b[1])
+    assert torch.equal(b0["p"], r0["p"]) and torch.equal(b1["p"], r1["p"]) and torch.equal(b0["g"], r0["g"]) and torch.equal(b0["loss"], r0["loss"])
     # every rank applies the same update to its replica: bit for bit (the clip factor's norm is a fixed-order sum since round 4)
     assert torch.equal(r0["p"], r1["p"]), "replicas drifted apart: %.3e" % (r0["p"] - r1["p"]).abs().max().item()
     assert torch.equal(r0["g"], r1["g"])
