@@ -384,6 +384,36 @@ def _slices(t, n=256):
     return f[::max(1, f.numel() // n)][:n]
 
 
+def _sample_idx(numel, n=1024):
+    """tools/make_golden.py::sample_idx -- the seeded element sample the fixtures hold of every gradient (`gsample.*`)."""
+    import numpy as np
+    if numel <= n:
+        return torch.arange(numel)
+    return torch.from_numpy(np.sort(np.random.default_rng(numel).choice(numel, size=n, replace=False)))
+
+
+def _grad_sample_stats(fx, names, params):
+    """The end-to-end gradient statistic with a variance (VERDICT r05 #6a; it replaces "worst of 64 strided elements", an extreme-value
+    statistic of one realisation of the generator's bf16 rounding noise): every tensor is compared on up to 1 024 seeded random elements
+    (`gsample.*`, from the reference's autograd), each error normalised by the tensor's largest reference element (`gamax.*`).  Returned:
+    the median / 95th / 99th percentile over ALL sampled elements of all tensors (~1e5 values), and the largest per-tensor 95th percentile
+    among tensors with at least 64 sampled elements."""
+    pooled, per_tensor = [], []
+    for k, p in zip(names, params):
+        if float(fx["gnorm." + k]) < 1e-7 or ("gsample." + k) not in fx:
+            continue
+        idx = _sample_idx(p.grad.numel()).to(p.grad.device)
+        a = p.grad.detach().reshape(-1)[idx].double().cpu()
+        e = (a - tt(fx["gsample." + k]).double()).abs() / float(fx["gamax." + k])
+        pooled.append(e)
+        if e.numel() >= 64:                                # (a 4-element bias has no percentile: its norm is checked instead)
+            per_tensor.append((torch.quantile(e, 0.95).item(), k))
+    allv = torch.cat(pooled)
+    per_tensor.sort(reverse=True)
+    q = torch.quantile(allv, torch.tensor([0.5, 0.95, 0.99], dtype=torch.float64))
+    return dict(n=allv.numel(), q50=q[0].item(), q95=q[1].item(), q99=q[2].item(), worst_tensor_q95=per_tensor[0], top=per_tensor[:4])
+
+
 def _grad_and_update_errors(fx, names, params, opt):
     """Element-wise comparison of the parameter gradients (fixture `gslice.*`: 64 strided elements per tensor, from the reference's
     autograd) and of one clipped Adam step (`dslice.*`), plus the norms.  Returns the worst relative errors (max |a-b| / max |b|)."""
@@ -425,7 +455,7 @@ def _grad_and_update_errors(fx, names, params, opt):
     return worst
 
 
-def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag, models=None, batch=2, tol_gen=1e-2):
+def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_grad, tol_sens, tag, models=None, batch=2, tol_gen=1e-2, tol_q95=2e-3, tol_tq95=1e-2):
     from gfe_hip import det_init as det
     from gfe_hip.step import ClassifyStep, build_models
     gen, head, ft = models if models is not None else build_models(vol=vol, dim=dim, depth=depth, heads=heads, seed=seed, **gen_kw)
@@ -447,7 +477,11 @@ def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_g
     meas["loss"] = abs(loss.item() - float(fx["loss"])) / max(1.0, float(fx["loss"]))
     loss.backward()
     names = ["head." + k for k, _ in head.named_parameters()] + ["ft." + k for k, _ in ft.named_parameters()]
+    gstat = _grad_sample_stats(fx, names, st.all_params)      # (before the optimizer step: it reads the gradients)
     worst = _grad_and_update_errors(fx, names, st.all_params, st.opt)
+    print("%s gradient elements, %d sampled over all tensors (error / largest element of the tensor): median %.2e, 95th percentile %.2e, 99th %.2e; "
+          "largest per-tensor 95th percentile %.2e (%s); next %s"
+          % (tag, gstat["n"], gstat["q50"], gstat["q95"], gstat["q99"], *gstat["worst_tensor_q95"], [("%.1e" % e, k) for e, k in gstat["top"][1:]]))
     print("%s measured rel errors vs the reference (fp32 CPU): %s | worst gradient element %.2e (%s), gradient norm %.2e (%s), "
           "Adam update element %.2e (%s), update norm %.2e (%s); gradient elements per tensor: median %.2e, six worst %s"
           % (tag, {k: "%.2e" % v for k, v in meas.items()}, *worst["gslice"], *worst["gnorm"], *worst["dslice"], *worst["dnorm"], worst["median"],
@@ -458,10 +492,17 @@ def _check_step_fixture(fx, gen_kw, vol, dim, depth, heads, seed, tol_fwd, tol_g
     # different roundings from its atomically accumulated GroupNorm fold) carried through the head's backward: typical tensor 2-3e-3,
     # tensors that are signed sums with heavy cancellation (the 4-element bias of the image-token Linear = 1024 feature gradients each,
     # the 32-wide dt_proj, a feed-forward row) up to 6e-2 of their largest element, and WHICH tensor is worst changes from run to run.
+    # What is ASSERTED since round 6 are the statistics with a variance: the pooled 95th percentile and the per-tensor 95th percentile
+    # of the sampled elements, and the norms.  The worst single element of the 64-element slices is still printed above (it moved between
+    # 3.4e-2 and 5.2e-2 with nothing but the number of K ranges of one generator product, profiles/r05/t2_realisations.txt) and only guarded
+    # by a loose bound against gross errors.
+    # measured (round 6): pooled 95th percentile 8.4e-4 (T2) / 1.3e-3 (T1), 99th 2.0e-3 / 3.6e-3 -- the bf16 tolerance of BASELINE.json
+    # is 1e-2 -- largest per-tensor 95th percentile 4.6e-3 / 5.8e-3
+    assert gstat["q95"] < tol_q95 and gstat["q99"] < 3 * tol_q95 and gstat["worst_tensor_q95"][0] < tol_tq95, gstat
     assert worst["median"] < tol_grad / 2 and worst["gnorm"][0] < tol_grad, worst
     for e, k in worst["top"]:
-        assert e < tol_sens, (k, e)
-    assert worst["dslice"][0] < tol_sens and worst["dnorm"][0] < tol_grad, worst
+        assert e < 2 * tol_sens, (k, e)
+    assert worst["dslice"][0] < 2 * tol_sens and worst["dnorm"][0] < tol_grad, worst
 
 
 def test_reduced_step_vs_reference_fixture():
@@ -470,7 +511,7 @@ def test_reduced_step_vs_reference_fixture():
     fx = golden("t1_reduced_step.npz")
     _check_step_fixture(fx, dict(f_maps=(8, 16, 32), vit_kwargs=dict(dim=64, depth=2, heads=2, dim_head=16, mlp_dim=128)),
                         (32, 32, 32), 64, 2, 8, 11, tol_fwd=1e-2, tol_grad=2e-2, tol_sens=5e-2, tag="T1 (reduced, 32^3)",
-                        tol_gen=2e-2)        # 8 / 16 / 32 channels: fewer terms per sum to average the roundings out (measured 1.2e-2)
+                        tol_gen=2e-2, tol_q95=3e-3, tol_tq95=1.2e-2)        # 8 / 16 / 32 channels: fewer terms per sum to average the roundings out (measured 1.2e-2)
 
 
 def test_full_96_step_vs_reference_fixture():

@@ -272,6 +272,14 @@ def slices(t, n=256):
     return npy(f[::step][:n].double())
 
 
+def sample_idx(numel, n=1024):
+    """The element sample of the end-to-end gradient statistics (VERDICT r05 #6a): n indices drawn without replacement by a generator
+    seeded with the tensor's size -- tests/test_head_gpu.py rebuilds the same indices; every element of a tensor up to n elements."""
+    if numel <= n:
+        return np.arange(numel)
+    return np.sort(np.random.default_rng(numel).choice(numel, size=n, replace=False))
+
+
 def run_step(R, gen, head, ft, vol, B, cards, n_cont, seed, full_grads):
     x, x_cat, x_num, y = det.det_inputs(B, vol, cards, n_cont, seed=seed)
     head.eval(); ft.eval()     # dropout off: parity fixtures are deterministic (SURVEY.md 8-a row B7)
@@ -292,6 +300,8 @@ def run_step(R, gen, head, ft, vol, B, cards, n_cont, seed, full_grads):
     for k, p in params:
         fx["gnorm." + k] = npy(p.grad.double().norm())
         fx["gslice." + k] = slices(p.grad, 64)
+        fx["gsample." + k] = p.grad.detach().reshape(-1)[torch.from_numpy(sample_idx(p.grad.numel()))].numpy().astype(np.float32)
+        fx["gamax." + k] = npy(p.grad.double().abs().max())
     # per-parameter clip (classify_mamba.py:106-107) then one Adam step (:64, :108)
     allp = [p for _, p in params]
     opt = torch.optim.Adam(allp, lr=1e-4)
