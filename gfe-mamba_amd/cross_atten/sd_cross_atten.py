@@ -56,6 +56,13 @@ class CrossAttention(nn.Module):
             return k, v
         return self.k_proj(y), self.v_proj(y)
 
+    def _fold_fits(self, imgs):
+        """the shape limits of gfe_cross_attn_q1_folded_* (csrc/xattn_fold.hip xf_shape_ok), checked here so that a larger condition falls
+        back to the materialised path instead of raising GFE_ERR_SHAPE"""
+        d3 = imgs[0].shape[2]
+        return (len(imgs) <= 4 and all(im.shape[2] == d3 and im.shape[1] == imgs[0].shape[1] for im in imgs) and d3 <= 256
+                and len(imgs) * d3 <= 1024 and self.n_heads <= 64 and self.d_head <= 1024)
+
     @staticmethod
     def _images(y):
         """the condition as a list of f32 (B, d_cross, keys_i) matrices whose COLUMNS are the keys: a Condition's volumes in place, or
@@ -74,8 +81,12 @@ class CrossAttention(nn.Module):
         b, lq, d = x.shape
         q = self.q_proj(x)
         if lq == 1 and kv is None and not (torch.is_tensor(y) and y.requires_grad):
-            return self.out_proj(cross_attn_q1_folded(q, self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias,
-                                                      self.n_heads, self._images(y)))
+            imgs = self._images(y)
+            if self._fold_fits(imgs):
+                return self.out_proj(cross_attn_q1_folded(q, self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias,
+                                                          self.n_heads, imgs))
+            # beyond the folded kernels' limits (include/gfe_hip.h: at most 4 volumes of at most 256 keys each, 1024 keys in all, 64 heads):
+            # K and V materialised, the one-query kernel over them -- the path every call took before round 5
         k, v = kv if kv is not None else self.project_kv(y)
         if lq == 1:
             return self.out_proj(cross_attn_q1(q, k, v, self.n_heads))           # (a condition that itself wants a gradient)

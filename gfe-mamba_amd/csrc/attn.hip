@@ -409,7 +409,11 @@ __global__ __launch_bounds__(ANW * 64, GFE_ATTN_MINW) void attn_fwd_kernel(const
         volatile int* flag = reinterpret_cast<volatile int*>(smem);
         int lane_c = lane;
         asm volatile("" : "+v"(lane_c));
-        const bool bad = (q0 + (lane_c & 31) < p.n) && !(l >= 8.6736174e-19f && l <= 1.2676506e30f);      // 2^-60 .. 2^100; NaN / inf are "bad"
+        // The row sum must lie in [2^-60, 2^100]; NaN / inf / negative are "bad" too.  Tested on the BITS: this file is compiled with
+        // -fno-honor-nans, under which a float comparison may be rewritten so that it is false for a NaN.  For a non-negative
+        // finite float the bit pattern is monotone in the value; a set sign bit, an all-ones exponent and every NaN fall outside the range.
+        const unsigned lbits = __float_as_uint(l);
+        const bool bad = (q0 + (lane_c & 31) < p.n) && !(lbits >= 0x21800000u && lbits <= 0x71800000u);      // 2^-60 = 0x21800000, 2^100 = 0x71800000
         if (tid == 0) *flag = 0;
         GFE_FUZZ();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -169,6 +169,8 @@ class _CrossAttnQ1Folded(torch.autograd.Function):
         ip = [ptr(im) for im in ims] + [None] * (4 - len(ims))
         call("gfe_cross_attn_q1_folded_bwd", ptr(d), ptr(wk.detach()), ptr(wv.detach()), *ip, len(ims), ptr(p),
              ptr(dc_ws), ptr(part), ptr(ds_ws), ptr(dr), ptr(dq), B, H, dh, HW, D3, stream())
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3] or (bv is not None and ctx.needs_input_grad[4])):
+            return (dq.view(qs), None, None, None, None, None) + (None,) * len(ims)      # frozen k_proj / v_proj: no rank-update launches
         # the weight gradients are leaves of the backward: on the side stream when they go straight into the optimizer's slots (train_ops._leaf)
         (dwk, own_k), (dwv, own_v) = _acc_target(wk), _acc_target(wv)
         dbv, own_b = (None, True) if bv is None else _acc_target(bv)
@@ -367,8 +369,13 @@ def dropout(x, p, training=True):
     if not training or p <= 0.0:
         return x
     _need_cuda(x, "dropout")
+    if torch.cuda.is_current_stream_capturing():
+        # the seed is a host-side counter passed BY VALUE: a captured graph would replay one mask for ever (geglu_dropout mixes a device
+        # step counter in for that reason; this operator has none -- ADVICE r05)
+        raise RuntimeError("gfe_hip dropout() inside a HIP-graph capture would bake its seed into the graph: capture in eval mode, or use geglu_dropout's device counter")
     _DROP_CALLS[0] += 1
-    seed = (torch.initial_seed() * 1000003 + 7919 * _DROP_CALLS[0]) & 0x7FFFFFFFFFFFFFFF
+    # operator tag 0x5D in the top byte of the counter term: the (seed, call) streams of dropout() and geglu_dropout() (7919 * m) cannot coincide
+    seed = (torch.initial_seed() * 1000003 + ((0x5D << 40) | (_DROP_CALLS[0] & 0xFFFFFFFFFF))) & 0x7FFFFFFFFFFFFFFF
     return _Dropout.apply(x, float(p), seed)
 
 

@@ -365,7 +365,9 @@ int gfe_gn_apply(const void* x, const float* scale, const float* shift, void* y,
 int gfe_mask_relu_bf16(const void* dy, const void* y, void* out, int64_t n, void* stream);
 /* GroupNorm backward, pass 1: S1[b,c] += sum_v dx^, S2[b,c] += sum_v dx^ * (x - mu[b,c]) * rstd[b,c]  (mu / rstd: the group's values per channel).
  * ws (ABI 45): B * gfe_gn_bwd_sums_blocks(V) * 2C floats -- every block stores its partial row there and a second launch adds them in order
- * (bit-reproducible); NULL: f32 atomics.  The same holds for gfe_conv_out1_bwd (ws: gfe_gen_rows_blocks(rows) * (C + 1) floats) and
+ * (bit-reproducible); NULL: f32 atomics.  Shape contract: C % 8 == 0, C <= 2048 and 256 % (C / 8) == 0 -- a 256-thread block is cut into
+ * 256 / (C / 8) voxel lanes of C / 8 eight-channel threads, so C / 8 must divide 256 (C in {8, 16, 32, 64, 128, 256, 512, 1024, 2048}: every
+ * generator width); anything else returns GFE_ERR_SHAPE.  The same holds for gfe_conv_out1_bwd (ws: gfe_gen_rows_blocks(rows) * (C + 1) floats) and
  * gfe_conv_in1_wgrad (gfe_gen_rows_blocks(rows) * 2C). */
 int gfe_gn_bwd_sums_blocks(int64_t V);
 int gfe_gen_rows_blocks(int64_t rows);

@@ -79,7 +79,7 @@ def test_product_library_carries_no_diagnostic_switch(tmp_path):
     used = set()
     for f in os.listdir(CSRC):
         if f.endswith((".hip", ".h")) and f != "diag_guard.h":
-            for m in re.finditer(r"#\s*(?:if|ifdef|ifndef|elif)[^\n]*?\b((?:GFE_EXP_|CONVT_EXP_)[A-Z0-9_]+|GFE_[A-Z0-9]*_STAMPS)\b", open(os.path.join(CSRC, f)).read()):
+            for m in re.finditer(r"#\s*(?:if|ifdef|ifndef|elif)[^\n]*?\b((?:GFE_EXP_|CONVT_EXP_)[A-Z0-9_]+|GFE_[A-Z0-9]*_STAMPS|GFE_ATTN_ALWAYS_TRACK)\b", open(os.path.join(CSRC, f)).read()):
                 used.add(m.group(1))
     assert used, "no switches found: the pattern no longer matches the sources"
     missing = sorted(u for u in used if ("defined(%s)" % u) not in guard)
