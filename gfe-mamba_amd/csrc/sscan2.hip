@@ -67,7 +67,9 @@ __device__ unsigned long long g_s2_stamps[48];
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: behind a block's global stores and
 // (backward) float atomics -- which stay counted for 600-3000 cycles -- that stalls every wave once per tile for nothing: no global
 // data is exchanged between the waves of a block here, only LDS.
+// (GFE_LB: the same barrier between two timing-fuzz sites -- common.h; nothing in the product build)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define GFE_LB() do { GFE_FUZZ(); lds_barrier(); GFE_FUZZ(); } while (0)
 
 // Staging math, branch-free (the generic helpers in common.h compile to nested exec-masked branches around v_log / the series, which at
 // one wave per SIMD cost more than both paths together).  softplus(x) = max(x, 0) + log1p(e), e = exp(-|x|): series below 2^-7 (1 + e
@@ -247,6 +249,7 @@ template <typename T, typename TBC, bool STATE_ONLY>
 __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     typedef Row4<T> R;
     typedef Row4<TBC> RBC;
+    GFE_FUZZ_INIT();
     __shared__ __attribute__((aligned(16))) FTile tiles[3];     // a ring of three: tile k+1 is complete one barrier BEFORE the scan waves finish tile k, so they read its first steps ahead of the barrier
     __shared__ __attribute__((aligned(16))) float ypart[STATE_ONLY ? TT * CB : 2 * YP_TILE];   // STATE_ONLY: the staging lanes' sums of dt on their way to sdelta
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
@@ -332,26 +335,26 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         fetch(1);
         park(1, 1, k1);
         fetch(2);
-        lds_barrier();                                                // tiles 0 and 1 are ready
+        GFE_LB();                                                // tiles 0 and 1 are ready
         park(2, 2, k2);                                               // iteration 0: nothing to finish yet
         fetch(3);
-        lds_barrier();
+        GFE_LB();
         for (int k = 1; k < nt; k += 3) {                             // iteration k: the scan waves are on tile k; finish k-1, park k+2, fetch k+3
             if (!STATE_ONLY) finish(k - 1, k0);
             park(k + 2, 0, k0);
             fetch(k + 3);
-            lds_barrier();
+            GFE_LB();
             if (k + 1 < nt) {
                 if (!STATE_ONLY) finish(k, k1);
                 park(k + 3, 1, k1);
                 fetch(k + 4);
-                lds_barrier();
+                GFE_LB();
             }
             if (k + 2 < nt) {
                 if (!STATE_ONLY) finish(k + 1, k2);
                 park(k + 4, 2, k2);
                 fetch(k + 5);
-                lds_barrier();
+                GFE_LB();
             }
         }
         if (!STATE_ONLY) {
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
             if (r3 == 0) finish(nt - 1, k0); else if (r3 == 1) finish(nt - 1, k1); else finish(nt - 1, k2);
         } else {
             *reinterpret_cast<f4*>(&ypart[sr * CB + 4 * sc]) = sdt;
-            lds_barrier();
+            GFE_LB();
             if (tid < CB) {
                 float s = 0.f;
 #pragma unroll 8
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
     const bool do_ck = !STATE_ONLY && p.ckpt != nullptr;         // (uniform)
     float* ckp = p.ckpt + ((((size_t)b * p.nseg + t0 / SEG) * p.ED + e) * 16 + 2 * pr);
     const size_t ckstride = (size_t)p.ED * 16;
-    lds_barrier();
+    GFE_LB();
     constexpr int LD = 6;
     f4 ddr[TT / 2], bcr[TT];
     int kb = 0;                                                      // k mod 3
@@ -442,18 +445,20 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
         head_reads(kb);                                              // the next tile's first steps: in flight across the barrier (that tile was complete one barrier ago)
         if (!STATE_ONLY) {
             // the barrier publishes this tile's partial rows: LDS operations complete in order, so "at most the head reads outstanding" means every write has landed
+            GFE_FUZZ();
             asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(LD + 2 + (LD + 2 + 1) / 2) : "memory");
+            GFE_FUZZ();
             S2_STAMP(4)
             continue;
         }
         S2_STAMP(2)
-        lds_barrier();
+        GFE_LB();
         S2_STAMP(4)
     }
     S2_STAMP_FLUSH(STATE_ONLY ? 36 : 0)
     if (STATE_ONLY) {
         *reinterpret_cast<f2*>(p.hstate + sbase) = h;
-        lds_barrier();                                               // (the staging waves' sum of dt)
+        GFE_LB();                                               // (the staging waves' sum of dt)
     }
 }
 
@@ -524,6 +529,7 @@ template <typename T, typename TBC, bool STATE_ONLY, bool DET>
 __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     typedef Row4<T> R;
     typedef Row4<TBC> RBC;
+    GFE_FUZZ_INIT();
     __shared__ __attribute__((aligned(16))) BTile stg[2];
     __shared__ __attribute__((aligned(16))) float red[STATE_ONLY ? 4 : 16 * RSL];   // [wave][channel & 3] slabs of [step][16 dB | 16 dC]
     __shared__ __attribute__((aligned(16))) f2 part[STATE_ONLY ? 2 : TT * 4 * PB];  // [step][pair & 3][channel] {d(dt*u), d dt} summed over lane bit 4
@@ -647,11 +653,11 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
             fetch(K - 1);
             park(K - 1, stg[0], S);
             fetch(K - 2);
-            lds_barrier();
+            GFE_LB();
             for (int k = K - 1, i = 0; k >= 0; --k, ++i) {
                 park(k - 1, stg[(i + 1) & 1], S);
                 fetch(k - 2);
-                lds_barrier();
+                GFE_LB();
             }
             return;
         }
@@ -659,32 +665,32 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         fetch(K - 1);
         park(K - 1, stg[0], s1);
         fetch(K - 2);
-        lds_barrier();                                                   // A_0
-        lds_barrier();                                                   // B_0 (iteration 0: nothing to drain)
+        GFE_LB();                                                   // A_0
+        GFE_LB();                                                   // B_0 (iteration 0: nothing to drain)
         park(K - 2, stg[1], s0);
         fetch(K - 3);
-        lds_barrier();                                                   // A_1
+        GFE_LB();                                                   // A_1
         for (int i = 1; i < K; i += 2) {                                 // iteration i: the scan waves are on segment K-1-i
             drain(K - i, s1);
-            lds_barrier();                                               // B_i
+            GFE_LB();                                               // B_i
             park(K - 2 - i, stg[(i + 1) & 1], s1);
             fetch(K - 3 - i);
-            lds_barrier();                                               // A_{i+1}
+            GFE_LB();                                               // A_{i+1}
             if (i + 1 < K) {
                 drain(K - 1 - i, s0);
-                lds_barrier();
+                GFE_LB();
                 park(K - 3 - i, stg[i & 1], s0);
                 fetch(K - 4 - i);
-                lds_barrier();
+                GFE_LB();
             }
         }
         if (K & 1) drain(0, s1); else drain(0, s0);
         // dD / dbias: this lane's sums over its rows of every segment; the 32 row lanes of a channel quad meet in LDS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_barrier();                                                   // (every wave's last fold is done with `red`)
+        GFE_LB();                                                   // (every wave's last fold is done with `red`)
         *reinterpret_cast<f4*>(&red[sr * CB + 4 * sc]) = dDacc;
         *reinterpret_cast<f4*>(&red[TT * CB + sr * CB + 4 * sc]) = dbacc;
-        lds_barrier();
+        GFE_LB();
         if (tid < 2 * CB) {
             const int ch = tid & (CB - 1), which = tid >> 5;
             float s = 0.f;
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     if (!STATE_ONLY) hck_next = *reinterpret_cast<const f2*>(pck + (size_t)(K - 1) * ckstride);
     float* redp = &red[STATE_ONLY ? 0 : (w * 4 + (lane & 3)) * RSL + (lane >> 5) * 16 + 2 * pr];
     f2* partp = &part[STATE_ONLY ? 0 : (((lane >> 4) & 1) * 4 + ((lane >> 2) & 3)) * PB + cl];
-    lds_barrier();                                                       // A_0
+    GFE_LB();                                                       // A_0
     S2_STAMP_DECL
     for (int k = K - 1, i = 0; k >= 0; --k, ++i) {
         const BTile& tl = stg[i & 1];
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
                 SB;
                 adj_u(Y); SB;
             }
-            lds_barrier();                                               // A_{i+1}
+            GFE_LB();                                               // A_{i+1}
             continue;
         }
 
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         }
         SB;
         S2_STAMP(3)
-        lds_barrier();                                                   // B_i: the previous segment's red / part have been drained
+        GFE_LB();                                                   // B_i: the previous segment's red / part have been drained
         SB;
         {   // ---- phase 2: the adjoint, last step first.  Stage A (step t): dh, dC, q, dB, da;  stage B (step t+1): the lane's shares of d(dt*u)
             // and d dt, dB | dC over lane bit 5 -> red, dA;  stage C (steps t+2, t+3 when t is even): fold over lane bit 4 -> part.
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         }
 #undef SB
         S2_STAMP(4)
-        lds_barrier();                                                   // A_{i+1}
+        GFE_LB();                                                   // A_{i+1}
         S2_STAMP(5)
     }
     S2_STAMP_FLUSH(16)
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
         *reinterpret_cast<f2*>(p.qstate + sbase) = q;
         return;
     }
-    lds_barrier(); lds_barrier();                                        // (the staging waves' dD / dbias sums)
+    GFE_LB(); GFE_LB();                                        // (the staging waves' dD / dbias sums)
     if (p.a_log) dAacc *= An;                                            // d/dA_log = dA * dA/dA_log = dA * A
     if (DET) {                                                           // this (sample, chunk)'s row of partials: plain stores, summed in order later
         float* pv = p.part_vec + ((size_t)b * p.nchunks + c) * ((size_t)p.ED * 18);

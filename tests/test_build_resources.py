@@ -99,3 +99,34 @@ def test_product_library_carries_no_diagnostic_switch(tmp_path):
         exp = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "exp_build", "lib_stamps.so")
         if os.path.exists(exp):
             assert hasattr(ctypes.CDLL(exp), "gfe_diag_build")
+
+
+def test_scan_forward_counted_barrier_wait_matches_the_emitted_lds_stream(tmp_path):
+    """csrc/sscan2.hip, forward scan waves: the tile barrier is preceded by `s_waitcnt lgkmcnt(12)`, not lgkmcnt(0): the next tile's first
+    twelve fragment reads stay in flight across the barrier, and -- LDS operations of a wave complete in order -- "at most twelve outstanding"
+    means every partial-row WRITE of the tile has landed.  That argument holds only if exactly those twelve reads, and nothing else, were
+    issued behind the last write.  The count is a source constant; what hipcc emits is checked here on the ISA of every instantiation."""
+    asm = tmp_path / "sscan2.s"
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-honor-nans", "-S", "--cuda-device-only",
+                          os.path.join(CSRC, "sscan2.hip"), "-o", str(asm)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    s = asm.read_text()
+    seen = 0
+    for m in re.finditer(r"^(_ZN[^\n]*sscan2_fwd_kernel[^\n]*Lb0[^\n]*):", s, re.M):
+        body = s[m.end():s.index(".Lfunc_end", m.end())]
+        lines = [l.strip() for l in body.splitlines()]
+        waits = [i for i, l in enumerate(lines) if re.match(r"s_waitcnt lgkmcnt\((\d+)\)", l) and i + 1 < len(lines) and lines[i + 1].startswith("s_barrier")]
+        counted = [i for i in waits if not lines[i].startswith("s_waitcnt lgkmcnt(0)")]
+        assert len(counted) == 1, (m.group(1), [lines[i] for i in waits])
+        i = counted[0]
+        n = int(re.match(r"s_waitcnt lgkmcnt\((\d+)\)", lines[i]).group(1))
+        reads, j = 0, i - 1
+        while j >= 0 and not lines[j].startswith("ds_write"):
+            if lines[j].startswith("ds_read"):
+                reads += 1
+            else:
+                assert not lines[j].startswith("ds_"), (m.group(1), lines[j])
+            j -= 1
+        assert j >= 0 and reads == n, (m.group(1), reads, n)
+        seen += 1
+    assert seen == 4

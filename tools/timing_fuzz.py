@@ -43,6 +43,8 @@ def child(role, args):
     lib = os.path.basename(gfe_hip.LIB_PATH)
     if args.workload == "vit3d":
         return child_vit3d(role, args, lib, torch, G, det)
+    if args.workload == "scan":
+        return child_scan(role, args, lib, torch, G, det)
     gen, _, _ = build_models(vol=vol, seed=0)
     x = det.det_inputs(8, vol, seed=77)[0].cuda()
 
@@ -85,6 +87,59 @@ def child(role, args):
     print(json.dumps({"role": "fuzz", "lib": lib, "iters": args.iters, "runs": 2 * args.iters, "mismatching_runs": len(fails),
                       "stages": sorted({f["stage"] for f in fails}), "seconds": round(time.time() - t0, 1),
                       "median_ms_incl_fingerprints": {"batch8": round(ms8[len(ms8) // 2], 1), "batch1": round(ms1[len(ms1) // 2], 1)}}), flush=True)
+    return 1 if fails else 0
+
+
+def child_scan(role, args, lib, torch, G, det):
+    """--workload scan (round 6): the fused selective scan's forward and backward (csrc/sscan2.hip: 4 scan + 4 staging waves per block, a ring of
+    three input tiles read across the tile barrier, per-pair partial rows handed over through LDS, a counted lgkmcnt wait in front of the
+    barrier) at four shapes -- one launch each way (B = 8, L = 300), the chunked two-pass plan (B = 1, L = 1000, chunk 256), f32 I/O with ragged
+    L = 77 and config 2's own length (L = 4096, 128 tiles per block) -- with the fixed-order accumulation (GFE_SCAN_DETERMINISTIC=1): y and all eight gradients must come out bit-identical."""
+    os.environ["GFE_SCAN_DETERMINISTIC"] = "1"
+    from gfe_hip.scan_ops import selective_scan_tm
+    g = torch.Generator().manual_seed(3)
+    cases = []
+    for (B, L, ED, dt_, chunk) in ((8, 300, 128, torch.bfloat16, 0), (1, 1000, 256, torch.bfloat16, 256), (2, 77, 64, torch.float32, 0), (2, 4096, 256, torch.bfloat16, 0)):
+        mk = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g) * sc).to(dt_).cuda().requires_grad_(True)
+        u, d, z, Bm, Cm = mk(B, L, ED), mk(B, L, ED, sc=0.3), mk(B, L, ED), mk(B, L, 16), mk(B, L, 16)
+        A = (-(torch.rand(ED, 16, generator=g) * 6 + 0.2)).cuda().requires_grad_(True)
+        D = torch.randn(ED, generator=g).cuda().requires_grad_(True)
+        bias = (torch.randn(ED, generator=g) - 3).cuda().requires_grad_(True)
+        dy = torch.randn(B, L, ED, generator=g).to(dt_).cuda()
+        cases.append(((u, d, A, Bm, Cm, D, z, bias), dy, chunk))
+
+    def run():
+        out = {}
+        for i, (ins, dy, chunk) in enumerate(cases):
+            for t in ins:
+                t.grad = None
+            u, d, A, Bm, Cm, D, z, bias = ins
+            y = selective_scan_tm(u, d, A, Bm, Cm, D, z=z, delta_bias=bias, delta_softplus=True, chunk=chunk)
+            y.backward(dy)
+            out["y%d" % i] = y.detach()
+            for n, t in zip(("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "dbias"), ins):
+                out["%s%d" % (n, i)] = t.grad
+        return {k_: G.fingerprint(v_.detach().float().reshape(1, -1)).cpu() for k_, v_ in out.items()}
+
+    if role == "ref":
+        assert "fuzz" not in lib, lib
+        ref, again = run(), run()
+        order = tuple(ref.keys())
+        d = G.first_divergence(ref, again, order)
+        torch.save({"ref": ref}, args.ref)
+        print(json.dumps({"role": "ref", "workload": "scan", "lib": lib, "device": G.device_report(), "tensors": len(ref), "repeat_mismatch": d and (d[0], d[2])}), flush=True)
+        return 1 if d else 0
+    assert "fuzz" in lib, "the fuzz child must load the fuzz library (GFE_HIP_LIB): " + lib
+    ref = torch.load(args.ref)["ref"]
+    order = tuple(ref.keys())
+    fails, t0 = [], time.time()
+    for it in range(args.iters):
+        d = G.first_divergence(ref, run(), order)
+        if d:
+            fails.append({"iter": it, "tensor": d[0], "cells": d[1], "ncells": d[2]})
+            print("MISMATCH", json.dumps(fails[-1]), flush=True)
+    print(json.dumps({"role": "fuzz", "workload": "scan", "lib": lib, "iters": args.iters, "mismatching_runs": len(fails),
+                      "tensors": sorted({f["tensor"] for f in fails}), "seconds": round(time.time() - t0, 1)}), flush=True)
     return 1 if fails else 0
 
 
@@ -149,7 +204,7 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="K=V for both children (bisect switches)")
     ap.add_argument("--ref", default=os.path.join(ROOT, "gpurun_out", "timing_fuzz_ref.pt"))
     ap.add_argument("--role", default=None)
-    ap.add_argument("--workload", default="generator", choices=["generator", "vit3d"])
+    ap.add_argument("--workload", default="generator", choices=["generator", "vit3d", "scan"])
     ap.add_argument("--heavy", action="store_true", help="the heavier fuzz level (make fuzz_heavy: every other site visit sleeps, long sleeps at 1 of 32)")
     args = ap.parse_args()
     if args.role:
