@@ -165,8 +165,10 @@ __device__ __forceinline__ f2 chunk_carry(const float* __restrict__ state, const
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (k0 + j < n) {
+                // the first folded chunk meets H = 0: its own sum of dt is not needed -- and not written: the state passes skip the chunk
+                // whose end state nobody folds (the last one forward, the first one backward), so that slot of sdelta is uninitialised memory
                 const f2 x = A2 * sdv[j];
-                H = f2{fast_exp2(x.x), fast_exp2(x.y)} * H + loc[j];
+                H = (k0 + j == 0) ? loc[j] : f2{fast_exp2(x.x), fast_exp2(x.y)} * H + loc[j];
             }
         }
     }
@@ -465,7 +467,8 @@ __global__ __launch_bounds__(512) void sscan2_fwd_kernel(const S2Fwd p) {
 template <typename T, typename TBC>
 int sscan2_fwd_launch2(const S2Fwd& p, hipStream_t st) {
     const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
-    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_fwd_kernel<T, TBC, true>), grid, blk, 0, st, p);      // local end states + sum dt of every chunk
+    // local end states + sum dt of every chunk but the LAST (nobody folds its end state: with two chunks that is half of this pass)
+    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_fwd_kernel<T, TBC, true>), dim3(grid.x, grid.y - 1, grid.z), blk, 0, st, p);
     hipLaunchKernelGGL((sscan2_fwd_kernel<T, TBC, false>), grid, blk, 0, st, p);
     return gfe_launch_status();
 }
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(512) void sscan2_bwd_kernel(const S2Bwd p) {
     __shared__ __attribute__((aligned(16))) f2 part[STATE_ONLY ? 2 : TT * 4 * PB];  // [step][pair & 3][channel] {d(dt*u), d dt} summed over lane bit 4
     const bool staging = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;      // wave-uniform role
     const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
-    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y, b = blockIdx.z;
+    const int e0 = xcd_paired_group(blockIdx.x, gridDim.x) * CB, c = blockIdx.y + (STATE_ONLY ? 1 : 0), b = blockIdx.z;     // (the state pass runs chunks 1 .. nchunks-1: nobody folds chunk 0's carry)
     const int t0 = c * p.T, t1 = min(p.L, t0 + p.T);
     const int nrows = t1 - t0;
     const int K = (nrows + TT - 1) / TT;                                // segments of this chunk
@@ -914,7 +917,8 @@ __global__ __launch_bounds__(256) void sscan2_fold_kernel(const S2Bwd p, int nb_
 template <typename T, typename TBC, bool DET>
 int sscan2_bwd_launch3(const S2Bwd& p, hipStream_t st) {
     const dim3 blk(512), grid((unsigned)(p.ED / CB), p.nchunks, p.B);
-    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_bwd_kernel<T, TBC, true, false>), grid, blk, 0, st, p);      // local adjoint carries of every chunk
+    // local adjoint carries of every chunk but the FIRST (the kernel numbers its chunks from 1 in this mode)
+    if (p.nchunks > 1) hipLaunchKernelGGL((sscan2_bwd_kernel<T, TBC, true, false>), dim3(grid.x, grid.y - 1, grid.z), blk, 0, st, p);
     hipLaunchKernelGGL((sscan2_bwd_kernel<T, TBC, false, DET>), grid, blk, 0, st, p);
     if (DET) {
         const int nb_vec = (int)ceil_div((int64_t)p.ED * 18, 256);
@@ -941,7 +945,8 @@ int gfe_sscan2_plan(int64_t B, int64_t L, int64_t ED, int chunk_req, int* T_out,
     } else {
         const int64_t waves = B * (ED / 8);                       // one scan wave = 8 channels x 8 state pairs
         if (waves < 768) {                                        // cannot fill 1024 SIMDs: cut L (two passes + carry)
-            const int64_t want = ceil_div(1024, waves);           // one block per CU (round 6: a block's LDS image is 116-133 KB; two rounds of blocks cost more than they hide)
+            const int64_t want = ceil_div(2048, waves);           // two rounds of one-block-per-CU grids (a block's LDS image is 116-133 KB): measured 3-4 % under one round
+                                                                  // of twice as long chunks at B = 1 and B = 4, equal at B = 2 (profiles/r06/scan_batch_sweep.txt)
             T = ceil_div(ceil_div(L, want), SEG) * SEG;
             if (T < 64) T = 64;
         }

@@ -10,21 +10,4 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- $P > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_LDS SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS --kernel-trace --output-format csv -d $O/pmc_sq3 -o p -- $P > /dev/null 2>&1
 cd $R
-python3 - <<PY
-import csv, glob, collections, os
-O = "$O"
-out = open(os.path.join(O, "pmc_summary.txt"), "w")
-for d in sorted(glob.glob(O + "/pmc_*")):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-    if not f: continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"]
-        if "sscan2_" not in k: continue
-        k = ("fwd" if "sscan2_fwd" in k else "bwd" if "sscan2_bwd" in k else "fold") + ("_state" if "true" in k.split("(")[0].split(",")[-2 if "bwd" in k else -1] else "")
-        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"])); dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    for k in sorted(agg):
-        line = f"{os.path.basename(d):8s} {k:10s} avg_us {sum(dur[k]) / len(dur[k]) / 1e3:8.1f} " + " ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(agg[k].items()))
-        print(line); out.write(line + "\n")
-out.close()
-PY
+python3 $R/tools/pmc_summ.py $O
