@@ -406,7 +406,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvParam
             // 2 pieces per stage (1.93), every wave 1/8 of the tile in "its" stage (1.79), all DMA on the weight waves (1.67), block-
             // staggered burst stage (no change), and an address-arithmetic-free burst with the tile origin in the scalar offset
             // (2.11: the 64 misses then sit in front of the next stages' weight pieces in the CU's in-order vector-memory path)
-            if constexpr (A_BUFS == 2) { if (a_wave && do_a && s == 0 && next_unit) a_dma(nxt, slab1, (u + 1) & 1, 0, A_PER_WAVE); }
+            // Round 6: the burst goes out in TWO halves, behind the first tap of stages 0 and 1 (all of it in stage 0 when the unit has one stage):
+            // the weight pieces of stage 2, issued at the top of stage 1, then queue behind 32 tile pieces instead of 64 in the CU's in-order
+            // vector-memory path.  64->64 @96^3, alternating runs on two boxes: 1.430-1.436 -> 1.412-1.414 ms and 1.378-1.387 -> 1.360-1.365 ms
+            // (profiles/r06/conv_burst_split_ab.txt; halves at stages 0 / 2 or 0 / 4, thirds, quarters: no gain or a loss).  Same pieces, same
+            // images, same arithmetic: every wave still drains its vmcnt before the unit's epilogue.
+            if constexpr (A_BUFS == 2) {
+                if (a_wave && do_a && next_unit) {
+                    constexpr int AH = A_PER_WAVE / 2;
+                    if (s == 0) a_dma(nxt, slab1, (u + 1) & 1, 0, nstage >= 2 ? AH : A_PER_WAVE);
+                    else if (s == 1) a_dma(nxt, slab1, (u + 1) & 1, AH, A_PER_WAVE);
+                }
+            }
 #endif
             };
             // 27-tap path: the first tap's fragment reads go out BEFORE the DMA instructions, so their LDS round trip runs under the 3 (weight
