@@ -188,3 +188,37 @@ def test_mambablock_selective_scan_methods_match_reference_fixture():
         y = blk.selective_scan(i["x"], i["delta"], i["A"], i["B"], i["C"], i["D"])
         ys = blk.selective_scan_seq(i["x"], i["delta"], i["A"], i["B"], i["C"], i["D"])
     assert rel_err(y, tt(fx["ss_y"])) < TOL32 and rel_err(ys, tt(fx["ss_y_seq"])) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [0, 32, 64])
+def test_selective_scan_tile_ring_edge_lengths(chunk):
+    """Round 6 kernels (csrc/sscan2.hip, N = 16): the input tiles form a ring of three read across the tile barrier, the staging lanes finish a
+    tile two barriers after they parked it, the state passes skip the chunk nobody folds.  Lengths around every tile count from one to five
+    (1 ... 161 steps: 1, 2, 3, 4, 5+ tiles with full and ragged last tiles), one launch and chunked (chunks of one and two tiles, ragged last
+    chunk), fused bias + softplus + D + gate, against the oracle in f64: output and all eight gradients."""
+    from gfe_hip.scan_ops import selective_scan_tm
+    g = torch.Generator().manual_seed(41 + chunk)
+    B, ED, N = 2, 64, 16
+    for L in (1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 129, 161):
+        if chunk and L <= chunk:
+            continue
+        u = torch.randn(B, L, ED, generator=g).requires_grad_(True)
+        d = (torch.randn(B, L, ED, generator=g) * 0.5).requires_grad_(True)
+        A = (-torch.rand(ED, N, generator=g) * 5 - 0.1).requires_grad_(True)
+        Bm = torch.randn(B, L, N, generator=g).requires_grad_(True)
+        Cm = torch.randn(B, L, N, generator=g).requires_grad_(True)
+        D = torch.randn(ED, generator=g).requires_grad_(True)
+        z = torch.randn(B, L, ED, generator=g).requires_grad_(True)
+        bias = (torch.randn(ED, generator=g) - 2).requires_grad_(True)
+        w = torch.randn(B, L, ED, generator=g)
+        ins = [u, d, A, Bm, Cm, D, z, bias]
+        gi = [t.detach().to(DEV).requires_grad_(True) for t in ins]
+        y = selective_scan_tm(gi[0], gi[1], gi[2], gi[3], gi[4], gi[5], z=gi[6], delta_bias=gi[7], delta_softplus=True, chunk=chunk)
+        dd = [t.double() for t in ins]
+        ref = O.selective_scan(dd[0], torch.nn.functional.softplus(dd[1] + dd[7]), dd[2], dd[3], dd[4], dd[5]) * torch.nn.functional.silu(dd[6])
+        assert rel_err(y, ref) < TOL32, (L, chunk, rel_err(y, ref))
+        (y * w.to(DEV)).sum().backward()
+        gr = torch.autograd.grad((ref * w.double()).sum(), dd)
+        for k, (a, b) in enumerate(zip(gi, gr)):
+            assert rel_err(a.grad, b) < TOL32, (L, chunk, k, rel_err(a.grad, b))
