@@ -5,21 +5,20 @@
 //   cross_atten/mamba.py:243-259  softplus(delta + dt_proj.bias) and the y*silu(z) gate of the `selective_scan_fn` plug-in
 //   cross_atten/pscan.py:151-224  PScan.forward / backward (the recurrence and its adjoint)
 //
-// Why a second formulation (instruction prices from tools/probes/valu_rates.hip): the scan is VALU-issue bound --
-// one v_exp_f32 (8 cycles) and four f32 operations per state-step -- so the only lever is the number of instructions issued per
-// state-step.  sscan.hip keeps a channel's 16 states in one lane; filling the chip then needs chunks along L and TWO passes over
-// every chunk (local end state, then the real pass), i.e. two exp per state-step.  Here a lane owns one channel x one PAIR of
-// states: B*ED*8 lanes fill 1024 SIMDs from B = 8 up without cutting L, every state-step is computed once, the pair keeps the
-// arithmetic in v_pk_* form, and a segment's states fit in registers for the backward (no third exp, no LDS checkpoints).
+// Why a second formulation: the scan is vector-ISSUE bound -- one v_exp_f32 and four f32 operations per state-step -- so the
+// only lever is the number of instructions issued per state-step.  sscan.hip keeps a channel's 16 states in one lane; filling the chip then
+// needs chunks along L and TWO passes over every chunk (local end state, then the real pass), i.e. two exp per state-step.  Here a lane owns
+// one channel x one PAIR of states: B*ED*8 lanes fill 1024 SIMDs from B = 8 up without cutting L, every state-step is computed once, the pair
+// keeps the arithmetic in v_pk_* form, and a segment's states fit in registers for the backward (no third exp, no LDS checkpoints).
 // L is cut into chunks (two passes + carry) only when B*ED/8 waves cannot fill the chip (B = 1).
 //
-// Work split: block = 4 waves = 32 channels of one (batch, chunk); wave = 8 channels x 8 state pairs:
-//     lane bits {2,3,4} = pair p   (the sum over states = over p runs on DPP row operations + v_permlane16_swap, no selects)
-//     lane bits {0,1,5} = channel c within the wave
-// u / delta / z rows reach the block as 64-B (bf16) or 128-B (f32) row segments, are turned ONCE per (t, channel) into
-// dt = softplus(delta + bias), dt*u, D*u and silu(z) and parked in LDS (double-buffered 32-step tiles, one barrier per tile);
-// B / C rows are parked as {B[2p], B[2p+1], C[2p], C[2p+1]} so that one ds_read_b128 feeds a step.  y goes back through LDS so
-// that global stores are whole row segments.
+// Work split (round 6): block = 8 waves = 32 channels of one (batch, chunk): 4 SCAN waves, each 8 channels x 8 state pairs
+//     lane bits {2,3,4} = pair p,  lane bits {0,1,5} = channel c within the wave
+// + 4 STAGING waves, their SIMD partners.  The scan waves keep only what is per (step, channel, state) and hand every sum over lanes to the
+// LDS array as raw per-lane partials; the staging waves fetch the rows (branch-free raw buffer I/O: counted vmcnt waits), do the
+// per-(step, channel) math once (softplus, SiLU, products), park {dt, dt*u} and {B[2p], B[2p+1], C[2p], C[2p+1]} in LDS, and finish the
+// previous tile's outputs from the partial rows (in-lane f4 sums) as whole-row stores.  What a lone wave pays per instruction, and why this
+// formulation sits on its floor at B = 8, is measured in DESIGN.md 4.3 (tools/probes/lone_wave_mix.hip, tools/scan_exp/).
 #include "common.h"
 
 namespace {
@@ -29,13 +28,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int TT = 32;       // steps per LDS tile == checkpoint interval: the backward recomputes one tile at a time with its states in registers
 constexpr int CB = 32;       // channels per block (4 waves x 8)
-constexpr int EPS = 36;      // row stride (floats) of the [step][channel] arrays: banks 4*p + c are distinct for the butterfly's owners
 constexpr int SEG = TT;
-
-// [channel][step] arrays (dt, dt*u): a lane reads 4 consecutive steps of its channel per ds_read_b128.  The 4-step groups of a row are
-// XOR-swizzled by the channel so that both the staging writes (32 lanes = 8 channel quads x 4 steps) and the reads (4 rows per
-// 16-lane group) are bank-conflict free without padding.
-__device__ __forceinline__ int dts_index(int ch, int t) { return ch * TT + ((((t >> 2) ^ (ch >> 2) ^ ((ch >> 1) & 1)) & 7) << 2) + (t & 3); }
 
 struct S2Fwd {
     const void* u; const void* delta; const void* z; const void* Bm; const void* Cm;      // Bm / Cm: f32 or bf16 rows (bc_bf16)
@@ -84,53 +77,6 @@ __device__ __forceinline__ float softplus_nb(float x, float* sig = nullptr) {
     if (sig) { const float r = fast_rcp(w1); *sig = x >= 0.f ? r : e * r; }
     return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()) + l;
 }
-
-// Sum over the 8 pair-lanes (lane bits 2,3,4) of 8 per-lane values v[0..7]; the lane with pair index p returns the total of v[p].
-// Halving butterfly: bit 4 by v_permlane16_swap (rows of 16 lanes trade registers), bits 3 and 2 by pairs of bank-masked
-// v_add_f32_dpp (row_ror:8; row_shl:4 / row_shr:4): each pair writes the two halves of one result register, so a level costs two
-// instructions per result and needs neither v_cndmask nor copies -- 16 VALU instructions per 8 values.
-// (Inline asm because the masked v_add_dpp has no builtin; the leading s_nop 1 is the VALU-write -> DPP-read hazard, which hipcc does
-// not pad inside or in front of an asm statement.)
-__device__ __forceinline__ float reduce_pairs8(const float (&v)[8]) {
-    float w[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
-        w[j] = __uint_as_float(x[0]) + __uint_as_float(x[1]);          // rows with bit4 = 0: total of v[j]; bit4 = 1: total of v[j+4]
-    }
-    float x0, x1, r;
-    // lanes 0-7 of a row (bit3 = 0): w[j] + w[j] of lane^8;  lanes 8-15: w[j+2] + w[j+2] of lane^8
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                 "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc"
-                 : "=&v"(x0), "=&v"(x1) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
-    // banks 0,2 (bit2 = 0): x0 + x0 of lane+4;  banks 1,3 (bit2 = 1): x1 + x1 of lane-4
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
-                 : "=&v"(r) : "v"(x0), "v"(x1));
-    return r;
-}
-
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-    typedef f4 type;
-    static __device__ __forceinline__ type pack(const f4& v) { return v; }
-    static __device__ __forceinline__ void unpack(const type& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-    static __device__ __forceinline__ type zero() { return type{0.f, 0.f, 0.f, 0.f}; }
-};
-template <> struct Vec4<bf16_t> {
-    typedef uint2 type;
-    static __device__ __forceinline__ type pack(const f4& v) {
-        return make_uint2((uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16), (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16));
-    }
-    static __device__ __forceinline__ void unpack(const type& v, float (&o)[4]) {
-        o[0] = bf16lo_to_f32(v.x); o[1] = bf16hi_to_f32(v.x); o[2] = bf16lo_to_f32(v.y); o[3] = bf16hi_to_f32(v.y);
-    }
-    static __device__ __forceinline__ type zero() { return make_uint2(0u, 0u); }
-};
 
 // A block's 32 channels are a 64-byte segment of every (b, t) row of the bf16 tensors: HALF a 128-byte line, the other half belongs to the
 // neighbouring channel group.  Workgroups go to the 8 XCDs round-robin, so with the identity mapping the two halves are fetched by two
