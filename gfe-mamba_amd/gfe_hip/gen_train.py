@@ -142,8 +142,11 @@ class _Conv1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        cout = weight.shape[0]
-        y = K.conv_igemm(x.detach(), K.pack_conv1(weight), [(0, 0, 0)], cout, bias=bias.detach().float().contiguous(), stats=True)
+        cout, cin = weight.shape[:2]
+        if K.conv1x1_ok(cin, cout):                   # the streaming product (conv1x1.hip); other widths stay on the one-tap implicit GEMM
+            y = K.conv1x1(x.detach(), weight.detach().reshape(cout, cin).to(torch.bfloat16).contiguous(), bias.detach().float().contiguous(), stats=True)
+        else:
+            y = K.conv_igemm(x.detach(), K.pack_conv1(weight), [(0, 0, 0)], cout, bias=bias.detach().float().contiguous(), stats=True)
         ctx.save_for_backward(x.detach(), weight)
         return y
 
@@ -153,8 +156,11 @@ class _Conv1Fn(torch.autograd.Function):
         d = dy.contiguous()
         cout, cin = weight.shape[:2]
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = K.conv_igemm(d, K.pack_conv1(weight.detach().transpose(0, 1).contiguous()), [(0, 0, 0)], cin)
+        if ctx.needs_input_grad[0]:                   # dx = dy W: the same product with the channels swapped
+            if K.conv1x1_ok(cout, cin):
+                dx = K.conv1x1(d, weight.detach().reshape(cout, cin).t().to(torch.bfloat16).contiguous(), None, stats=False)
+            else:
+                dx = K.conv_igemm(d, K.pack_conv1(weight.detach().transpose(0, 1).contiguous()), [(0, 0, 0)], cin)
         d2, x2 = d.view(-1, cout), x.view(-1, cin)
         if ctx.needs_input_grad[1]:
             dw = K.gemm_ex(d2, True, x2, True, split_k=max(1, min(256, d2.shape[0] // 4096))).view(weight.shape).to(weight.dtype)

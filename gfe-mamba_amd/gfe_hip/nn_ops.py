@@ -112,6 +112,32 @@ def pack_conv1(weight):
 _CT_AXIS = {0: [(0, 1)], 1: [(0, 2), (1, 0)]}
 
 
+def conv1x1(x, w_bf16, bias, stats=True):
+    """1x1x1 conv Cin -> Cout + bias of a channels-last (B, D, H, W, Cin) bf16 tensor (gfe_conv1x1: ResNetBlock.conv1,
+    buildingblocks.py:204-208).  w_bf16: the Conv3d weight as (Cout, Cin) bf16.  stats: tag the result with the GroupNorm partials
+    of what was stored (`out.gn_partials`), as conv_igemm(stats=True) does."""
+    B, D, H, W, cin = x.shape
+    cout = w_bf16.shape[0]
+    assert x.dtype == BF16 and x.is_contiguous() and w_bf16.dtype == BF16 and w_bf16.is_contiguous() and w_bf16.shape[1] == cin
+    V = D * H * W
+    out = torch.empty((B, D, H, W, cout), dtype=BF16, device=x.device)
+    ws = None
+    if stats:
+        ws = torch.empty((B, lib().gfe_conv1x1_stat_slots(V), 2, cout), dtype=torch.float32, device=x.device)     # every element is written
+    call("gfe_conv1x1", ptr(x), ptr(w_bf16), ptr(bias), ptr(out), B, V, cin, cout, ptr(ws), 0 if ws is None else ws.shape[1], 0, stream())
+    if stats:
+        out.gn_partials = ws
+    return out
+
+
+def conv1x1_ok(cin, cout):
+    """Shapes gfe_conv1x1 takes (everything else stays on the one-tap conv_igemm path)."""
+    if cin not in (64, 128) or cout < 64 or cout % 64:
+        return False
+    g = cout // (128 if (cin == 64 and cout % 128 == 0) else 64)
+    return g in (1, 2, 4)
+
+
 def pack_convT(weight):
     """nn.ConvTranspose3d weight (Cin, Cout, 3, 3, 3), stride 2, padding 1 -> {parity (pd,ph,pw): (packed, taps)}."""
     cin, cout = weight.shape[:2]

@@ -91,6 +91,10 @@ class ResNetBlock(nn.Module):
         if c1.in_channels == 1:
             w, b = self._pack.get([c1.weight, c1.bias], lambda: (_f32(c1.weight).view(-1), _f32(c1.bias)))
             return K.conv_in1(x, w, b, stats=True)
+        if K.conv1x1_ok(c1.in_channels, c1.out_channels) and x.dim() == 5 and x.shape[-1] == c1.in_channels:
+            # the plain streaming product (conv1x1.hip): no halo tile staged for one tap
+            w, b = self._pack.get([c1.weight, c1.bias], lambda: (c1.weight.detach().reshape(c1.out_channels, c1.in_channels).to(torch.bfloat16).contiguous(), _f32(c1.bias)))
+            return K.conv1x1(x, w, b, stats=True)
         w, b = self._pack.get([c1.weight, c1.bias], lambda: (K.pack_conv1(c1.weight), _f32(c1.bias)))
         return K.conv_igemm(x, w, [(0, 0, 0)], c1.out_channels, bias=b, stats=True)
 

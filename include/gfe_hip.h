@@ -27,7 +27,7 @@ extern "C" {
 #define GFE_ERR_DTYPE  -3   /* unsupported dtype */
 #define GFE_ERR_HIP    -4   /* hipGetLastError() != hipSuccess after launch */
 
-#define GFE_ABI_VERSION 48
+#define GFE_ABI_VERSION 49
 
 #define GFE_F32  0
 #define GFE_BF16 1
@@ -174,6 +174,19 @@ int gfe_stream_create_cu_range(int lo, int hi, void** stream);
 int gfe_stream_destroy(void* stream);
 /* GroupNorm-partial slots per sample one gfe_conv3d_igemm call with stats_ws writes (see above). Host-only. */
 int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cout);
+
+/* 1x1x1 convolution Cin -> Cout + bias of a channels-last tensor, as a plain streaming product (ABI 49; csrc/conv1x1.hip).
+ * Replaces: the encoders' ResNetBlock.conv1 = nn.Conv3d(in, out, 1) (pytorch3dunet/unet3d/buildingblocks.py:204-208, applied at :218-229),
+ * which rounds 1-5 ran through gfe_conv3d_igemm with a one-tap list.
+ *   x: (B, V, Cin) bf16, V = D*H*W voxels per sample.  w: (Cout, Cin) bf16, the Conv3d weight as it is (no packing).  bias: (Cout) f32 or NULL.
+ *   y: (B, V, Cout) bf16.  Cin in {64, 128}; Cout a multiple of 64 with Cout / 128 (Cin == 64 and Cout % 128 == 0) or Cout / 64 in {1, 2, 4}.
+ *   stats_ws (or NULL): GroupNorm partials of y, layout (B, stats_nblk, 2, Cout) f32 as gfe_conv3d_igemm's: the call writes EVERY element of
+ *   slots stats_slot0 .. stats_slot0 + gfe_conv1x1_stat_slots(V) - 1 (one per block of a sample, <= 64 of them, a function of V alone; sums of the rounded
+ *   outputs per 8 consecutive channels on the octet's first channel, zeros on the other seven), so the workspace needs no zero fill. */
+int gfe_conv1x1(const void* x, const void* w, const float* bias, void* y, int64_t B, int64_t V, int64_t Cin, int64_t Cout,
+                float* stats_ws, int64_t stats_nblk, int64_t stats_slot0, void* stream);
+/* GroupNorm-partial slots per sample one gfe_conv1x1 call with stats_ws writes. Host-only. */
+int gfe_conv1x1_stat_slots(int64_t V);
 
 /* The whole TransposeConvUpsampling + summation join (buildingblocks.py:396-400, 523-537) in ONE launch: the 8 output-parity
  * classes that gfe_conv3d_igemm takes as 8 calls become the innermost dimension of the persistent blocks' work list, so a block

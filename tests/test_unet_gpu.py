@@ -921,3 +921,58 @@ def test_fused_maxpool_in_the_first_block_epilogue_is_bit_identical(shape):
     assert torch.equal(y.pooled2[0], K.maxpool2(y2)) and y.pooled2[1] == y._version
     y.add_(0)                                                       # an in-place write invalidates the fused pooling: the consumer re-pools
     assert y.pooled2[1] != y._version
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (2, 5, 6, 7)), (128, 256, (1, 9, 9, 9)), (64, 64, (3, 4, 8, 9)), (128, 128, (2, 3, 16, 16)),
+                                            (64, 256, (1, 7, 11, 5)), (64, 128, (2, 41, 41, 41)), (128, 256, (1, 1, 1, 1))])
+def test_pointwise_lift_conv_streaming_product(cin, cout, shape):
+    """gfe_conv1x1 (ResNetBlock.conv1 of the 64 -> 128 / 128 -> 256 encoders, buildingblocks.py:204-208) against F.conv3d on the same bf16
+    operands: ragged voxel counts (not a multiple of the 16-voxel tile or of the block), every channel-group layout, a volume of several
+    tiles per wave (41^3); its GroupNorm partials against sums over the tensor it stored; the one-tap implicit-GEMM path
+    it replaces; and a sample's bits do not depend on the batch it rides in."""
+    from gfe_hip import nn_ops as K
+    g = torch.Generator().manual_seed(cin + cout + shape[1])
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, cin, generator=g).to(BF).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(BF)
+    b = torch.randn(cout, generator=g)
+    assert K.conv1x1_ok(cin, cout)
+    y = K.conv1x1(x, w.to(DEV), b.to(DEV), stats=True)
+    ref = x.float().cpu().reshape(-1, cin) @ w.float().t() + b                                  # f32 on the bf16 operands
+    assert rel_err(y.float().cpu().reshape(-1, cout), ref) < 5e-3                               # bf16 rounding of the result
+    assert (y.float().cpu().reshape(-1, cout) - ref).abs().max() <= ref.abs().max() * 2 ** -8    # ... of every element (half an ulp of the largest)
+    # statistics = sums over the stored (rounded) tensor, per 8 consecutive channels on the octet's first channel
+    ws = y.gn_partials
+    assert ws.shape == (B, K.lib().gfe_conv1x1_stat_slots(D * H * W), 2, cout) and torch.isfinite(ws).all()
+    tot = ws.double().sum(1).cpu()                                                               # (B, 2, cout)
+    yf = y.double().cpu().reshape(B, -1, cout)
+    s = yf.sum(1).reshape(B, cout // 8, 8).sum(-1)
+    q = (yf * yf).sum(1).reshape(B, cout // 8, 8).sum(-1)
+    assert (tot.reshape(B, 2, cout // 8, 8)[..., 1:] == 0).all()
+    assert rel_err(tot.reshape(B, 2, cout // 8, 8)[:, 0, :, 0], s) < 1e-5 and rel_err(tot.reshape(B, 2, cout // 8, 8)[:, 1, :, 0], q) < 1e-5
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+    s1, t1 = K.groupnorm_scale_shift(y, gamma, beta, 8)
+    s0, t0 = K.groupnorm_scale_shift(y.clone(), gamma, beta, 8)                                  # the separate statistics pass
+    assert rel_err(s1, s0) < 1e-5 and rel_err(t1, t0) < 1e-5
+    # the path it replaces: same operands, another summation order -> at most rare one-ulp flips
+    y_old = K.conv_igemm(x, K.pack_conv1(w.float().reshape(cout, cin, 1, 1, 1).to(DEV)), [(0, 0, 0)], cout, bias=b.to(DEV))
+    assert rel_err(y.float(), y_old.float()) < 8e-3
+    if B > 1:
+        y1 = K.conv1x1(x[B - 1:].contiguous(), w.to(DEV), b.to(DEV), stats=True)
+        assert torch.equal(y1[0], y[B - 1]) and torch.equal(y1.gn_partials[0], y.gn_partials[B - 1])
+    # without statistics / without bias
+    y2 = K.conv1x1(x, w.to(DEV), None, stats=False)
+    assert getattr(y2, "gn_partials", None) is None
+    assert rel_err(y2.float().cpu().reshape(-1, cout), ref - b) < 5e-3
+
+
+@pytest.mark.gpu
+def test_pointwise_lift_conv_refuses_what_it_does_not_cover():
+    from gfe_hip import nn_ops as K
+    import gfe_hip
+    assert not K.conv1x1_ok(32, 64) and not K.conv1x1_ok(64, 96) and not K.conv1x1_ok(128, 512) and not K.conv1x1_ok(64, 1024)
+    assert K.conv1x1_ok(64, 512) and K.conv1x1_ok(128, 64)
+    x = torch.zeros(1, 2, 2, 2, 32, dtype=BF, device=DEV)
+    with pytest.raises(gfe_hip.GfeError):
+        K.conv1x1(x, torch.zeros(64, 32, dtype=BF, device=DEV), None)
