@@ -69,6 +69,24 @@ def test_f32_gemm_inblock_rule_is_a_host_side_function_of_shape_and_alignment():
     assert q(37, 2048, 512) == 1 and q(296, 2048, 512) == 0                                                          # >= 512 tiles of 32 x 32: one staged launch
 
 
+def test_pointwise_conv_plan_and_shape_rules_are_host_side():
+    """gfe_conv1x1 (ABI 49): the GroupNorm-partial slot count is a function of the SAMPLE's voxel count alone (<= 64 blocks of >= 256 voxels, so
+    a volume's statistics do not depend on the batch it rides in), the Python gate `conv1x1_ok` names exactly the shapes the entry point
+    takes, and bad arguments come back as error codes before anything is launched."""
+    from gfe_hip import nn_ops as K
+    L = gfe_hip.lib()
+    assert L.gfe_conv1x1_stat_slots(48 ** 3) == 64 and L.gfe_conv1x1_stat_slots(24 ** 3) == 54 and L.gfe_conv1x1_stat_slots(1) == 1
+    assert L.gfe_conv1x1_stat_slots(256) == 1 and L.gfe_conv1x1_stat_slots(257) == 2 and L.gfe_conv1x1_stat_slots(41 ** 3) <= 64
+    assert K.conv1x1_ok(64, 128) and K.conv1x1_ok(128, 256) and K.conv1x1_ok(64, 64) and K.conv1x1_ok(128, 128) and K.conv1x1_ok(64, 512)
+    assert not K.conv1x1_ok(1, 64) and not K.conv1x1_ok(32, 64) and not K.conv1x1_ok(64, 96) and not K.conv1x1_ok(128, 512) and not K.conv1x1_ok(256, 128)
+    X = 0x7f0000000000                                             # fake device addresses: validation fails first, nothing is dereferenced
+    assert L.gfe_conv1x1(None, X, None, X, 1, 8, 64, 128, None, 0, 0, None) == -1                   # NULL x
+    assert L.gfe_conv1x1(X, X, None, X, 1, 8, 32, 128, None, 0, 0, None) == -2                      # Cin
+    assert L.gfe_conv1x1(X, X, None, X, 1, 8, 128, 512, None, 0, 0, None) == -2                     # eight channel groups
+    assert L.gfe_conv1x1(X, X, None, X, 1, 1 << 24, 64, 128, None, 0, 0, None) == -2                # a sample beyond the 32-bit buffer offsets
+    assert L.gfe_conv1x1(X, X, None, X, 1, 48 ** 3, 64, 128, X, 10, 0, None) == -2                  # statistics workspace with too few slots
+
+
 def test_committed_traffic_counters_belong_to_the_kernels_in_the_tree():
     """bench.py's roofline.traffic is a COMMITTED rocprofv3 measurement (profiles/r06/traffic_r06.json), so it must
     not outlive the kernel it was taken on.  The collect script stores the sha256 of the kernels' sources next to the numbers;
