@@ -189,7 +189,8 @@ int gfe_conv1x1(const void* x, const void* w, const float* bias, void* y, int64_
                 float* stats_ws, int64_t stats_nblk, int64_t stats_slot0, void* stream) {
     GFE_REQUIRE(x && w && y, GFE_ERR_NULL);
     GFE_REQUIRE(B >= 1 && B <= 65535 && V >= 1 && (Cin == 64 || Cin == 128) && Cout >= 64 && Cout % 64 == 0, GFE_ERR_SHAPE);
-    GFE_REQUIRE(V * Cout * 2 < (int64_t)1 << 31 && Cout * Cin * 2 < (int64_t)1 << 31, GFE_ERR_SHAPE);        // 32-bit buffer offsets per sample
+    GFE_REQUIRE(V * Cout * 2 < (int64_t)1 << 31 && V * Cin * 2 < (int64_t)1 << 31 && Cout * Cin * 2 < (int64_t)1 << 31, GFE_ERR_SHAPE);   // 32-bit buffer offsets per sample
+    GFE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0, GFE_ERR_SHAPE);   // 16-byte accesses
     C1Params p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.y = (bf16_t*)y; p.stats = stats_ws;
     p.V = (int)V; p.Cin = (int)Cin; p.Cout = (int)Cout; p.vb = c1_vb(V);

@@ -179,7 +179,7 @@ int gfe_conv3d_stat_slots(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Co
  * Replaces: the encoders' ResNetBlock.conv1 = nn.Conv3d(in, out, 1) (pytorch3dunet/unet3d/buildingblocks.py:204-208, applied at :218-229),
  * which rounds 1-5 ran through gfe_conv3d_igemm with a one-tap list.
  *   x: (B, V, Cin) bf16, V = D*H*W voxels per sample.  w: (Cout, Cin) bf16, the Conv3d weight as it is (no packing).  bias: (Cout) f32 or NULL.
- *   y: (B, V, Cout) bf16.  Cin in {64, 128}; Cout a multiple of 64 with Cout / 128 (Cin == 64 and Cout % 128 == 0) or Cout / 64 in {1, 2, 4}.
+ *   y: (B, V, Cout) bf16.  All four pointers 16-byte aligned, V * max(Cin, Cout) * 2 < 2^31.  Cin in {64, 128}; Cout a multiple of 64 with Cout / 128 (Cin == 64 and Cout % 128 == 0) or Cout / 64 in {1, 2, 4}.
  *   stats_ws (or NULL): GroupNorm partials of y, layout (B, stats_nblk, 2, Cout) f32 as gfe_conv3d_igemm's: the call writes EVERY element of
  *   slots stats_slot0 .. stats_slot0 + gfe_conv1x1_stat_slots(V) - 1 (one per block of a sample, <= 64 of them, a function of V alone; sums of the rounded
  *   outputs per 8 consecutive channels on the octet's first channel, zeros on the other seven), so the workspace needs no zero fill. */

@@ -69,6 +69,18 @@ def test_scan_kernels_keep_their_two_waves_per_simd(tmp_path):
         assert res[k]["LDS Size"] <= 160 * 1024, (k, res[k])
 
 
+def test_pointwise_conv_streams_from_registers_without_spills_or_lds_in_the_loop(tmp_path):
+    """csrc/conv1x1.hip: four-wave blocks, two per CU (`__launch_bounds__(256, 2)`): every instantiation within 256 registers, nothing in
+    scratch, and the only LDS is the 1-2 KB the GroupNorm partials are folded through at the block's end (operands go from global memory
+    straight into the MFMA registers)."""
+    res = _resources("conv1x1.hip", tmp_path)
+    ks = [k for k in res if "conv1x1_kernel" in k]
+    assert len(ks) == 6                               # (KS, NCT) in {(2, 8), (2, 4), (4, 4)} x {with, without statistics}
+    for k in ks:
+        assert res[k]["VGPRs"] <= 256 and res[k]["VGPRs Spill"] == 0 and res[k]["ScratchSize"] == 0, (k, res[k])
+        assert res[k]["LDS Size"] <= 2048, (k, res[k])
+
+
 def test_product_library_carries_no_diagnostic_switch(tmp_path):
     """the timing / ablation switches of csrc/ (GFE_EXP_*, CONVT_EXP_*, *_STAMPS) build diagnostic libraries only.
     (1) every switch the sources test is listed in csrc/diag_guard.h; (2) one of them without -DGFE_DIAG does not compile; (3) `make all`
